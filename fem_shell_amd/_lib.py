@@ -1,0 +1,66 @@
+"""ctypes binding of libfemshell_hip.so (include/femshell_hip.h). Fails loudly when the HIP
+library is missing -- there is NO CPU fallback on the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfemshell_hip.so")
+
+FS_WANT_K, FS_WANT_M, FS_WANT_KT, FS_WANT_FINT = 1, 2, 4, 8
+FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK = 0, 1
+
+_vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
+
+SIGNATURES = {
+    "fs_last_error": (ctypes.c_char_p, []),
+    "fs_device_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_int)]),
+    "fs_shell_quad_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
+                                           _vp, _vp, _vp, _vp]),
+    "fs_shell_quad_geom": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "fs_blk_expand": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "fs_csr_numeric": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "fs_vec_gather_sum": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "fs_csr_numeric_blk": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "fs_csr_pattern_blk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+class FemShellHipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FemShellHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().fs_last_error().decode(errors="replace")
+        raise FemShellHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

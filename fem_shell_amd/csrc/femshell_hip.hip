@@ -1,0 +1,860 @@
+// femshell_hip.hip -- MI355X (gfx950) kernels + C ABI for the element-matrix / CSR-assembly hot path.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC   (csrc/Makefile)
+//
+// -ffp-contract=off is the file default because the GEOMETRY stage (local frame, local
+// coordinates, characteristic vectors, Jacobians, tangent vectors) reproduces the reference's
+// rounding sequence bit for bit (parity floor is eps*L/h, so a differently
+// rounded geometry stage breaks 1e-12 parity on large meshes).  FMAs there are written explicitly
+// where NumPy/OpenBLAS uses them.  Everything downstream (B^T C B, condensation, T^T K T) only has
+// to agree at the eps level and opts back in to contraction with `#pragma clang fp contract(fast)`.
+//
+// Kernel design (DESIGN.md "mitc4_k"): fp64 VALU, 4 lanes per element (16 elements per wave).
+//   stage 1: lane g of a quad = Gauss point g: geometry (replicated), strain-displacement data of
+//            its Gauss point for the 4 nodes -> LDS (17 doubles per node, bank-conflict-free reads)
+//   stage 2: lane q of a quad = node-pair task (i<=j): 6x6 local block summed over the 4 Gauss
+//            points from LDS, bubble condensation, 3x3-block rotation to global axes, one
+//            contiguous 288-byte store (FS_LAYOUT_SYMBLK).  10 tasks per element in 3 rounds.
+// Citations: file:line relative to /root/reference/src/fem_shell/.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "femshell_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess)
+        snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+
+#define FS_LAUNCH_CHECK(name)                                         \
+    do {                                                              \
+        hipError_t e__ = hipGetLastError();                           \
+        if (e__ != hipSuccess) return fail(FS_EHIP, name, e__);       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// rounding-pinned primitives (file default: contraction OFF)
+// ------------------------------------------------------------------------------------------
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+__device__ __forceinline__ double dot3(const double *a, const double *b) {
+    // np.dot on contiguous length-3 float64 == sequential FMA chain
+    double s = a[0] * b[0];
+    s = FMA(a[1], b[1], s);
+    s = FMA(a[2], b[2], s);
+    return s;
+}
+__device__ __forceinline__ double dots4(double a0, double a1, double a2, double a3, double b0,
+                                        double b1, double b2, double b3) {
+    // np.dot(dN, xl[:, k]) (strided operand, n = 4): OpenBLAS generic-stride ddot
+    double m2 = a2 * b2, m3 = a3 * b3;
+    double t1 = FMA(a0, b0, m2), t2 = FMA(a1, b1, m3);
+    return t1 + t2;
+}
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
+    // np.cross: rounded products, then subtraction
+    double p, q;
+    p = a[1] * b[2]; q = a[2] * b[1]; c[0] = p - q;
+    p = a[2] * b[0]; q = a[0] * b[2]; c[1] = p - q;
+    p = a[0] * b[1]; q = a[1] * b[0]; c[2] = p - q;
+}
+__device__ __forceinline__ double norm3(const double *a) { return __builtin_sqrt(dot3(a, a)); }
+
+constexpr double kGP = 0.57735026918962584;  // 1.0/np.sqrt(3.0)  (MITC4.py:87)
+
+struct QuadGeom {
+    double e1[3], e2[3], e3[3];
+    double xl[4][2];
+    double a[5];  // a_A..a_E
+    int status;
+};
+
+// MITC4.py:436-476 (_compute_local_coordinates) + :157-208 (characteristic vectors, coefficients)
+__device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom &g) {
+    g.status = 0;
+    double v1[3], v2[3], c1[3], c2[3], n1[3], n2[3];
+    for (int k = 0; k < 3; k++) { v1[k] = x[1][k] - x[0][k]; v2[k] = x[2][k] - x[0][k]; }
+    cross3(v1, v2, c1);
+    const double l1 = norm3(c1);
+    const bool ok1 = l1 > 1e-12;
+    for (int k = 0; k < 3; k++) n1[k] = c1[k] / l1;
+    for (int k = 0; k < 3; k++) { v1[k] = x[2][k] - x[0][k]; v2[k] = x[3][k] - x[0][k]; }
+    cross3(v1, v2, c2);
+    const double l2 = norm3(c2);
+    const bool ok2 = l2 > 1e-12;
+    for (int k = 0; k < 3; k++) n2[k] = c2[k] / l2;
+    double e3[3];
+    for (int k = 0; k < 3; k++) {
+        const double both = (n1[k] + n2[k]) / 2.0;
+        e3[k] = (ok1 && ok2) ? both : (ok1 ? n1[k] : (ok2 ? n2[k] : (k == 2 ? 1.0 : 0.0)));
+    }
+    if (ok1 || ok2) {
+        const double l = norm3(e3);
+        for (int k = 0; k < 3; k++) e3[k] = e3[k] / l;
+    }
+    double e1[3];
+    for (int k = 0; k < 3; k++) e1[k] = x[1][k] - x[0][k];
+    double d = dot3(e1, e3);
+    for (int k = 0; k < 3; k++) { const double t = d * e3[k]; e1[k] = e1[k] - t; }
+    if (norm3(e1) < 1e-12) {
+        for (int k = 0; k < 3; k++) e1[k] = x[2][k] - x[0][k];
+        d = dot3(e1, e3);
+        for (int k = 0; k < 3; k++) { const double t = d * e3[k]; e1[k] = e1[k] - t; }
+    }
+    double l = norm3(e1);
+    for (int k = 0; k < 3; k++) e1[k] = e1[k] / l;
+    double e2[3];
+    cross3(e3, e1, e2);
+    l = norm3(e2);
+    for (int k = 0; k < 3; k++) e2[k] = e2[k] / l;
+    for (int k = 0; k < 3; k++) { g.e1[k] = e1[k]; g.e2[k] = e2[k]; g.e3[k] = e3[k]; }
+    for (int i = 0; i < 4; i++) { g.xl[i][0] = dot3(x[i], e1); g.xl[i][1] = dot3(x[i], e2); }
+    if (!(l == l) || !(g.xl[0][0] == g.xl[0][0])) g.status |= FS_ST_NAN_FRAME;
+
+    // characteristic vectors (Ko, Lee, Bathe 2017, eqs 9-12)
+    double xr[3], xs[3], xd[3], nv[3], nh[3];
+    for (int k = 0; k < 3; k++) {
+        xr[k] = 0.25 * (((-x[0][k] + x[1][k]) + x[2][k]) - x[3][k]);
+        xs[k] = 0.25 * (((-x[0][k] - x[1][k]) + x[2][k]) + x[3][k]);
+        xd[k] = 0.25 * (((x[0][k] - x[1][k]) + x[2][k]) - x[3][k]);
+    }
+    cross3(xr, xs, nv);
+    double nn = norm3(nv);
+    if (nn < 1e-12) {
+        double a[3], b[3];
+        for (int k = 0; k < 3; k++) { a[k] = x[1][k] - x[0][k]; b[k] = x[2][k] - x[0][k]; }
+        cross3(a, b, nv);
+        nn = norm3(nv);
+    }
+    for (int k = 0; k < 3; k++) nh[k] = nv[k] / nn;
+    const double A00 = dot3(xr, xr), A01 = dot3(xr, xs), A02 = dot3(xr, nh);
+    const double A10 = dot3(xs, xr), A11 = dot3(xs, xs), A12 = dot3(xs, nh);
+    const double A20 = dot3(nh, xr), A21 = dot3(nh, xs), A22 = dot3(nh, nh);
+    // dual vectors: np.linalg.solve(A, e_k) -> closed-form adjugate (eps-level difference only)
+    const double c00 = A11 * A22 - A12 * A21, c01 = A12 * A20 - A10 * A22, c02 = A10 * A21 - A11 * A20;
+    const double det = A00 * c00 + A01 * c01 + A02 * c02;
+    double mr[3], ms[3];
+    if (det != 0.0) {
+        const double c10 = A02 * A21 - A01 * A22, c11 = A00 * A22 - A02 * A20, c12 = A01 * A20 - A00 * A21;
+        const double r0 = c00 / det, r1 = c01 / det, r2 = c02 / det;
+        const double s0 = c10 / det, s1 = c11 / det, s2 = c12 / det;
+        for (int k = 0; k < 3; k++) {
+            mr[k] = r0 * xr[k] + r1 * xs[k] + r2 * nh[k];
+            ms[k] = s0 * xr[k] + s1 * xs[k] + s2 * nh[k];
+        }
+    } else {
+        for (int k = 0; k < 3; k++) { mr[k] = xr[k] / A00; ms[k] = xs[k] / A11; }
+    }
+    const double c_r = dot3(xd, mr), c_s = dot3(xd, ms);
+    double dd = c_r * c_r + c_s * c_s - 1.0;
+    if (__builtin_fabs(dd) < 1e-12) dd = (dd >= 0) ? 1e-12 : -1e-12;
+    g.a[0] = c_r * (c_r - 1.0) / (2.0 * dd);
+    g.a[1] = c_r * (c_r + 1.0) / (2.0 * dd);
+    g.a[2] = c_s * (c_s - 1.0) / (2.0 * dd);
+    g.a[3] = c_s * (c_s + 1.0) / (2.0 * dd);
+    g.a[4] = -2.0 * c_r * c_s / dd;
+    if (!(g.a[0] == g.a[0])) g.status |= FS_ST_BAD_COEFF;
+}
+
+// MITC4.py:141-155
+__device__ __forceinline__ void dshape(double xi, double eta, double *dxi, double *deta) {
+    dxi[0] = -0.25 * (1.0 - eta); dxi[1] = +0.25 * (1.0 - eta);
+    dxi[2] = +0.25 * (1.0 + eta); dxi[3] = -0.25 * (1.0 + eta);
+    deta[0] = -0.25 * (1.0 - xi); deta[1] = -0.25 * (1.0 + xi);
+    deta[2] = +0.25 * (1.0 + xi); deta[3] = +0.25 * (1.0 - xi);
+}
+
+// MITC4.py:614-632 (J) ; returns detJ, fills J^-1 = [[ia, ib],[ic, id]]
+__device__ __forceinline__ double jacobian(const QuadGeom &g, const double *dxi, const double *deta,
+                                           double &ia, double &ib, double &ic, double &id) {
+    const double J00 = dots4(dxi[0], dxi[1], dxi[2], dxi[3], g.xl[0][0], g.xl[1][0], g.xl[2][0], g.xl[3][0]);
+    const double J01 = dots4(dxi[0], dxi[1], dxi[2], dxi[3], g.xl[0][1], g.xl[1][1], g.xl[2][1], g.xl[3][1]);
+    const double J10 = dots4(deta[0], deta[1], deta[2], deta[3], g.xl[0][0], g.xl[1][0], g.xl[2][0], g.xl[3][0]);
+    const double J11 = dots4(deta[0], deta[1], deta[2], deta[3], g.xl[0][1], g.xl[1][1], g.xl[2][1], g.xl[3][1]);
+    const double p = J00 * J11, q = J01 * J10;
+    const double det = p - q;
+    ia = J11 / det; ib = -J01 / det; ic = -J10 / det; id = J00 / det;
+    return det;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS layout of one wave (16 elements): component-major, g-major, then a (node, quad) swizzle that
+// makes every stage-2 read (uniform component and Gauss point, per-lane node) conflict-free:
+// within a 32-lane group the 8 quads x 4 nodes map to 32 distinct double-banks.
+// ------------------------------------------------------------------------------------------
+constexpr int NC = 17;  // per (node, gp): Bm[3][3] | dNdx dNdy | Bs[2][3]
+constexpr int C_BM = 0, C_DN = 9, C_BS = 11;
+constexpr int LDS_DET = NC * 4 * 64;       // detJ[g][Q]
+constexpr int LDS_KNB = LDS_DET + 64;      // condensation rows Knb[c<6][node][Q]
+constexpr int LDS_WAVE = LDS_KNB + 6 * 64; // 4800 doubles = 38400 B
+
+__device__ __forceinline__ int lds_slot(int c, int g, int node, int Q) {
+    return ((c * 4 + g) << 6) + ((Q >> 3) << 5) + (node << 3) + (Q & 7);
+}
+
+__device__ __forceinline__ double quad_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// MITC4+ stiffness, FS_LAYOUT_SYMBLK output
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
+                                                     const int32_t *__restrict__ prop_id,
+                                                     const fs_shell_prop *__restrict__ props,
+                                                     int64_t E, double *__restrict__ out,
+                                                     int32_t *__restrict__ status) {
+    __shared__ double lds[LDS_WAVE];
+    const int lane = threadIdx.x;
+    const int Q = lane >> 2, g = lane & 3;
+    const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
+    const bool valid = e_raw < E;
+    const int64_t e = valid ? e_raw : (E - 1);
+
+    double x[4][3];
+    {
+        const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
+        for (int t = 0; t < 6; t++) {
+            const double2 v = p[t];
+            (&x[0][0])[2 * t] = v.x;
+            (&x[0][0])[2 * t + 1] = v.y;
+        }
+    }
+    const fs_shell_prop *pr = props + prop_id[e];
+
+    QuadGeom geo;
+    quad_geometry(x, geo);
+
+    // ---------------- stage 1: Gauss point g ----------------
+    const double xi = (g == 1 || g == 2) ? kGP : -kGP;
+    const double eta = (g >= 2) ? kGP : -kGP;
+    double dxi[4], deta[4];
+    dshape(xi, eta, dxi, deta);
+    double ia, ib, ic, id;
+    const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
+    int st = geo.status | ((detJ > 0.0) ? 0 : FS_ST_BAD_JAC);
+
+    // tangent vectors at the 5 tying points (MITC4.py:589-612 evaluated at A,B,C,D,E; the zero
+    // shape-derivative terms are dropped, which is exact), projected on the frame (:287-296)
+    double grA[3], grB[3], gsC[3], gsD[3], grE[3], gsE[3];
+    {
+        double t3[3];
+        for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
+        grA[0] = dot3(t3, geo.e1); grA[1] = dot3(t3, geo.e2); grA[2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
+        grB[0] = dot3(t3, geo.e1); grB[1] = dot3(t3, geo.e2); grB[2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
+        gsC[0] = dot3(t3, geo.e1); gsC[1] = dot3(t3, geo.e2); gsC[2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
+        gsD[0] = dot3(t3, geo.e1); gsD[1] = dot3(t3, geo.e2); gsD[2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
+        grE[0] = dot3(t3, geo.e1); grE[1] = dot3(t3, geo.e2); grE[2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
+        gsE[0] = dot3(t3, geo.e1); gsE[1] = dot3(t3, geo.e2); gsE[2] = dot3(t3, geo.e3);
+    }
+
+    const int qoff = ((Q >> 3) << 5) + (Q & 7);
+    double knb[4][3][2];  // partial Knb of this Gauss point: node, (w,thx,thy), bubble
+    double kbb00, kbb01, kbb11;
+    {
+#pragma clang fp contract(fast)
+        // shape-function derivatives in local axes (MITC4.py:642-657)
+        double dNx[4], dNy[4];
+        for (int i = 0; i < 4; i++) {
+            dNx[i] = ia * dxi[i] + ib * deta[i];
+            dNy[i] = ic * dxi[i] + id * deta[i];
+        }
+        // ---- MITC4+ membrane (MITC4.py:351-392): W = T_eps * blend (3x5) ----
+        const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
+        const double r = xi, s = eta;
+        double bl[3][5];
+        bl[0][0] = 0.5 * (1.0 - 2.0 * aA + s + 2.0 * aA * s * s);
+        bl[0][1] = 0.5 * (1.0 - 2.0 * aB - s + 2.0 * aB * s * s);
+        bl[0][2] = aC * (-1.0 + s * s);
+        bl[0][3] = aD * (-1.0 + s * s);
+        bl[0][4] = aE * (-1.0 + s * s);
+        bl[1][0] = aA * (-1.0 + r * r);
+        bl[1][1] = aB * (-1.0 + r * r);
+        bl[1][2] = 0.5 * (1.0 - 2.0 * aC + r + 2.0 * aC * r * r);
+        bl[1][3] = 0.5 * (1.0 - 2.0 * aD - r + 2.0 * aD * r * r);
+        bl[1][4] = aE * (-1.0 + r * r);
+        bl[2][0] = 2.0 * (0.25 * (r + 4.0 * aA * r * s));
+        bl[2][1] = 2.0 * (0.25 * (-r + 4.0 * aB * r * s));
+        bl[2][2] = 2.0 * (0.25 * (s + 4.0 * aC * r * s));
+        bl[2][3] = 2.0 * (0.25 * (-s + 4.0 * aD * r * s));
+        bl[2][4] = 2.0 * (1.0 + aE * r * s);
+        double Te[3][3];
+        if (__builtin_fabs(detJ) < 1e-12) {  // MITC4.py:331-332
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) Te[a][b] = (a == b) ? 1.0 : 0.0;
+        } else {  // MITC4.py:334-347
+            Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
+            Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
+            Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
+        }
+        double W[3][5];
+        for (int a = 0; a < 3; a++)
+            for (int t = 0; t < 5; t++) W[a][t] = Te[a][0] * bl[0][t] + Te[a][1] * bl[1][t] + Te[a][2] * bl[2][t];
+        // tying shape-derivative constants: dN/dxi at A,B ; dN/deta at C,D ; both at E
+        const double dA[4] = {0.0, 0.0, 0.5, -0.5}, dB[4] = {-0.5, 0.5, 0.0, 0.0};
+        const double dC[4] = {0.0, -0.5, 0.5, 0.0}, dD[4] = {-0.5, 0.0, 0.0, 0.5};
+        const double dEx[4] = {-0.25, 0.25, 0.25, -0.25}, dEe[4] = {-0.25, -0.25, 0.25, 0.25};
+        for (int i = 0; i < 4; i++) {
+            double Y[5][3];
+            for (int k = 0; k < 3; k++) {
+                Y[0][k] = grA[k] * dA[i];
+                Y[1][k] = grB[k] * dB[i];
+                Y[2][k] = gsC[k] * dC[i];
+                Y[3][k] = gsD[k] * dD[i];
+                Y[4][k] = 0.5 * (grE[k] * dEe[i] + gsE[k] * dEx[i]);
+            }
+            for (int a = 0; a < 3; a++)
+                for (int k = 0; k < 3; k++) {
+                    double v = W[a][0] * Y[0][k];
+                    v += W[a][1] * Y[1][k];
+                    v += W[a][2] * Y[2][k];
+                    v += W[a][3] * Y[3][k];
+                    v += W[a][4] * Y[4][k];
+                    lds[lds_slot(C_BM + a * 3 + k, g, i, 0) + qoff] = v;
+                }
+            lds[lds_slot(C_DN + 0, g, i, 0) + qoff] = dNx[i];
+            lds[lds_slot(C_DN + 1, g, i, 0) + qoff] = dNy[i];
+        }
+        // ---- MITC4 edge-tied shear (MITC4.py:792-878) ----
+        const auto &xl = geo.xl;
+        double Ax, Bx, Cx, Ay, By, Cy;
+        double ex[4], ey[4];  // edge deltas: 0: 41, 1: 21, 2: 32, 3: 34
+        {
+#pragma clang fp contract(off)
+            ex[0] = xl[3][0] - xl[0][0]; ey[0] = xl[3][1] - xl[0][1];
+            ex[1] = xl[1][0] - xl[0][0]; ey[1] = xl[1][1] - xl[0][1];
+            ex[2] = xl[2][0] - xl[1][0]; ey[2] = xl[2][1] - xl[1][1];
+            ex[3] = xl[2][0] - xl[3][0]; ey[3] = xl[2][1] - xl[3][1];
+            Ax = ((-xl[0][0] + xl[1][0]) + xl[2][0]) - xl[3][0];
+            Bx = ((xl[0][0] - xl[1][0]) + xl[2][0]) - xl[3][0];
+            Cx = ((-xl[0][0] - xl[1][0]) + xl[2][0]) + xl[3][0];
+            Ay = ((-xl[0][1] + xl[1][1]) + xl[2][1]) - xl[3][1];
+            By = ((xl[0][1] - xl[1][1]) + xl[2][1]) - xl[3][1];
+            Cy = ((-xl[0][1] - xl[1][1]) + xl[2][1]) + xl[3][1];
+        }
+        // Rot = [[sin b, -sin a], [-cos b, cos a]], a = atan2(Ay,Ax), b = pi/2 - atan2(Cx,Cy)
+        const double nA = __builtin_sqrt(Ax * Ax + Ay * Ay), nC = __builtin_sqrt(Cx * Cx + Cy * Cy);
+        const double sa = Ay / nA, ca = Ax / nA, sb = Cy / nC, cb = Cx / nC;
+        double r1, r2;
+        {
+#pragma clang fp contract(off)
+            const double p0 = Cx + xi * Bx, p1 = Cy + xi * By;
+            r1 = __builtin_sqrt(FMA(p1, p1, p0 * p0));
+            const double q0 = Ax + eta * Bx, q1 = Ay + eta * By;
+            r2 = __builtin_sqrt(FMA(q1, q1, q0 * q0));
+        }
+        const double f1 = r1 / (8.0 * detJ), f2 = r2 / (8.0 * detJ);
+        // node -> (edge of row 0 [eta-edges 21/34], weight), (edge of row 1 [xi-edges 41/32], weight)
+        const double me = 1.0 - eta, pe = 1.0 + eta, mx = 1.0 - xi, px = 1.0 + xi;
+        const int e0[4] = {1, 1, 3, 3}, e1[4] = {0, 2, 2, 0};
+        const double w0[4] = {me, me, pe, pe}, w1[4] = {mx, px, px, mx};
+        const double h0[4] = {-0.5, 0.5, 0.5, -0.5};  // G row of eta-edges: w coefficient
+        const double h1[4] = {-0.5, -0.5, 0.5, 0.5};  // G row of xi-edges: w coefficient
+        double Bs[4][2][3];
+        for (int i = 0; i < 4; i++) {
+            const double a0 = w0[i] * f1, a1 = w1[i] * f2;
+            const double v0[3] = {a0 * h0[i], a0 * (-ey[e0[i]] * 0.25), a0 * (ex[e0[i]] * 0.25)};
+            const double v1[3] = {a1 * h1[i], a1 * (-ey[e1[i]] * 0.25), a1 * (ex[e1[i]] * 0.25)};
+            for (int k = 0; k < 3; k++) {
+                Bs[i][0][k] = sb * v0[k] - sa * v1[k];
+                Bs[i][1][k] = -cb * v0[k] + ca * v1[k];
+                lds[lds_slot(C_BS + k, g, i, 0) + qoff] = Bs[i][0][k];
+                lds[lds_slot(C_BS + 3 + k, g, i, 0) + qoff] = Bs[i][1][k];
+            }
+        }
+        lds[LDS_DET + g * 16 + Q] = detJ;
+
+        // ---- bubble enrichment (MITC4.py:214-222, 880-907): partial Knb, Kbb of this GP ----
+        const double Cb00 = pr->D[0], Cb01 = pr->D[1], Cb02 = pr->D[2];
+        const double Cb10 = pr->D[3], Cb11 = pr->D[4], Cb12 = pr->D[5];
+        const double Cb20 = pr->D[6], Cb21 = pr->D[7], Cb22 = pr->D[8];
+        const double Cs00 = pr->Cs[0], Cs01 = pr->Cs[1], Cs10 = pr->Cs[2], Cs11 = pr->Cs[3];
+        const double Nb = (1.0 - xi * xi) * (1.0 - eta * eta);
+        const double dNbxi = -2.0 * xi * (1.0 - eta * eta), dNbeta = -2.0 * eta * (1.0 - xi * xi);
+        const double bx = ia * dNbxi + ib * dNbeta, by = ic * dNbxi + id * dNbeta;
+        // Bkb = [[0,bx],[-by,0],[-bx,by]] ; Cb*Bkb (3x2)
+        const double q00 = -Cb01 * by - Cb02 * bx, q01 = Cb00 * bx + Cb02 * by;
+        const double q10 = -Cb11 * by - Cb12 * bx, q11 = Cb10 * bx + Cb12 * by;
+        const double q20 = -Cb21 * by - Cb22 * bx, q21 = Cb20 * bx + Cb22 * by;
+        // Bsb = [[0,Nb],[-Nb,0]] ; Cs*Bsb (2x2)
+        const double s00 = -Cs01 * Nb, s01 = Cs00 * Nb, s10 = -Cs11 * Nb, s11 = Cs10 * Nb;
+        for (int i = 0; i < 4; i++) {
+            // Bk_i columns: thx = (0,-dNy,-dNx) ; thy = (dNx,0,dNy) ; w = 0
+            const double kx0 = -dNy[i] * q10 - dNx[i] * q20, kx1 = -dNy[i] * q11 - dNx[i] * q21;
+            const double ky0 = dNx[i] * q00 + dNy[i] * q20, ky1 = dNx[i] * q01 + dNy[i] * q21;
+            for (int k = 0; k < 3; k++) {
+                double v0 = Bs[i][0][k] * s00 + Bs[i][1][k] * s10;
+                double v1 = Bs[i][0][k] * s01 + Bs[i][1][k] * s11;
+                if (k == 1) { v0 += kx0; v1 += kx1; }
+                if (k == 2) { v0 += ky0; v1 += ky1; }
+                knb[i][k][0] = detJ * v0;
+                knb[i][k][1] = detJ * v1;
+            }
+        }
+        // Kbb = Bkb^T Cb Bkb + Bsb^T Cs Bsb
+        kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
+        kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
+        kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
+    }
+    // reduce the bubble blocks over the 4 Gauss points of the quad (every lane gets the sums)
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++) {
+            knb[i][k][0] = quad_sum(knb[i][k][0]);
+            knb[i][k][1] = quad_sum(knb[i][k][1]);
+        }
+    kbb00 = quad_sum(kbb00); kbb01 = quad_sum(kbb01); kbb11 = quad_sum(kbb11);
+    st |= __shfl_xor(st, 1);
+    st |= __shfl_xor(st, 2);
+    // lane g publishes Knb rows of node g
+    for (int i = 0; i < 4; i++)
+        if (i == g)
+            for (int k = 0; k < 3; k++) {
+                lds[LDS_KNB + ((2 * k) << 6) + (i << 3) + qoff] = knb[i][k][0];
+                lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 3) + qoff] = knb[i][k][1];
+            }
+    // Kbb^-1 (MITC4.py:994-998; singular -> no condensation)
+    const double kdet = kbb00 * kbb11 - kbb01 * kbb01;
+    const bool cond_ok = (kdet != 0.0) && (kdet == kdet);
+    const double i00 = cond_ok ? kbb11 / kdet : 0.0, i01 = cond_ok ? -kbb01 / kdet : 0.0,
+                 i11 = cond_ok ? kbb00 / kdet : 0.0;
+    if (status && valid && g == 0) status[e] = st;
+
+    __syncthreads();
+
+    // ---------------- stage 2: node-pair tasks ----------------
+    const double Cm[3][3] = {{pr->A[0], pr->A[1], pr->A[2]}, {pr->A[3], pr->A[4], pr->A[5]}, {pr->A[6], pr->A[7], pr->A[8]}};
+    const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
+    const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
+    const double kd = pr->k_drill;
+    const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
+    double Bl[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? pr->B[a * 3 + b] : 0.0;
+    const bool any_coupled = __any(coupled);
+    const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+
+    for (int round = 0; round < 3; round++) {
+#pragma clang fp contract(fast)
+        int ti, tj;
+        bool active = valid;
+        if (round == 0) { ti = g; tj = g; }
+        else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
+        else { ti = g & 1; tj = (g & 1) + 2; active = active && (g < 2); }
+        const int oi = (ti << 3) + qoff, oj = (tj << 3) + qoff;
+        // shape-function signs of nodes ti, tj (for N_i at the Gauss points)
+        const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
+        const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
+
+        double L[6][6];
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) L[a][b] = 0.0;
+
+        for (int gg = 0; gg < 4; gg++) {
+            const double w = lds[LDS_DET + gg * 16 + Q];
+            double bmi[3][3], bmj[3][3], bsi[2][3], bsj[2][3];
+            for (int c = 0; c < 9; c++) {
+                (&bmi[0][0])[c] = w * lds[((c * 4 + gg) << 6) + oi];
+                (&bmj[0][0])[c] = lds[((c * 4 + gg) << 6) + oj];
+            }
+            const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + oi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + oi];
+            const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + oj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + oj];
+            for (int c = 0; c < 6; c++) {
+                (&bsi[0][0])[c] = w * lds[(((C_BS + c) * 4 + gg) << 6) + oi];
+                (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + oj];
+            }
+            const double wdxi = w * dxi_, wdyi = w * dyi_;
+            // membrane: L[u,v,w][u,v,w] += w Bm_i^T Cm Bm_j            (MITC4.py:934-944)
+            double CB[3][3];
+            for (int rr = 0; rr < 3; rr++)
+                for (int b = 0; b < 3; b++)
+                    CB[rr][b] = Cm[rr][0] * bmj[0][b] + Cm[rr][1] * bmj[1][b] + Cm[rr][2] * bmj[2][b];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++)
+                    L[a][b] += bmi[0][a] * CB[0][b] + bmi[1][a] * CB[1][b] + bmi[2][a] * CB[2][b];
+            // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
+            double CK[3][2];
+            for (int rr = 0; rr < 3; rr++) {
+                CK[rr][0] = -(Cb[rr][1] * dyj + Cb[rr][2] * dxj);
+                CK[rr][1] = Cb[rr][0] * dxj + Cb[rr][2] * dyj;
+            }
+            for (int c = 0; c < 2; c++) {
+                L[3][3 + c] += -(wdyi * CK[1][c] + wdxi * CK[2][c]);
+                L[4][3 + c] += wdxi * CK[0][c] + wdyi * CK[2][c];
+            }
+            // shear: L[w,thx,thy][w,thx,thy] += w Bs_i^T Cs Bs_j        (MITC4.py:986)
+            double CS[2][3];
+            for (int rr = 0; rr < 2; rr++)
+                for (int b = 0; b < 3; b++) CS[rr][b] = Cs[rr][0] * bsj[0][b] + Cs[rr][1] * bsj[1][b];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) L[2 + a][2 + b] += bsi[0][a] * CS[0][b] + bsi[1][a] * CS[1][b];
+            // drilling: k w outer(Bd_i, Bd_j) on (u,v,thz)                (MITC4.py:909-928,1014)
+            const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
+            const double Ni = 0.25 * (1.0 + sxi * xg) * (1.0 + syi * yg);
+            const double Nj = 0.25 * (1.0 + sxj * xg) * (1.0 + syj * yg);
+            const double bdi[3] = {-0.5 * wdyi * kd, 0.5 * wdxi * kd, -Ni * (w * kd)};
+            const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
+            const int dm[3] = {0, 1, 5};
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) L[dm[a]][dm[b]] += bdi[a] * bdj[b];
+            // membrane-bending coupling (MITC4_composite.py:210-248, nodal-only form)
+            if (any_coupled) {
+                double LKj[3][2], LKi[3][2];
+                for (int rr = 0; rr < 3; rr++) {
+                    LKj[rr][0] = -(Bl[rr][1] * dyj + Bl[rr][2] * dxj);
+                    LKj[rr][1] = Bl[rr][0] * dxj + Bl[rr][2] * dyj;
+                    LKi[rr][0] = -(Bl[rr][1] * wdyi + Bl[rr][2] * wdxi);
+                    LKi[rr][1] = Bl[rr][0] * wdxi + Bl[rr][2] * wdyi;
+                }
+                for (int a = 0; a < 3; a++)
+                    for (int c = 0; c < 2; c++) {
+                        L[a][3 + c] += bmi[0][a] * LKj[0][c] + bmi[1][a] * LKj[1][c] + bmi[2][a] * LKj[2][c];
+                        L[3 + c][a] += LKi[0][c] * bmj[0][a] + LKi[1][c] * bmj[1][a] + LKi[2][c] * bmj[2][a];
+                    }
+            }
+        }
+        // bubble condensation: L[w,thx,thy][w,thx,thy] -= (Knb_i Kbb^-1) Knb_j^T (MITC4.py:996)
+        {
+            double ki[3][2], kj[3][2];
+            for (int k = 0; k < 3; k++) {
+                ki[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oi]; ki[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oi];
+                kj[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oj]; kj[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oj];
+            }
+            for (int a = 0; a < 3; a++) {
+                const double h0 = ki[a][0] * i00 + ki[a][1] * i01, h1 = ki[a][0] * i01 + ki[a][1] * i11;
+                for (int b = 0; b < 3; b++) L[2 + a][2 + b] -= h0 * kj[b][0] + h1 * kj[b][1];
+            }
+        }
+        // rotation to global axes, 3x3 block-wise: G = R^T X R  (MITC4.py:634-640,1032-1033)
+        double G[6][6];
+        for (int ba = 0; ba < 2; ba++)
+            for (int bb = 0; bb < 2; bb++) {
+                double Y[3][3];
+                for (int p = 0; p < 3; p++)
+                    for (int q = 0; q < 3; q++)
+                        Y[p][q] = R[0][p] * L[3 * ba][3 * bb + q] + R[1][p] * L[3 * ba + 1][3 * bb + q] + R[2][p] * L[3 * ba + 2][3 * bb + q];
+                for (int p = 0; p < 3; p++)
+                    for (int q = 0; q < 3; q++)
+                        G[3 * ba + p][3 * bb + q] = Y[p][0] * R[0][q] + Y[p][1] * R[1][q] + Y[p][2] * R[2][q];
+            }
+        if (round == 0) {  // diagonal block: K = 0.5 (K + K^T)  (MITC4.py:1034)
+            for (int a = 0; a < 6; a++)
+                for (int b = a + 1; b < 6; b++) {
+                    const double m = 0.5 * (G[a][b] + G[b][a]);
+                    G[a][b] = m; G[b][a] = m;
+                }
+        }
+        if (active) {
+            const int p = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
+            double2 *dst = reinterpret_cast<double2 *>(out + (e * 10 + p) * 36);
+            for (int t = 0; t < 18; t++) dst[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MITC4 consistent mass (MITC4.py:1038-1061), FS_LAYOUT_SYMBLK: one thread per (element, pair)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__ xyz,
+                                                      const int32_t *__restrict__ prop_id,
+                                                      const fs_shell_prop *__restrict__ props,
+                                                      int64_t E, double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * 10) return;
+    const int64_t e = t / 10;
+    const int p = (int)(t - e * 10);
+    const int pi[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, pj[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+    const int ti = pi[p], tj = pj[p];
+    double x[4][3];
+    for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
+    QuadGeom geo;
+    quad_geometry(x, geo);
+    const fs_shell_prop *pr = props + prop_id[e];
+    const double mt = pr->m_t, mr = pr->m_r;
+    const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
+    const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
+    double ct = 0.0, cr = 0.0;
+    for (int g = 0; g < 4; g++) {
+        const double xi = (g == 1 || g == 2) ? kGP : -kGP, eta = (g >= 2) ? kGP : -kGP;
+        double dxi[4], deta[4], ia, ib, ic, id;
+        dshape(xi, eta, dxi, deta);
+        const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
+        const double Ni = 0.25 * (1.0 + sxi * xi) * (1.0 + syi * eta);
+        const double Nj = 0.25 * (1.0 + sxj * xi) * (1.0 + syj * eta);
+        ct = ct + Ni * Nj * mt * 1.0 * detJ;  // val_t = N[i]*N[j]*m_trans*w*detJ
+        cr = cr + Ni * Nj * mr * 1.0 * detJ;
+    }
+    const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    double G[6][6];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) G[a][b] = 0.0;
+    for (int p3 = 0; p3 < 3; p3++)
+        for (int q = 0; q < 3; q++) {
+            // T^T (c I) T evaluated as ((R^T c) R): sum_k (R[k][p] c) R[k][q]
+            double st = 0.0, sr = 0.0;
+            for (int k = 0; k < 3; k++) {
+                st = FMA(R[k][p3] * ct, R[k][q], st);
+                sr = FMA(R[k][p3] * cr, R[k][q], sr);
+            }
+            G[p3][q] = st;
+            G[3 + p3][3 + q] = sr;
+        }
+    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
+    for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
+}
+
+// geometry probe for bit-exactness tests
+__global__ void mitc4_geom_kernel(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
+                                  double *acoef) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double x[4][3];
+    for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
+    QuadGeom geo;
+    quad_geometry(x, geo);
+    for (int k = 0; k < 3; k++) {
+        frame[e * 9 + k] = geo.e1[k]; frame[e * 9 + 3 + k] = geo.e2[k]; frame[e * 9 + 6 + k] = geo.e3[k];
+    }
+    for (int i = 0; i < 4; i++) { xl[e * 8 + 2 * i] = geo.xl[i][0]; xl[e * 8 + 2 * i + 1] = geo.xl[i][1]; }
+    for (int g = 0; g < 4; g++) {
+        const double xi = (g == 1 || g == 2) ? kGP : -kGP, eta = (g >= 2) ? kGP : -kGP;
+        double dxi[4], deta[4], ia, ib, ic, id;
+        dshape(xi, eta, dxi, deta);
+        detJ[e * 4 + g] = jacobian(geo, dxi, deta, ia, ib, ic, id);
+    }
+    for (int k = 0; k < 5; k++) acoef[e * 5 + k] = geo.a[k];
+}
+
+// FS_LAYOUT_SYMBLK -> dense [E][nn*d][nn*d]
+__global__ void blk_expand_kernel(const double *__restrict__ packed, int64_t E, int nn, int d,
+                                  double *__restrict__ dense) {
+    const int nd = nn * d;
+    const int64_t total = E * nd * nd;
+    const int npair = nn * (nn + 1) / 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = t / (nd * nd);
+        const int rc = (int)(t - e * nd * nd);
+        const int r = rc / nd, c = rc - r * nd;
+        int i = r / d, k = r - i * d, j = c / d, l = c - j * d;
+        if (i > j) { int tmp = i; i = j; j = tmp; tmp = k; k = l; l = tmp; }
+        const int p = i * nn - (i * (i - 1)) / 2 + (j - i);
+        dense[t] = packed[(e * npair + p) * (d * d) + k * d + l];
+    }
+}
+
+// generic segmented gather-sum (CSR values or vectors), one thread per destination slot
+__global__ void seg_gather_sum_kernel(const double *__restrict__ vals, const int64_t *__restrict__ src,
+                                      const int64_t *__restrict__ seg_ptr, int64_t n,
+                                      double *__restrict__ out) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lo = seg_ptr[s], hi = seg_ptr[s + 1];
+        double v = 0.0;
+        for (int64_t q = lo; q < hi; q++) v = v + vals[src[q]];  // element order == reference order
+        out[s] = v;
+    }
+}
+
+// node-pair block assembly: one thread per (block, k, l); blocks sorted by (I, J)
+template <int D>
+__global__ __launch_bounds__(256) void csr_numeric_blk_kernel(const double *__restrict__ vals,
+                                                              const int64_t *__restrict__ nbr_ptr,
+                                                              const int32_t *__restrict__ blk_row,
+                                                              const int64_t *__restrict__ blk_ptr,
+                                                              const int64_t *__restrict__ contrib,
+                                                              int64_t nblk, double *__restrict__ data) {
+    constexpr int DD = D * D;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * DD) return;
+    const int64_t b = t / DD;
+    const int kl = (int)(t - b * DD);
+    const int k = kl / D, l = kl - k * D;
+    const int lk = l * D + k;
+    const int64_t I = blk_row[b];
+    const int64_t r0 = nbr_ptr[I], m = nbr_ptr[I + 1] - r0;
+    const int64_t lo = blk_ptr[b], hi = blk_ptr[b + 1];
+    double v = 0.0;
+    for (int64_t q = lo; q < hi; q++) {
+        const int64_t c = contrib[q];
+        v = v + vals[(c >> 1) * DD + ((c & 1) ? lk : kl)];
+    }
+    data[DD * r0 + (int64_t)k * D * m + D * (b - r0) + l] = v;
+}
+
+template <int D>
+__global__ void csr_pattern_blk_kernel(const int64_t *__restrict__ nbr_ptr, const int32_t *__restrict__ blk_row,
+                                       const int32_t *__restrict__ nbr, int64_t n_nodes, int64_t nblk,
+                                       int64_t *__restrict__ indptr, int32_t *__restrict__ indices) {
+    constexpr int DD = D * D;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_nodes * D) {
+        const int64_t I = t / D;
+        const int k = (int)(t - I * D);
+        const int64_t r0 = nbr_ptr[I], m = nbr_ptr[I + 1] - r0;
+        indptr[t] = DD * r0 + (int64_t)k * D * m;
+        if (t == n_nodes * D - 1) indptr[t + 1] = DD * nbr_ptr[n_nodes];
+    }
+    if (t < nblk * DD) {
+        const int64_t b = t / DD;
+        const int kl = (int)(t - b * DD);
+        const int k = kl / D, l = kl - k * D;
+        const int64_t I = blk_row[b];
+        const int64_t r0 = nbr_ptr[I], m = nbr_ptr[I + 1] - r0;
+        indices[DD * r0 + (int64_t)k * D * m + D * (b - r0) + l] = nbr[b] * D + l;
+    }
+}
+
+__global__ void gather_dofs_kernel(const double *__restrict__ u, const int64_t *__restrict__ dofs,
+                                   int64_t n, double *__restrict__ ue) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (int64_t)gridDim.x * blockDim.x)
+        ue[t] = u[dofs[t]];
+}
+
+inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fs_last_error(void) { return g_err; }
+
+int fs_device_info(int device, char *name, int len, int *cu_count) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(FS_EHIP, "hipGetDeviceProperties", e);
+    if (name && len > 0) snprintf(name, len, "%s", prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FS_ENOSYS, "device is not gfx950");
+    return FS_OK;
+}
+
+int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                        int32_t n_props, const double *u_e, int64_t E, uint32_t want,
+                        uint32_t layout, double *Ke, double *Me, double *KTe, double *fe,
+                        int32_t *status, void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_quad_batch: bad sizes");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_shell_quad_batch: null input");
+    if (layout != FS_LAYOUT_SYMBLK)
+        return fail(FS_EINVAL, "fs_shell_quad_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
+    if (want & (FS_WANT_KT | FS_WANT_FINT)) {
+        (void)u_e; (void)KTe; (void)fe;
+        return fail(FS_ENOSYS, "fs_shell_quad_batch: KT/FINT not built yet");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (want & FS_WANT_K) {
+        if (!Ke) return fail(FS_EINVAL, "fs_shell_quad_batch: Ke is null");
+        const unsigned grid = (unsigned)((E + 15) / 16);
+        hipLaunchKernelGGL(mitc4_k_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
+        FS_LAUNCH_CHECK("mitc4_k_kernel");
+    }
+    if (want & FS_WANT_M) {
+        if (!Me) return fail(FS_EINVAL, "fs_shell_quad_batch: Me is null");
+        hipLaunchKernelGGL(mitc4_m_kernel, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz,
+                           prop_id, props, E, Me);
+        FS_LAUNCH_CHECK("mitc4_m_kernel");
+    }
+    return FS_OK;
+}
+
+int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
+                       double *acoef, void *stream) {
+    if (E <= 0) return E == 0 ? FS_OK : fail(FS_EINVAL, "fs_shell_quad_geom: E < 0");
+    hipLaunchKernelGGL(mitc4_geom_kernel, dim3(grid_for(E, 64, INT32_MAX)), dim3(64), 0, (hipStream_t)stream,
+                       xyz, E, frame, xl, detJ, acoef);
+    FS_LAUNCH_CHECK("mitc4_geom_kernel");
+    return FS_OK;
+}
+
+int fs_blk_expand(const double *packed, int64_t E, int32_t nn, int32_t d, double *dense, void *stream) {
+    if (E <= 0) return E == 0 ? FS_OK : fail(FS_EINVAL, "fs_blk_expand: E < 0");
+    if (nn <= 0 || d <= 0) return fail(FS_EINVAL, "fs_blk_expand: bad nn/d");
+    hipLaunchKernelGGL(blk_expand_kernel, dim3(grid_for(E * nn * d * nn * d, 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, packed, E, nn, d, dense);
+    FS_LAUNCH_CHECK("blk_expand_kernel");
+    return FS_OK;
+}
+
+int fs_csr_numeric(const double *vals, const int64_t *src, const int64_t *seg_ptr, int64_t nnz,
+                   double *data, void *stream) {
+    if (nnz <= 0) return nnz == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric: nnz < 0");
+    hipLaunchKernelGGL(seg_gather_sum_kernel, dim3(grid_for(nnz, 256, 1 << 16)), dim3(256), 0,
+                       (hipStream_t)stream, vals, src, seg_ptr, nnz, data);
+    FS_LAUNCH_CHECK("seg_gather_sum_kernel");
+    return FS_OK;
+}
+
+int fs_vec_gather_sum(const double *vals, const int64_t *src, const int64_t *seg_ptr, int64_t n,
+                      double *out, void *stream) {
+    return fs_csr_numeric(vals, src, seg_ptr, n, out, stream);
+}
+
+int fs_csr_numeric_blk(const double *vals, const int64_t *nbr_ptr, const int32_t *blk_row,
+                       const int64_t *blk_ptr, const int64_t *contrib, int64_t nblk, int32_t d,
+                       double *data, void *stream) {
+    if (nblk <= 0) return nblk == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric_blk: nblk < 0");
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 6) {
+        hipLaunchKernelGGL(csr_numeric_blk_kernel<6>, dim3(grid_for(nblk * 36, 256, INT32_MAX)), dim3(256), 0, s,
+                           vals, nbr_ptr, blk_row, blk_ptr, contrib, nblk, data);
+    } else if (d == 3) {
+        hipLaunchKernelGGL(csr_numeric_blk_kernel<3>, dim3(grid_for(nblk * 9, 256, INT32_MAX)), dim3(256), 0, s,
+                           vals, nbr_ptr, blk_row, blk_ptr, contrib, nblk, data);
+    } else {
+        return fail(FS_EINVAL, "fs_csr_numeric_blk: d must be 3 or 6");
+    }
+    FS_LAUNCH_CHECK("csr_numeric_blk_kernel");
+    return FS_OK;
+}
+
+int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int32_t *nbr,
+                       int64_t n_nodes, int64_t nblk, int32_t d, int64_t *indptr, int32_t *indices,
+                       void *stream) {
+    if (n_nodes <= 0 || nblk < 0) return fail(FS_EINVAL, "fs_csr_pattern_blk: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (nblk * d * d > n_nodes * d) ? nblk * d * d : n_nodes * d;
+    if (d == 6) {
+        hipLaunchKernelGGL(csr_pattern_blk_kernel<6>, dim3(grid_for(n, 256, INT32_MAX)), dim3(256), 0, s, nbr_ptr,
+                           blk_row, nbr, n_nodes, nblk, indptr, indices);
+    } else if (d == 3) {
+        hipLaunchKernelGGL(csr_pattern_blk_kernel<3>, dim3(grid_for(n, 256, INT32_MAX)), dim3(256), 0, s, nbr_ptr,
+                           blk_row, nbr, n_nodes, nblk, indptr, indices);
+    } else {
+        return fail(FS_EINVAL, "fs_csr_pattern_blk: d must be 3 or 6");
+    }
+    FS_LAUNCH_CHECK("csr_pattern_blk_kernel");
+    return FS_OK;
+}
+
+int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream) {
+    if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_gather_dofs: n < 0");
+    hipLaunchKernelGGL(gather_dofs_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, u,
+                       dofs, n, u_e);
+    FS_LAUNCH_CHECK("gather_dofs_kernel");
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+/*
+ * femshell_hip.h -- C ABI of libfemshell_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the element-matrix + CSR-assembly hot path of efirvida/fem-shell.
+ * The reference has no FFI for this path (it is pure Python); each entry point below cites the
+ * reference routine (file:line relative to /root/reference/src/fem_shell/) whose per-element /
+ * per-mesh work it replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (hipMalloc / torch tensor) unless a
+ *     parameter is documented as host memory;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - return value: 0 on success, negative errno-style code on failure (never throws);
+ *     fs_last_error() returns a thread-local message for the last failure;
+ *   - per-element geometric failures (degenerate frame, non-positive Jacobian) are reported
+ *     through an int32 status[E] array (FS_ST_* bits), not through the return value.
+ */
+#ifndef FEMSHELL_HIP_H
+#define FEMSHELL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_OK 0
+#define FS_EINVAL (-22)
+#define FS_ENOSYS (-38)
+#define FS_EHIP (-5)
+
+/* `want` bits */
+#define FS_WANT_K 1u
+#define FS_WANT_M 2u
+#define FS_WANT_KT 4u
+#define FS_WANT_FINT 8u
+
+/* element-matrix layouts */
+#define FS_LAYOUT_DENSE 0u  /* [E][nd][nd] C-order == reference `_ke_array` (core/assembler.py:213-215) */
+#define FS_LAYOUT_SYMBLK 1u /* [E][npair][d*d]: node-pair blocks (i<=j) only, row-major d x d each;
+                               block (j,i) is the transpose.  pair index p(i,j)=i*nn-i*(i-1)/2+(j-i) */
+
+/* status[E] bits */
+#define FS_ST_NAN_FRAME 1   /* zero-area / zero-norm local frame (MITC4.py:436-476 silently NaNs) */
+#define FS_ST_BAD_COEFF 2   /* characteristic-vector solve failed (MITC4.py:186-193) */
+#define FS_ST_BAD_JAC 4     /* det J <= 0 at a Gauss point */
+
+/* property-table flags */
+#define FS_PROP_COUPLED 1   /* add membrane-bending coupling (MITC4_composite.py:98-99,206-248) */
+#define FS_PROP_LAMINATE 2  /* composite subclass (NL membrane stress uses (A e + B k)/h) */
+
+/* One row per distinct shell property (isotropic ShellProperty or CompositeShellProperty),
+ * built on the host by fem_shell_amd.properties.build_prop_table with the reference's own
+ * NumPy expressions (MITC4.py:671-734, MITC4_composite.py:172-204, core/laminate.py:336-452). */
+typedef struct fs_shell_prop {
+    double A[9];      /* Cm : membrane 3x3            */
+    double B[9];      /* laminate coupling 3x3 (0 iso) */
+    double D[9];      /* Cb : bending 3x3             */
+    double Cs[4];     /* transverse shear 2x2         */
+    double h;         /* total thickness              */
+    double m_t;       /* mass / area                  */
+    double m_r;       /* rotational inertia / area    */
+    double k_drill;   /* drilling stabilisation factor */
+    double C_raw[9];  /* membrane stress-strain (Cm/h) */
+    int32_t flags;    /* FS_PROP_*                    */
+    int32_t nonlinear;
+} fs_shell_prop;      /* 360 bytes */
+
+const char *fs_last_error(void);
+/* library / device probe: returns FS_OK when a gfx950 device is usable; fills name (<=len). */
+int fs_device_info(int device, char *name, int len, int *cu_count);
+
+/*
+ * MITC4+ batch.  Replaces, per element, MITC4.__init__/_compute_local_coordinates
+ * (elements/MITC4.py:52-127,436-476), K (:1018-1036 with k_m :934-944, _k_bending_shear
+ * :946-1000, k_drill :1002-1016, MITC4Composite._coupling_stiffness MITC4_composite.py:210-248),
+ * M (:1038-1061) and, with u_e, compute_tangent_stiffness / compute_internal_forces
+ * (:1246-1341, MITC4_composite.py:521-621) -- i.e. the body of the element loop of
+ * MeshAssembler._precompute_elements (core/assembler.py:121-193).
+ *   xyz     [E][4][3]  nodal coordinates (global axes)
+ *   prop_id [E]        row of `props`
+ *   props   [n_props]  property table (device)
+ *   u_e     [E][24]    element displacement vectors (global axes) or NULL (KT/FINT only)
+ *   Ke/Me/KTe          outputs in `layout` (NULL if not wanted); fe [E][24]
+ *   status  [E]        FS_ST_* bits (may be NULL)
+ */
+int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                        int32_t n_props, const double *u_e, int64_t E, uint32_t want,
+                        uint32_t layout, double *Ke, double *Me, double *KTe, double *fe,
+                        int32_t *status, void *stream);
+
+/* Geometry stage only, for bit-exactness tests against the oracle:
+ * frame[E][9] (e1,e2,e3), xl[E][8], detJ[E][4], acoef[E][5] (a_A..a_E). */
+int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
+                       double *acoef, void *stream);
+
+/* FS_LAYOUT_SYMBLK -> FS_LAYOUT_DENSE ([E][nn*d][nn*d]); nn nodes/element, d dofs/node. */
+int fs_blk_expand(const double *packed, int64_t E, int32_t nn, int32_t d, double *dense,
+                  void *stream);
+
+/*
+ * Numeric CSR assembly, generic form (any element mix).  Replaces the setValuesLocal(ADD_VALUES)
+ * loop + assemble() of MeshAssembler.assemble_stiffness_matrix / assemble_mass_matrix
+ * (core/assembler.py:269-336): data[s] = sum over q in [seg_ptr[s], seg_ptr[s+1]) of
+ * vals[src[q]], contributions ordered by element index (== the reference's insertion order).
+ */
+int fs_csr_numeric(const double *vals, const int64_t *src, const int64_t *seg_ptr, int64_t nnz,
+                   double *data, void *stream);
+
+/*
+ * Numeric CSR assembly, node-pair block form for meshes whose nodes all carry d dofs
+ * (d = 6 shells, 3 solids) and whose element matrices are in FS_LAYOUT_SYMBLK.
+ *   nbr_ptr [N+1]      node-graph row pointer (block rows)
+ *   blk_row [nblk]     block-row (node I) of each node-pair block, blocks sorted by (I,J)
+ *   blk_ptr [nblk+1]   contributions of each block
+ *   contrib [ncontrib] (index of the d*d source block in `vals`) << 1 | transposed, sorted by
+ *                      element index inside each block
+ *   data               CSR values, rows = d*I+k, row-major, sorted columns:
+ *                      data[d*d*nbr_ptr[I] + k*d*m_I + d*r + l], r = rank of J among I's neighbours
+ */
+int fs_csr_numeric_blk(const double *vals, const int64_t *nbr_ptr, const int32_t *blk_row,
+                       const int64_t *blk_ptr, const int64_t *contrib, int64_t nblk, int32_t d,
+                       double *data, void *stream);
+
+/* Symbolic companion of fs_csr_numeric_blk (pattern of core/assembler.py:222-241 for uniform-d
+ * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph.
+ * nbr[nblk] = neighbour node J of each block. */
+int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int32_t *nbr,
+                       int64_t n_nodes, int64_t nblk, int32_t d, int64_t *indptr,
+                       int32_t *indices, void *stream);
+
+/* f[dof] = sum of fe contributions in element order (core/assembler.py:338-384 and the new
+ * assemble_internal_forces): same segmented form as fs_csr_numeric. */
+int fs_vec_gather_sum(const double *vals, const int64_t *src, const int64_t *seg_ptr,
+                      int64_t n, double *out, void *stream);
+
+/* u_e[e][a] = u[dofs[e][a]]  (gather for KT / f_int re-assembly) */
+int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

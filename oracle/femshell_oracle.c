@@ -1,0 +1,753 @@
+/*
+ * femshell_oracle.c -- scalar C restatement (ORACLE) of efirvida/fem-shell's MITC4+ element
+ * matrices and CSR assembly.  TEST INFRASTRUCTURE ONLY (see femshell_oracle.h).
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp -shared -fPIC (oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: the geometry stage reproduces the reference's rounding
+ * sequence (NumPy 2.2 + OpenBLAS 0.3.29 as measured in the build container):
+ *   np.dot on contiguous length-3/4 vectors = sequential FMA chain          -> dot3(), dotc4()
+ *   np.dot(dN, xl[:,k]) (strided operand, n=4) = fma(a0,b0,a2*b2)+fma(a1,b1,a3*b3) -> dots4()
+ *   np.cross = rounded products then subtraction (no FMA)                   -> cross3()
+ *   np.linalg.norm(v) = sqrt(dot(v,v))
+ * Everything downstream of the geometry stage follows the reference's operation structure with
+ * plain dense loops (agreement at the eps level is all that is required there).
+ *
+ * Citations are file:line relative to /root/reference/src/fem_shell/.
+ */
+#include "femshell_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------- rounding-pinned primitives ---------- */
+static inline double dot3(const double *a, const double *b) {
+    double s = a[0] * b[0];
+    s = fma(a[1], b[1], s);
+    s = fma(a[2], b[2], s);
+    return s;
+}
+static inline double dots4(const double *a, const double *b, int sb) { /* b strided */
+    double m2 = a[2] * b[2 * sb], m3 = a[3] * b[3 * sb];
+    double t1 = fma(a[0], b[0], m2), t2 = fma(a[1], b[sb], m3);
+    return t1 + t2;
+}
+static inline double dotc4(const double *a, const double *b) { /* both contiguous */
+    double s = a[0] * b[0];
+    s = fma(a[1], b[1], s);
+    s = fma(a[2], b[2], s);
+    s = fma(a[3], b[3], s);
+    return s;
+}
+static inline void cross3(const double *a, const double *b, double *c) {
+    double p, q;
+    p = a[1] * b[2]; q = a[2] * b[1]; c[0] = p - q;
+    p = a[2] * b[0]; q = a[0] * b[2]; c[1] = p - q;
+    p = a[0] * b[1]; q = a[1] * b[0]; c[2] = p - q;
+}
+static inline double norm3(const double *a) { return sqrt(dot3(a, a)); }
+
+typedef struct {
+    double x[4][3];
+    double e1[3], e2[3], e3[3];
+    double xl[4][2];
+    double aA, aB, aC, aD, aE;
+    int status;
+} geom_t;
+
+static const double GP = 0.57735026918962584; /* 1/sqrt(3) as computed by 1.0/np.sqrt(3.0) */
+
+static void dshape(double xi, double eta, double *dxi, double *deta) { /* MITC4.py:141-155 */
+    dxi[0] = -0.25 * (1.0 - eta); dxi[1] = +0.25 * (1.0 - eta);
+    dxi[2] = +0.25 * (1.0 + eta); dxi[3] = -0.25 * (1.0 + eta);
+    deta[0] = -0.25 * (1.0 - xi); deta[1] = -0.25 * (1.0 + xi);
+    deta[2] = +0.25 * (1.0 + xi); deta[3] = +0.25 * (1.0 - xi);
+}
+static void shape(double xi, double eta, double *N) { /* MITC4.py:133-139 */
+    N[0] = 0.25 * (1.0 - xi) * (1.0 - eta); N[1] = 0.25 * (1.0 + xi) * (1.0 - eta);
+    N[2] = 0.25 * (1.0 + xi) * (1.0 + eta); N[3] = 0.25 * (1.0 - xi) * (1.0 + eta);
+}
+
+/* MITC4.py:436-476 _compute_local_coordinates */
+static void local_frame(geom_t *g) {
+    double (*n)[3] = g->x;
+    double v1[3], v2[3], c[3], nrm[2][3];
+    int nn = 0;
+    for (int k = 0; k < 3; k++) { v1[k] = n[1][k] - n[0][k]; v2[k] = n[2][k] - n[0][k]; }
+    cross3(v1, v2, c);
+    double l = norm3(c);
+    if (l > 1e-12) { for (int k = 0; k < 3; k++) nrm[nn][k] = c[k] / l; nn++; }
+    for (int k = 0; k < 3; k++) { v1[k] = n[2][k] - n[0][k]; v2[k] = n[3][k] - n[0][k]; }
+    cross3(v1, v2, c);
+    l = norm3(c);
+    if (l > 1e-12) { for (int k = 0; k < 3; k++) nrm[nn][k] = c[k] / l; nn++; }
+    double e3[3];
+    if (nn == 2) { for (int k = 0; k < 3; k++) e3[k] = (nrm[0][k] + nrm[1][k]) / 2.0; }
+    else if (nn == 1) { for (int k = 0; k < 3; k++) e3[k] = nrm[0][k] / 1.0; }
+    else { e3[0] = 0; e3[1] = 0; e3[2] = 1; }
+    if (nn) { l = norm3(e3); for (int k = 0; k < 3; k++) e3[k] = e3[k] / l; }
+    double e1[3];
+    for (int k = 0; k < 3; k++) e1[k] = n[1][k] - n[0][k];
+    double d = dot3(e1, e3);
+    for (int k = 0; k < 3; k++) { double t = d * e3[k]; e1[k] = e1[k] - t; }
+    if (norm3(e1) < 1e-12) {
+        for (int k = 0; k < 3; k++) e1[k] = n[2][k] - n[0][k];
+        d = dot3(e1, e3);
+        for (int k = 0; k < 3; k++) { double t = d * e3[k]; e1[k] = e1[k] - t; }
+    }
+    l = norm3(e1);
+    for (int k = 0; k < 3; k++) e1[k] = e1[k] / l;
+    double e2[3];
+    cross3(e3, e1, e2);
+    l = norm3(e2);
+    for (int k = 0; k < 3; k++) e2[k] = e2[k] / l;
+    memcpy(g->e1, e1, sizeof e1); memcpy(g->e2, e2, sizeof e2); memcpy(g->e3, e3, sizeof e3);
+    for (int i = 0; i < 4; i++) { g->xl[i][0] = dot3(n[i], e1); g->xl[i][1] = dot3(n[i], e2); }
+    if (!(l == l) || !(g->xl[0][0] == g->xl[0][0])) g->status |= 1; /* NaN frame */
+}
+
+static void solve3(const double A[3][3], const double *b, double *x, int *sing) {
+    /* np.linalg.solve on 3x3 (MITC4.py:187-188) -> closed-form adjugate; eps-level only */
+    double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    if (det == 0.0) { *sing = 1; return; }
+    double c10 = A[0][2] * A[2][1] - A[0][1] * A[2][2];
+    double c11 = A[0][0] * A[2][2] - A[0][2] * A[2][0];
+    double c12 = A[0][1] * A[2][0] - A[0][0] * A[2][1];
+    double c20 = A[0][1] * A[1][2] - A[0][2] * A[1][1];
+    double c21 = A[0][2] * A[1][0] - A[0][0] * A[1][2];
+    double c22 = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    x[0] = (c00 * b[0] + c10 * b[1] + c20 * b[2]) / det;
+    x[1] = (c01 * b[0] + c11 * b[1] + c21 * b[2]) / det;
+    x[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) / det;
+}
+
+/* MITC4.py:157-208 characteristic vectors + membrane coefficients */
+static void membrane_coeffs(geom_t *g) {
+    double (*n)[3] = g->x;
+    double xr[3], xs[3], xd[3], nv[3], nh[3];
+    for (int k = 0; k < 3; k++) {
+        xr[k] = 0.25 * (((-n[0][k] + n[1][k]) + n[2][k]) - n[3][k]);
+        xs[k] = 0.25 * (((-n[0][k] - n[1][k]) + n[2][k]) + n[3][k]);
+        xd[k] = 0.25 * (((n[0][k] - n[1][k]) + n[2][k]) - n[3][k]);
+    }
+    cross3(xr, xs, nv);
+    double nn = norm3(nv);
+    if (nn < 1e-12) {
+        double a[3], b[3];
+        for (int k = 0; k < 3; k++) { a[k] = n[1][k] - n[0][k]; b[k] = n[2][k] - n[0][k]; }
+        cross3(a, b, nv);
+        nn = norm3(nv);
+    }
+    for (int k = 0; k < 3; k++) nh[k] = nv[k] / nn;
+    double A[3][3] = {{dot3(xr, xr), dot3(xr, xs), dot3(xr, nh)},
+                      {dot3(xs, xr), dot3(xs, xs), dot3(xs, nh)},
+                      {dot3(nh, xr), dot3(nh, xs), dot3(nh, nh)}};
+    double b1[3] = {1, 0, 0}, b2[3] = {0, 1, 0}, cr[3], cs[3], mr[3], ms[3];
+    int sing = 0;
+    solve3(A, b1, cr, &sing);
+    solve3(A, b2, cs, &sing);
+    if (!sing) {
+        for (int k = 0; k < 3; k++) {
+            mr[k] = cr[0] * xr[k] + cr[1] * xs[k] + cr[2] * nh[k];
+            ms[k] = cs[0] * xr[k] + cs[1] * xs[k] + cs[2] * nh[k];
+        }
+    } else {
+        double drr = dot3(xr, xr), dss = dot3(xs, xs);
+        for (int k = 0; k < 3; k++) { mr[k] = xr[k] / drr; ms[k] = xs[k] / dss; }
+    }
+    double c_r = dot3(xd, mr), c_s = dot3(xd, ms);
+    double d = c_r * c_r + c_s * c_s - 1.0;
+    if (fabs(d) < 1e-12) d = (d >= 0) ? 1e-12 : -1e-12;
+    g->aA = c_r * (c_r - 1.0) / (2.0 * d);
+    g->aB = c_r * (c_r + 1.0) / (2.0 * d);
+    g->aC = c_s * (c_s - 1.0) / (2.0 * d);
+    g->aD = c_s * (c_s + 1.0) / (2.0 * d);
+    g->aE = -2.0 * c_r * c_s / d;
+    if (!(g->aA == g->aA)) g->status |= 2;
+}
+
+static void geom_init(geom_t *g, const double *xyz) {
+    memcpy(g->x, xyz, 12 * sizeof(double));
+    g->status = 0;
+    local_frame(g);
+    membrane_coeffs(g);
+}
+
+/* MITC4.py:614-632 J */
+static double jac(const geom_t *g, double xi, double eta, double J[2][2]) {
+    double dxi[4], deta[4];
+    dshape(xi, eta, dxi, deta);
+    const double *xl = &g->xl[0][0];
+    J[0][0] = dots4(dxi, xl, 2); J[0][1] = dots4(dxi, xl + 1, 2);
+    J[1][0] = dots4(deta, xl, 2); J[1][1] = dots4(deta, xl + 1, 2);
+    double p = J[0][0] * J[1][1], q = J[0][1] * J[1][0];
+    return p - q;
+}
+static void inv2(const double J[2][2], double det, double Ji[2][2]) {
+    Ji[0][0] = J[1][1] / det; Ji[0][1] = -J[0][1] / det;
+    Ji[1][0] = -J[1][0] / det; Ji[1][1] = J[0][0] / det;
+}
+/* MITC4.py:642-657 _get_dH */
+static double dH(const geom_t *g, double xi, double eta, double *dNdx, double *dNdy) {
+    double J[2][2], Ji[2][2], dxi[4], deta[4];
+    double det = jac(g, xi, eta, J);
+    inv2(J, det, Ji);
+    dshape(xi, eta, dxi, deta);
+    for (int i = 0; i < 4; i++) {
+        dNdx[i] = Ji[0][0] * dxi[i] + Ji[0][1] * deta[i];
+        dNdy[i] = Ji[1][0] * dxi[i] + Ji[1][1] * deta[i];
+    }
+    return det;
+}
+
+/* MITC4.py:589-612 J3D + :261-321 covariant rows. comp: 0 rr, 1 ss, 2 rs */
+static void cov_row(const geom_t *g, double xi, double eta, int comp, double *row) {
+    double dxi[4], deta[4], gr[3] = {0, 0, 0}, gs[3] = {0, 0, 0};
+    dshape(xi, eta, dxi, deta);
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++) {
+            double t = dxi[i] * g->x[i][k]; gr[k] = gr[k] + t;
+            t = deta[i] * g->x[i][k]; gs[k] = gs[k] + t;
+        }
+    double grl[3] = {dot3(gr, g->e1), dot3(gr, g->e2), dot3(gr, g->e3)};
+    double gsl[3] = {dot3(gs, g->e1), dot3(gs, g->e2), dot3(gs, g->e3)};
+    memset(row, 0, 24 * sizeof(double));
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++) {
+            if (comp == 0) row[6 * i + k] = grl[k] * dxi[i];
+            else if (comp == 1) row[6 * i + k] = gsl[k] * deta[i];
+            else row[6 * i + k] = 0.5 * (grl[k] * deta[i] + gsl[k] * dxi[i]);
+        }
+}
+
+/* MITC4.py:351-392 B_m_MITC4_plus -> Bm[3][24] */
+static void Bm_plus(const geom_t *g, double xi, double eta, double Bm[3][24]) {
+    double rrA[24], rrB[24], ssC[24], ssD[24], rsE[24];
+    cov_row(g, 0.0, 1.0, 0, rrA);
+    cov_row(g, 0.0, -1.0, 0, rrB);
+    cov_row(g, 1.0, 0.0, 1, ssC);
+    cov_row(g, -1.0, 0.0, 1, ssD);
+    cov_row(g, 0.0, 0.0, 2, rsE);
+    double aA = g->aA, aB = g->aB, aC = g->aC, aD = g->aD, aE = g->aE, r = xi, s = eta;
+    double Bc[3][24];
+    for (int c = 0; c < 24; c++) {
+        Bc[0][c] = (0.5 * (1.0 - 2.0 * aA + s + 2.0 * aA * s * s)) * rrA[c] +
+                   (0.5 * (1.0 - 2.0 * aB - s + 2.0 * aB * s * s)) * rrB[c] +
+                   aC * (-1.0 + s * s) * ssC[c] + aD * (-1.0 + s * s) * ssD[c] +
+                   aE * (-1.0 + s * s) * rsE[c];
+        Bc[1][c] = aA * (-1.0 + r * r) * rrA[c] + aB * (-1.0 + r * r) * rrB[c] +
+                   (0.5 * (1.0 - 2.0 * aC + r + 2.0 * aC * r * r)) * ssC[c] +
+                   (0.5 * (1.0 - 2.0 * aD - r + 2.0 * aD * r * r)) * ssD[c] +
+                   aE * (-1.0 + r * r) * rsE[c];
+        double brs = 0.25 * (r + 4.0 * aA * r * s) * rrA[c] + 0.25 * (-r + 4.0 * aB * r * s) * rrB[c] +
+                     0.25 * (s + 4.0 * aC * r * s) * ssC[c] + 0.25 * (-s + 4.0 * aD * r * s) * ssD[c] +
+                     (1.0 + aE * r * s) * rsE[c];
+        Bc[2][c] = 2.0 * brs;
+    }
+    /* MITC4.py:323-349 covariant -> cartesian */
+    double J[2][2], Ji[2][2], T[3][3];
+    double det = jac(g, xi, eta, J);
+    if (fabs(det) < 1e-12) {
+        memset(T, 0, sizeof T); T[0][0] = T[1][1] = T[2][2] = 1.0;
+    } else {
+        inv2(J, det, Ji);
+        double a = Ji[0][0], b = Ji[0][1], c = Ji[1][0], d = Ji[1][1];
+        T[0][0] = a * a; T[0][1] = c * c; T[0][2] = a * c;
+        T[1][0] = b * b; T[1][1] = d * d; T[1][2] = b * d;
+        T[2][0] = 2.0 * a * b; T[2][1] = 2.0 * c * d; T[2][2] = a * d + b * c;
+    }
+    for (int rr = 0; rr < 3; rr++)
+        for (int c = 0; c < 24; c++) {
+            double sum = 0;
+            for (int k = 0; k < 3; k++) sum = fma(T[rr][k], Bc[k][c], sum);
+            Bm[rr][c] = sum;
+        }
+}
+
+/* MITC4.py:756-772 standard B_m */
+static void Bm_std(const double *dNdx, const double *dNdy, double Bm[3][24]) {
+    memset(Bm, 0, 72 * sizeof(double));
+    for (int i = 0; i < 4; i++) {
+        Bm[0][6 * i] = dNdx[i]; Bm[1][6 * i + 1] = dNdy[i];
+        Bm[2][6 * i] = dNdy[i]; Bm[2][6 * i + 1] = dNdx[i];
+    }
+}
+/* MITC4.py:774-790 B_kappa */
+static void Bkappa(const double *dNdx, const double *dNdy, double Bk[3][24]) {
+    memset(Bk, 0, 72 * sizeof(double));
+    for (int i = 0; i < 4; i++) {
+        Bk[0][6 * i + 4] = dNdx[i]; Bk[1][6 * i + 3] = -dNdy[i];
+        Bk[2][6 * i + 4] = dNdy[i]; Bk[2][6 * i + 3] = -dNdx[i];
+    }
+}
+/* MITC4.py:792-878 B_gamma_MITC4 */
+static void Bgamma(const geom_t *g, double xi, double eta, double Bs[2][24]) {
+    const double (*xl)[2] = g->xl;
+    double dx34 = xl[2][0] - xl[3][0], dy34 = xl[2][1] - xl[3][1];
+    double dx21 = xl[1][0] - xl[0][0], dy21 = xl[1][1] - xl[0][1];
+    double dx32 = xl[2][0] - xl[1][0], dy32 = xl[2][1] - xl[1][1];
+    double dx41 = xl[3][0] - xl[0][0], dy41 = xl[3][1] - xl[0][1];
+    double G[4][12];
+    memset(G, 0, sizeof G);
+    G[0][0] = -0.5; G[0][1] = -dy41 * 0.25; G[0][2] = dx41 * 0.25;
+    G[0][9] = 0.5; G[0][10] = -dy41 * 0.25; G[0][11] = dx41 * 0.25;
+    G[1][0] = -0.5; G[1][1] = -dy21 * 0.25; G[1][2] = dx21 * 0.25;
+    G[1][3] = 0.5; G[1][4] = -dy21 * 0.25; G[1][5] = dx21 * 0.25;
+    G[2][3] = -0.5; G[2][4] = -dy32 * 0.25; G[2][5] = dx32 * 0.25;
+    G[2][6] = 0.5; G[2][7] = -dy32 * 0.25; G[2][8] = dx32 * 0.25;
+    G[3][6] = 0.5; G[3][7] = -dy34 * 0.25; G[3][8] = dx34 * 0.25;
+    G[3][9] = -0.5; G[3][10] = -dy34 * 0.25; G[3][11] = dx34 * 0.25;
+    double Ax = ((-xl[0][0] + xl[1][0]) + xl[2][0]) - xl[3][0];
+    double Bx = ((xl[0][0] - xl[1][0]) + xl[2][0]) - xl[3][0];
+    double Cx = ((-xl[0][0] - xl[1][0]) + xl[2][0]) + xl[3][0];
+    double Ay = ((-xl[0][1] + xl[1][1]) + xl[2][1]) - xl[3][1];
+    double By = ((xl[0][1] - xl[1][1]) + xl[2][1]) - xl[3][1];
+    double Cy = ((-xl[0][1] - xl[1][1]) + xl[2][1]) + xl[3][1];
+    double alph = atan2(Ay, Ax);
+    double beta = M_PI / 2.0 - atan2(Cx, Cy);
+    double Rot[2][2] = {{sin(beta), -sin(alph)}, {-cos(beta), cos(alph)}};
+    double Ms[2][4] = {{0, 1.0 - eta, 0, 1.0 + eta}, {1.0 - xi, 0, 1.0 + xi, 0}};
+    double Bsv[2][12];
+    for (int r = 0; r < 2; r++)
+        for (int j = 0; j < 12; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s = fma(Ms[r][k], G[k][j], s);
+            Bsv[r][j] = s;
+        }
+    double J[2][2];
+    double det = jac(g, xi, eta, J);
+    double p0 = Cx + xi * Bx, p1 = Cy + xi * By;
+    double r1 = sqrt(fma(p1, p1, p0 * p0));
+    double q0 = Ax + eta * Bx, q1 = Ay + eta * By;
+    double r2 = sqrt(fma(q1, q1, q0 * q0));
+    for (int j = 0; j < 12; j++) {
+        Bsv[0][j] = Bsv[0][j] * r1 / (8.0 * det);
+        Bsv[1][j] = Bsv[1][j] * r2 / (8.0 * det);
+    }
+    memset(Bs, 0, 48 * sizeof(double));
+    for (int r = 0; r < 2; r++)
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 3; k++)
+                Bs[r][6 * i + 2 + k] = fma(Rot[r][1], Bsv[1][3 * i + k], Rot[r][0] * Bsv[0][3 * i + k]);
+}
+
+static void gauss_point(int gp, double *xi, double *eta) { /* MITC4.py:87-88 */
+    static const double sx[4] = {-1, +1, +1, -1}, sy[4] = {-1, -1, +1, +1};
+    *xi = sx[gp] * GP; *eta = sy[gp] * GP;
+}
+
+/* acc[24][24] += s * Ba^T (ra x 24) C (ra x rb) Bb (rb x 24) */
+static void btcb(double *acc, double s, const double *Ba, int ra, const double *C, const double *Bb,
+                 int rb, int ncb) {
+    /* Ba: [ra][24]; Bb: [rb][ncb]; acc: [24][ncb] */
+    for (int i = 0; i < 24; i++) {
+        double t[6];
+        int any = 0;
+        for (int b = 0; b < rb; b++) {
+            double v = 0;
+            for (int a = 0; a < ra; a++) v += (s * Ba[a * 24 + i]) * C[a * rb + b];
+            t[b] = v; any |= (v != 0.0);
+        }
+        if (!any) continue;
+        for (int j = 0; j < ncb; j++) {
+            double v = 0;
+            for (int b = 0; b < rb; b++) v += t[b] * Bb[b * ncb + j];
+            acc[i * ncb + j] += v;
+        }
+    }
+}
+
+/* local-axis parts of MITC4.K: k_m (:934-944), _k_bending_shear (:946-1000), k_drill (:1002-1016),
+ * composite _coupling_stiffness (MITC4_composite.py:210-248; nodal-only form) */
+static void k_parts(const geom_t *g, const fso_shell_prop *p, double *km, double *kbs, double *kd,
+                    double *kc) {
+    double Knn[576], Knb[48], Kbb[4];
+    memset(km, 0, 576 * sizeof(double)); memset(Knn, 0, sizeof Knn);
+    memset(Knb, 0, sizeof Knb); memset(Kbb, 0, sizeof Kbb);
+    memset(kd, 0, 576 * sizeof(double));
+    if (kc) memset(kc, 0, 576 * sizeof(double));
+    for (int gp = 0; gp < 4; gp++) {
+        double xi, eta, dNdx[4], dNdy[4], N[4];
+        gauss_point(gp, &xi, &eta);
+        double det = dH(g, xi, eta, dNdx, dNdy);
+        double w = 1.0 * det;
+        double Bm[3][24], Bk[3][24], Bs[2][24];
+        Bm_plus(g, xi, eta, Bm);
+        btcb(km, w, &Bm[0][0], 3, p->A, &Bm[0][0], 3, 24);
+        Bkappa(dNdx, dNdy, Bk);
+        /* bubble: MITC4.py:214-222, 891-907, 880-889 */
+        double J[2][2], Ji[2][2];
+        jac(g, xi, eta, J); inv2(J, det, Ji);
+        double Nb = (1.0 - xi * xi) * (1.0 - eta * eta);
+        double dNbxi = -2.0 * xi * (1.0 - eta * eta), dNbeta = -2.0 * eta * (1.0 - xi * xi);
+        double dNbx = Ji[0][0] * dNbxi + Ji[0][1] * dNbeta, dNby = Ji[1][0] * dNbxi + Ji[1][1] * dNbeta;
+        double Bkb[3][2] = {{0, dNbx}, {-dNby, 0}, {-dNbx, dNby}};
+        double Bsb[2][2] = {{0, Nb}, {-Nb, 0}};
+        btcb(Knn, w, &Bk[0][0], 3, p->D, &Bk[0][0], 3, 24);
+        btcb(Knb, w, &Bk[0][0], 3, p->D, &Bkb[0][0], 3, 2);
+        Bgamma(g, xi, eta, Bs);
+        btcb(Knn, w, &Bs[0][0], 2, p->Cs, &Bs[0][0], 2, 24);
+        btcb(Knb, w, &Bs[0][0], 2, p->Cs, &Bsb[0][0], 2, 2);
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                double v = 0;
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) v += w * Bkb[r][a] * p->D[r * 3 + c] * Bkb[c][b];
+                for (int r = 0; r < 2; r++)
+                    for (int c = 0; c < 2; c++) v += w * Bsb[r][a] * p->Cs[r * 2 + c] * Bsb[c][b];
+                Kbb[a * 2 + b] += v;
+            }
+        /* drilling: MITC4.py:909-928, 1002-1016 */
+        shape(xi, eta, N);
+        double Bd[24];
+        memset(Bd, 0, sizeof Bd);
+        for (int i = 0; i < 4; i++) {
+            Bd[6 * i] = -0.5 * dNdy[i]; Bd[6 * i + 1] = 0.5 * dNdx[i]; Bd[6 * i + 5] = -N[i];
+        }
+        for (int i = 0; i < 24; i++)
+            for (int j = 0; j < 24; j++) kd[i * 24 + j] += w * p->k_drill * (Bd[i] * Bd[j]);
+        if (kc && (p->flags & FSO_PROP_COUPLED)) {
+            double tmp[576];
+            memset(tmp, 0, sizeof tmp);
+            btcb(tmp, w, &Bm[0][0], 3, p->B, &Bk[0][0], 3, 24);
+            for (int i = 0; i < 24; i++)
+                for (int j = 0; j < 24; j++) kc[i * 24 + j] += tmp[i * 24 + j] + tmp[j * 24 + i];
+        }
+    }
+    /* condensation MITC4.py:994-998 */
+    double det = Kbb[0] * Kbb[3] - Kbb[1] * Kbb[2];
+    memcpy(kbs, Knn, sizeof Knn);
+    if (det != 0.0 && det == det) {
+        double Ki[4] = {Kbb[3] / det, -Kbb[1] / det, -Kbb[2] / det, Kbb[0] / det};
+        for (int i = 0; i < 24; i++) {
+            double h0 = Knb[i * 2] * Ki[0] + Knb[i * 2 + 1] * Ki[2];
+            double h1 = Knb[i * 2] * Ki[1] + Knb[i * 2 + 1] * Ki[3];
+            for (int j = 0; j < 24; j++) kbs[i * 24 + j] -= h0 * Knb[j * 2] + h1 * Knb[j * 2 + 1];
+        }
+    }
+}
+
+/* T^T K T with T = blockdiag_8([e1;e2;e3]) (MITC4.py:634-640, 1032-1033) */
+static void rotate_to_global(const geom_t *g, const double *Kl, double *Kg) {
+    double R[3][3];
+    memcpy(R[0], g->e1, 24); memcpy(R[1], g->e2, 24); memcpy(R[2], g->e3, 24);
+    for (int bi = 0; bi < 8; bi++)
+        for (int bj = 0; bj < 8; bj++) {
+            double X[3][3], Y[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) X[a][b] = Kl[(3 * bi + a) * 24 + 3 * bj + b];
+            /* Y = R^T X */
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += R[k][a] * X[k][b];
+                    Y[a][b] = s;
+                }
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += Y[a][k] * R[k][b];
+                    Kg[(3 * bi + a) * 24 + 3 * bj + b] = s;
+                }
+        }
+}
+static void rotate_vec(const geom_t *g, const double *u, double *ul, int to_local) {
+    double R[3][3];
+    memcpy(R[0], g->e1, 24); memcpy(R[1], g->e2, 24); memcpy(R[2], g->e3, 24);
+    for (int b = 0; b < 8; b++)
+        for (int a = 0; a < 3; a++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (to_local ? R[a][k] : R[k][a]) * u[3 * b + k];
+            ul[3 * b + a] = s;
+        }
+}
+
+int fso_mitc4_geom(const double *xyz, double *e, double *xl, double *detJ, double *acoef) {
+    geom_t g;
+    geom_init(&g, xyz);
+    memcpy(e, g.e1, 24); memcpy(e + 3, g.e2, 24); memcpy(e + 6, g.e3, 24);
+    memcpy(xl, g.xl, 64);
+    for (int gp = 0; gp < 4; gp++) {
+        double xi, eta, J[2][2];
+        gauss_point(gp, &xi, &eta);
+        detJ[gp] = jac(&g, xi, eta, J);
+    }
+    acoef[0] = g.aA; acoef[1] = g.aB; acoef[2] = g.aC; acoef[3] = g.aD; acoef[4] = g.aE;
+    return g.status;
+}
+
+int fso_mitc4_K_parts(const double *xyz, const fso_shell_prop *p, double *km, double *kbs,
+                      double *kdrill, double *kcoup) {
+    geom_t g;
+    geom_init(&g, xyz);
+    k_parts(&g, p, km, kbs, kdrill, kcoup);
+    return g.status;
+}
+
+static void k_local(const geom_t *g, const fso_shell_prop *p, double *Kl, double *kbs_out,
+                    double *kd_out, double *kc_out) {
+    double km[576], kbs[576], kd[576], kc[576];
+    k_parts(g, p, km, kbs, kd, kc);
+    for (int i = 0; i < 576; i++) {
+        Kl[i] = km[i] + kbs[i] + kd[i];
+        if (p->flags & FSO_PROP_COUPLED) Kl[i] += kc[i];
+    }
+    if (kbs_out) memcpy(kbs_out, kbs, sizeof kbs);
+    if (kd_out) memcpy(kd_out, kd, sizeof kd);
+    if (kc_out) memcpy(kc_out, kc, sizeof kc);
+}
+
+int fso_mitc4_K(const double *xyz, const fso_shell_prop *p, double *Ke) {
+    geom_t g;
+    geom_init(&g, xyz);
+    double Kl[576], Kg[576];
+    k_local(&g, p, Kl, 0, 0, 0);
+    rotate_to_global(&g, Kl, Kg);
+    for (int i = 0; i < 24; i++)
+        for (int j = 0; j < 24; j++) Ke[i * 24 + j] = 0.5 * (Kg[i * 24 + j] + Kg[j * 24 + i]);
+    for (int gp = 0; gp < 4; gp++) {
+        double xi, eta, J[2][2];
+        gauss_point(gp, &xi, &eta);
+        double d = jac(&g, xi, eta, J);
+        if (!(d > 0.0)) g.status |= 4;
+    }
+    return g.status;
+}
+
+int fso_mitc4_M(const double *xyz, const fso_shell_prop *p, double *Me) {
+    geom_t g;
+    geom_init(&g, xyz);
+    double Ml[576];
+    memset(Ml, 0, sizeof Ml);
+    for (int gp = 0; gp < 4; gp++) {
+        double xi, eta, J[2][2], N[4];
+        gauss_point(gp, &xi, &eta);
+        double det = jac(&g, xi, eta, J);
+        shape(xi, eta, N);
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                double vt = N[i] * N[j] * p->m_t * 1.0 * det;
+                double vr = N[i] * N[j] * p->m_r * 1.0 * det;
+                for (int k = 0; k < 3; k++) Ml[(6 * i + k) * 24 + 6 * j + k] += vt;
+                for (int k = 3; k < 6; k++) Ml[(6 * i + k) * 24 + 6 * j + k] += vr;
+            }
+    }
+    rotate_to_global(&g, Ml, Me);
+    return g.status;
+}
+
+/* MITC4.py:1067-1341 (+ composite overrides MITC4_composite.py:499-621) */
+int fso_mitc4_NL(const double *xyz, const fso_shell_prop *p, const double *u, double *KT, double *f) {
+    geom_t g;
+    geom_init(&g, xyz);
+    double K0[576], kbs[576], kd[576], kc[576], ul[24];
+    k_local(&g, p, K0, kbs, kd, kc);
+    rotate_vec(&g, u, ul, 1);
+    if (!p->nonlinear) {
+        if (KT) rotate_to_global(&g, K0, KT); /* not symmetrised: MITC4.py:1259-1263 */
+        if (f) {
+            double fl[24];
+            for (int i = 0; i < 24; i++) {
+                double s = 0;
+                for (int j = 0; j < 24; j++) s += K0[i * 24 + j] * ul[j];
+                fl[i] = s;
+            }
+            rotate_vec(&g, fl, f, 0);
+        }
+        return g.status;
+    }
+    double KL[576], Ks[576], fl[24];
+    memset(KL, 0, sizeof KL); memset(Ks, 0, sizeof Ks);
+    /* sigma at (0,0): MITC4.py:1227-1240 ; composite MITC4_composite.py:499-508 */
+    double sig[3];
+    {
+        double dNdx[4], dNdy[4], Bm[3][24], Bk[3][24], eps[3] = {0, 0, 0}, kap[3] = {0, 0, 0};
+        dH(&g, 0.0, 0.0, dNdx, dNdy);
+        Bm_std(dNdx, dNdy, Bm); Bkappa(dNdx, dNdy, Bk);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 24; c++) { eps[r] += Bm[r][c] * ul[c]; kap[r] += Bk[r][c] * ul[c]; }
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            for (int c = 0; c < 3; c++) s += p->C_raw[r * 3 + c] * eps[c];
+            sig[r] = s;
+        }
+        /* laminate: (A eps + B kappa)/h. For isotropic rows B == 0 and C_raw == A/h up to
+         * rounding; the property table sets prop.B != 0 only for laminates, and C_raw*eps is
+         * replaced by (A eps + B kappa)/h when flag bit 1 (is_laminate) is set. */
+        if (p->flags & FSO_PROP_LAMINATE) {
+            for (int r = 0; r < 3; r++) {
+                double s = 0;
+                for (int c = 0; c < 3; c++) s += p->A[r * 3 + c] * eps[c];
+                double s2 = 0;
+                for (int c = 0; c < 3; c++) s2 += p->B[r * 3 + c] * kap[c];
+                sig[r] = (s + s2) / p->h;
+            }
+        }
+    }
+    if (f) {
+        for (int i = 0; i < 24; i++) {
+            double s = 0, s2 = 0, s3 = 0;
+            for (int j = 0; j < 24; j++) {
+                s += kbs[i * 24 + j] * ul[j]; s2 += kd[i * 24 + j] * ul[j];
+                if (p->flags & FSO_PROP_COUPLED) s3 += kc[i * 24 + j] * ul[j];
+            }
+            fl[i] = s + s2 + s3;
+        }
+    }
+    for (int gp = 0; gp < 4; gp++) {
+        double xi, eta, dNdx[4], dNdy[4];
+        gauss_point(gp, &xi, &eta);
+        double det = dH(&g, xi, eta, dNdx, dNdy);
+        /* H: global displacement components, local derivatives (MITC4.py:1092-1107) */
+        double H[3][3];
+        memset(H, 0, sizeof H);
+        for (int c = 0; c < 3; c++) {
+            double un[4] = {u[c], u[6 + c], u[12 + c], u[18 + c]};
+            H[c][0] = dotc4(un, dNdx); H[c][1] = dotc4(un, dNdy);
+        }
+        double BL[3][24], BNL[3][24], BG[6][24];
+        memset(BL, 0, sizeof BL); memset(BNL, 0, sizeof BNL); memset(BG, 0, sizeof BG);
+        for (int i = 0; i < 4; i++) {
+            int c = 6 * i;
+            BL[0][c] = dNdx[i]; BL[1][c + 1] = dNdy[i]; BL[2][c] = dNdy[i]; BL[2][c + 1] = dNdx[i];
+            for (int k = 0; k < 3; k++) {
+                BNL[0][c + k] = H[k][0] * dNdx[i];
+                BNL[1][c + k] = H[k][1] * dNdy[i];
+                BNL[2][c + k] = H[k][0] * dNdy[i] + H[k][1] * dNdx[i];
+                BG[2 * k][c + k] = dNdx[i]; BG[2 * k + 1][c + k] = dNdy[i];
+            }
+        }
+        double w = det * p->h;
+        if (KT) {
+            btcb(KL, w, &BL[0][0], 3, p->C_raw, &BNL[0][0], 3, 24);
+            btcb(KL, w, &BNL[0][0], 3, p->C_raw, &BL[0][0], 3, 24);
+            btcb(KL, w, &BNL[0][0], 3, p->C_raw, &BNL[0][0], 3, 24);
+            double S[36];
+            memset(S, 0, sizeof S);
+            for (int k = 0; k < 3; k++) {
+                S[(2 * k) * 6 + 2 * k] = sig[0] * p->h; S[(2 * k) * 6 + 2 * k + 1] = sig[2] * p->h;
+                S[(2 * k + 1) * 6 + 2 * k] = sig[2] * p->h; S[(2 * k + 1) * 6 + 2 * k + 1] = sig[1] * p->h;
+            }
+            btcb(Ks, det, &BG[0][0], 6, S, &BG[0][0], 6, 24);
+        }
+        if (f) {
+            double E[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double hh = 0;
+                    for (int k = 0; k < 3; k++) hh += H[k][a] * H[k][b];
+                    E[a][b] = 0.5 * (H[a][b] + H[b][a] + hh);
+                }
+            double eps[3] = {E[0][0], E[1][1], 2 * E[0][1]}, sm[3];
+            for (int r = 0; r < 3; r++) {
+                double s = 0;
+                for (int c = 0; c < 3; c++) s += p->C_raw[r * 3 + c] * eps[c];
+                sm[r] = s;
+            }
+            for (int i = 0; i < 24; i++) {
+                double s = 0;
+                for (int r = 0; r < 3; r++) s += (BL[r][i] + BNL[r][i]) * sm[r];
+                fl[i] += s * 1.0 * det * p->h;
+            }
+        }
+    }
+    if (KT) {
+        double Kt[576], Ksym[576];
+        for (int i = 0; i < 24; i++)
+            for (int j = 0; j < 24; j++) Ksym[i * 24 + j] = 0.5 * (Ks[i * 24 + j] + Ks[j * 24 + i]);
+        for (int i = 0; i < 576; i++) Kt[i] = K0[i] + KL[i] + Ksym[i];
+        double Kt2[576];
+        for (int i = 0; i < 24; i++)
+            for (int j = 0; j < 24; j++) Kt2[i * 24 + j] = 0.5 * (Kt[i * 24 + j] + Kt[j * 24 + i]);
+        rotate_to_global(&g, Kt2, KT);
+    }
+    if (f) rotate_vec(&g, fl, f, 0);
+    return g.status;
+}
+
+int fso_mitc4_K_batch(const double *xyz, const int32_t *prop_id, const fso_shell_prop *props,
+                      int64_t E, double *Ke, int32_t *status, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t e = 0; e < E; e++) {
+        int s = fso_mitc4_K(xyz + 12 * e, props + prop_id[e], Ke + 576 * e);
+        if (status) status[e] = s;
+    }
+    return 0;
+}
+int fso_mitc4_M_batch(const double *xyz, const int32_t *prop_id, const fso_shell_prop *props,
+                      int64_t E, double *Me, int32_t *status, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t e = 0; e < E; e++) {
+        int s = fso_mitc4_M(xyz + 12 * e, props + prop_id[e], Me + 576 * e);
+        if (status) status[e] = s;
+    }
+    return 0;
+}
+
+/* ---------- assembly restatement (core/assembler.py:222-241, 269-303) ---------- */
+static int cmp_i64(const void *a, const void *b) {
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return (x > y) - (x < y);
+}
+int64_t fso_csr_symbolic(const int64_t *dofs, int64_t E, int nd, int64_t ndof, int64_t *indptr,
+                         int32_t *indices) {
+    /* row -> list of elements (CSR of the transpose incidence), then per-row sort/unique */
+    int64_t *cnt = (int64_t *)calloc(ndof + 1, sizeof(int64_t));
+    for (int64_t e = 0; e < E; e++)
+        for (int a = 0; a < nd; a++) cnt[dofs[e * nd + a] + 1]++;
+    for (int64_t r = 0; r < ndof; r++) cnt[r + 1] += cnt[r];
+    int64_t *el = (int64_t *)malloc((cnt[ndof] > 0 ? cnt[ndof] : 1) * sizeof(int64_t));
+    int64_t *pos = (int64_t *)malloc((ndof + 1) * sizeof(int64_t));
+    memcpy(pos, cnt, (ndof + 1) * sizeof(int64_t));
+    for (int64_t e = 0; e < E; e++)
+        for (int a = 0; a < nd; a++) el[pos[dofs[e * nd + a]]++] = e;
+    int64_t cap = 4096, nnz = 0;
+    int64_t *buf = (int64_t *)malloc(cap * sizeof(int64_t));
+    if (!indices) indptr[0] = 0;
+    for (int64_t r = 0; r < ndof; r++) {
+        int64_t m = (cnt[r + 1] - cnt[r]) * nd;
+        if (m > cap) { cap = 2 * m; buf = (int64_t *)realloc(buf, cap * sizeof(int64_t)); }
+        int64_t k = 0;
+        for (int64_t q = cnt[r]; q < cnt[r + 1]; q++)
+            for (int b = 0; b < nd; b++) buf[k++] = dofs[el[q] * nd + b];
+        qsort(buf, k, sizeof(int64_t), cmp_i64);
+        int64_t u = 0;
+        for (int64_t i = 0; i < k; i++)
+            if (i == 0 || buf[i] != buf[i - 1]) {
+                if (indices) indices[nnz + u] = (int32_t)buf[i];
+                u++;
+            }
+        nnz += u;
+        if (!indices) indptr[r + 1] = nnz;
+    }
+    free(buf); free(pos); free(el); free(cnt);
+    return nnz;
+}
+int fso_csr_numeric(const int64_t *dofs, int64_t E, int nd, const double *vals_e,
+                    const int64_t *indptr, const int32_t *indices, double *data) {
+    for (int64_t e = 0; e < E; e++) {
+        const int64_t *d = dofs + e * nd;
+        const double *ke = vals_e + (int64_t)e * nd * nd;
+        for (int a = 0; a < nd; a++) {
+            int64_t r = d[a], lo0 = indptr[r], hi0 = indptr[r + 1];
+            for (int b = 0; b < nd; b++) {
+                int64_t c = d[b], lo = lo0, hi = hi0;
+                while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (indices[mid] < c) lo = mid + 1; else hi = mid; }
+                if (lo >= hi0 || indices[lo] != c) return -1;
+                data[lo] += ke[a * nd + b];
+            }
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,112 @@
+"""ctypes front-end of the CPU oracle (oracle/libfemshell_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by fem_shell_amd (the product path).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PROP_DTYPE = np.dtype([
+    ("A", "f8", (9,)), ("B", "f8", (9,)), ("D", "f8", (9,)), ("Cs", "f8", (4,)),
+    ("h", "f8"), ("m_t", "f8"), ("m_r", "f8"), ("k_drill", "f8"), ("C_raw", "f8", (9,)),
+    ("flags", "i4"), ("nonlinear", "i4"),
+])
+assert PROP_DTYPE.itemsize == 360
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libfemshell_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.fso_csr_symbolic.restype = ctypes.c_int64
+    return _LIB
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
+
+
+def as_props(props):
+    props = np.ascontiguousarray(props)
+    if props.dtype != PROP_DTYPE:
+        props = np.frombuffer(props.tobytes(), dtype=PROP_DTYPE).copy()
+    return props
+
+
+def mitc4_geom(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(4, 3)
+    e = np.zeros(9); xl = np.zeros(8); dj = np.zeros(4); ac = np.zeros(5)
+    st = lib().fso_mitc4_geom(_p(xyz), _p(e), _p(xl), _p(dj), _p(ac))
+    return e.reshape(3, 3), xl.reshape(4, 2), dj, ac, st
+
+
+def mitc4_K_parts(xyz, prop):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(4, 3)
+    prop = as_props(prop).reshape(-1)[:1]
+    out = [np.zeros((24, 24)) for _ in range(4)]
+    lib().fso_mitc4_K_parts(_p(xyz), _p(prop), *[_p(o) for o in out])
+    return out
+
+
+def mitc4_K_batch(xyz, prop_id, props, nthreads=1):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 4, 3)
+    E = xyz.shape[0]
+    prop_id = np.ascontiguousarray(prop_id, dtype=np.int32).reshape(E)
+    props = as_props(props)
+    Ke = np.empty((E, 24, 24)); st = np.zeros(E, dtype=np.int32)
+    lib().fso_mitc4_K_batch(_p(xyz), _p(prop_id), _p(props), ctypes.c_int64(E), _p(Ke), _p(st),
+                            ctypes.c_int(nthreads))
+    return Ke, st
+
+
+def mitc4_M_batch(xyz, prop_id, props, nthreads=1):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 4, 3)
+    E = xyz.shape[0]
+    prop_id = np.ascontiguousarray(prop_id, dtype=np.int32).reshape(E)
+    props = as_props(props)
+    Me = np.empty((E, 24, 24)); st = np.zeros(E, dtype=np.int32)
+    lib().fso_mitc4_M_batch(_p(xyz), _p(prop_id), _p(props), ctypes.c_int64(E), _p(Me), _p(st),
+                            ctypes.c_int(nthreads))
+    return Me, st
+
+
+def mitc4_NL(xyz, prop, u):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(4, 3)
+    prop = as_props(prop).reshape(-1)[:1]
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(24)
+    KT = np.zeros((24, 24)); f = np.zeros(24)
+    st = lib().fso_mitc4_NL(_p(xyz), _p(prop), _p(u), _p(KT), _p(f))
+    return KT, f, st
+
+
+def csr_assemble(dofs, ndof, vals_e):
+    """Pattern + element-order summation (core/assembler.py:222-241, 269-303)."""
+    dofs = np.ascontiguousarray(dofs, dtype=np.int64)
+    E, nd = dofs.shape
+    indptr = np.zeros(ndof + 1, dtype=np.int64)
+    nnz = lib().fso_csr_symbolic(_p(dofs), ctypes.c_int64(E), ctypes.c_int(nd),
+                                 ctypes.c_int64(ndof), _p(indptr), ctypes.c_void_p(0))
+    indices = np.zeros(nnz, dtype=np.int32)
+    lib().fso_csr_symbolic(_p(dofs), ctypes.c_int64(E), ctypes.c_int(nd), ctypes.c_int64(ndof),
+                           _p(indptr), _p(indices))
+    data = None
+    if vals_e is not None:
+        vals_e = np.ascontiguousarray(vals_e, dtype=np.float64)
+        data = np.zeros(nnz)
+        rc = lib().fso_csr_numeric(_p(dofs), ctypes.c_int64(E), ctypes.c_int(nd), _p(vals_e),
+                                   _p(indptr), _p(indices), _p(data))
+        assert rc == 0
+    return indptr, indices, data
