@@ -1,0 +1,316 @@
+"""MeshAssembler: the reference's global-assembler interface (core/assembler.py:12-516) on top of
+the batched HIP kernels.
+
+Same constructor `(mesh, model)`, same `model["elements"]` dictionary (element_family, material,
+thickness, laminate, properties, extra element kwargs), same attributes (`dofs_per_node`,
+`spatial_dim`, `dofs_count`, `_row_nnz`, `_dofs_array`, `_ke_array`, `_me_array`, `_element_map`,
+`_node_dofs_map`, `_is_mixed_mesh`) and the same assemble_* methods.  Differences, by design:
+  * matrices come back as `CsrMatrix` (device CSR: indptr/indices/data torch tensors) with
+    `.to_scipy()` and `.to_petsc()`; where petsc4py exists `.to_petsc()` yields the AIJ Mat the
+    unchanged solver layer expects (core/assembler.py:243-303);
+  * element matrices live on the GPU in FS_LAYOUT_SYMBLK; `_ke_array` / `_me_array` /
+    `_dofs_array` / `_element_map` are materialised lazily;
+  * degenerate elements raise ValueError (stricter than MITC4's silent NaN).
+"""
+import warnings
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, batch
+from .elements import ElementFactory, ElementFamily
+from .properties import (CompositeShellProperty, ShellProperty, build_prop_table, iso_row,
+                         laminate_row, PROP_DTYPE)
+from .symbolic import BlockPlan
+
+
+class CsrMatrix:
+    """Device CSR (rows = DOFs, sorted columns, explicit structural zeros kept, like PETSc AIJ
+    assembled without MAT_IGNORE_ZERO_ENTRIES)."""
+
+    def __init__(self, indptr, indices, data, shape):
+        self.indptr, self.indices, self.data, self.shape = indptr, indices, data, tuple(shape)
+
+    @property
+    def nnz(self):
+        return int(self.data.numel())
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.data.cpu().numpy(), self.indices.cpu().numpy(),
+                              self.indptr.cpu().numpy()), shape=self.shape)
+
+    def to_petsc(self, comm=None):
+        try:
+            from petsc4py import PETSc
+        except ImportError as exc:
+            raise ImportError("petsc4py is not installed: use CsrMatrix.to_scipy() or the device "
+                              "tensors directly") from exc
+        ip = self.indptr.cpu().numpy().astype(PETSc.IntType)
+        ix = self.indices.cpu().numpy().astype(PETSc.IntType)
+        return PETSc.Mat().createAIJWithArrays(self.shape, (ip, ix, self.data.cpu().numpy()), comm=comm)
+
+    def lump_rows(self):
+        """Row-sum lumping (solvers/fsi/linear_dynamic.py:227-234) as a device vector."""
+        rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.data.device),
+                                       self.indptr[1:] - self.indptr[:-1])
+        return torch.zeros(self.shape[0], dtype=self.data.dtype, device=self.data.device).index_add_(0, rows, self.data)
+
+
+class _LazyElementMap:
+    """dict-like view element id -> element object (built on demand; core/assembler.py:190)."""
+
+    def __init__(self, asm):
+        self._a, self._cache = asm, {}
+
+    def __len__(self):
+        return len(self._a._elem_ids)
+
+    def __iter__(self):
+        return iter(self._a._elem_ids.tolist())
+
+    def keys(self):
+        return self._a._elem_ids.tolist()
+
+    def items(self):
+        return ((k, self[k]) for k in self)
+
+    def values(self):
+        return (self[k] for k in self)
+
+    def __contains__(self, k):
+        return k in self._a._elem_pos
+
+    def __getitem__(self, eid):
+        if eid not in self._cache:
+            self._cache[eid] = self._a._make_element(self._a._elem_pos[eid])
+        return self._cache[eid]
+
+
+class MeshAssembler:
+    _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
+                          ElementFamily.SOLID: (3, 3)}
+
+    def __init__(self, mesh, model: Dict, comm=None, device=None):
+        self.mesh = mesh
+        self.model = model["elements"]
+        self.comm = comm
+        self.device = torch.device(device) if device is not None else batch._dev()
+        self.dofs_per_node = 0
+        self.spatial_dim = 0
+        self.dofs_count = 0
+        self._row_nnz: Optional[np.ndarray] = None
+        self._is_mixed_mesh = False
+        self._K_blk = self._M_blk = None
+        self._precompute_elements()
+        self._compute_sparsity_pattern()
+
+    # ------------------------------------------------------------------ input extraction
+    def _extract(self):
+        mesh = self.mesh
+        if hasattr(mesh, "coords") and hasattr(mesh, "conn"):      # ArrayMesh fast path
+            coords, conn = mesh.coords, mesh.conn
+            elem_ids = np.arange(conn.shape[0], dtype=np.int64)
+            thickness = None
+            set_lookup = None
+            if getattr(mesh, "set_id", None) is not None:
+                set_lookup = (mesh.set_id, mesh.set_names)
+            return coords, conn, elem_ids, thickness, set_lookup
+        # duck-typed reference mesh (core/assembler.py:72,107,121-187)
+        n2i = mesh.node_id_to_index
+        nn = {e.node_count for e in mesh.elements}
+        if len(nn) != 1:
+            raise NotImplementedError("mixed node counts on the duck-typed path")
+        E, nnodes = len(mesh.elements), nn.pop()
+        conn = np.empty((E, nnodes), dtype=np.int64)
+        coords = np.full((mesh.node_count, 3), np.nan)
+        elem_ids = np.empty(E, dtype=np.int64)
+        thickness = np.full(E, np.nan)
+        for i, el in enumerate(mesh.elements):
+            idx = [n2i[n] for n in el.node_ids]
+            conn[i] = idx
+            coords[idx] = np.asarray(el.node_coords, dtype=float)
+            elem_ids[i] = el.id
+            if getattr(el, "thickness", None) is not None:
+                thickness[i] = el.thickness
+        return coords, conn, elem_ids, (None if np.isnan(thickness).all() else thickness), None
+
+    def _property_ids(self, E, elem_ids, thickness, set_lookup):
+        """Rows of the device property table + per-element row index (core/assembler.py:111-162)."""
+        m = self.model
+        extra = {k: v for k, v in m.items()
+                 if k not in ("properties", "material", "thickness", "laminate", "element_family")}
+        nonlinear = bool(extra.get("nonlinear", False))
+        kappa = extra.get("shear_correction_factor")
+        rows, pid = [], np.full(E, -1, dtype=np.int32)
+        self._prop_objects = []
+
+        def add(row, obj):
+            rows.append(row)
+            self._prop_objects.append(obj)
+            return len(rows) - 1
+
+        props_map = m.get("properties")
+        if props_map is not None:
+            if set_lookup is not None:
+                set_id, names = set_lookup
+                for sid, name in enumerate(names):
+                    if name in props_map:
+                        p = props_map[name]
+                        r = add(laminate_row(p.laminate, nonlinear) if isinstance(p, CompositeShellProperty)
+                                else iso_row(p.material, p.thickness, kappa, nonlinear), p)
+                        pid[set_id == sid] = r
+            else:
+                pos = {int(e): i for i, e in enumerate(elem_ids)}
+                for name, p in props_map.items():
+                    if name in self.mesh.element_sets:
+                        r = add(laminate_row(p.laminate, nonlinear) if isinstance(p, CompositeShellProperty)
+                                else iso_row(p.material, p.thickness, kappa, nonlinear), p)
+                        for el in self.mesh.element_sets[name].elements:
+                            pid[pos[int(el.id)]] = r
+        rest = pid < 0
+        if rest.any():
+            if m.get("laminate") is not None:
+                pid[rest] = add(laminate_row(m["laminate"], nonlinear), CompositeShellProperty(m["laminate"]))
+            else:
+                if "material" not in m:
+                    raise TypeError("model['elements'] needs 'material'+'thickness', 'laminate' or 'properties'")
+                if thickness is not None and np.isfinite(thickness[rest]).any():
+                    warnings.warn("Per-element thickness via MeshElement.thickness is deprecated. Use a "
+                                  "'properties' dict mapping element-set names to ShellProperty / "
+                                  "CompositeShellProperty instead.", DeprecationWarning, stacklevel=1)
+                    th = np.where(np.isfinite(thickness), thickness, m.get("thickness", np.nan))
+                    for t in np.unique(th[rest]):
+                        pid[rest & (th == t)] = add(iso_row(m["material"], float(t), kappa, nonlinear),
+                                                    ShellProperty(m["material"], float(t)))
+                else:
+                    pid[rest] = add(iso_row(m["material"], m["thickness"], kappa, nonlinear),
+                                    ShellProperty(m["material"], m["thickness"]))
+        table = np.zeros(len(rows), dtype=PROP_DTYPE)
+        for i, r in enumerate(rows):
+            table[i] = r
+        return table, pid
+
+    # ------------------------------------------------------------------ precompute
+    def _precompute_elements(self):
+        fam = self.model.get("element_family")
+        if fam != ElementFamily.SHELL:
+            raise NotImplementedError("fem_shell_amd.MeshAssembler: only ElementFamily.SHELL is built "
+                                      "in this round (SOLID is the next row of SURVEY.md 8)")
+        self.dofs_per_node, self.spatial_dim = self._FAMILY_PROPERTIES[fam]
+        coords, conn, elem_ids, thickness, set_lookup = self._extract()
+        if conn.shape[1] != 4:
+            raise NotImplementedError("only 4-node shells (MITC4+) are built in this round")
+        E = conn.shape[0]
+        self._coords, self._conn, self._elem_ids = coords, conn, elem_ids
+        self._elem_pos = {int(e): i for i, e in enumerate(elem_ids)} if E < 2_000_000 else _RangePos(E)
+        self.dofs_count = int(self.mesh.node_count) * self.dofs_per_node
+        self._prop_table, self._prop_id = self._property_ids(E, elem_ids, thickness, set_lookup)
+        dev = self.device
+        self._conn_d = torch.from_numpy(conn).to(dev)
+        self._xyz_d = torch.from_numpy(coords).to(dev)[self._conn_d]          # [E,4,3] gather (plumbing)
+        self._pid_d = torch.from_numpy(self._prop_id).to(dev)
+        self._props_d = batch.to_device_props(self._prop_table)
+        self._plan = BlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node)
+        p = self._plan
+        self._plan_d = {k: torch.from_numpy(getattr(p, k)).to(dev)
+                        for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
+        self.refresh_element_matrices()
+
+    def refresh_element_matrices(self, want_K=True, want_M=True):
+        """(Re)run the element kernels: K and M of every element, like the element loop of
+        core/assembler.py:121-193 (which always evaluates both)."""
+        out = batch.quad_batch(self._xyz_d, self._pid_d, self._props_d, len(self._prop_table),
+                               want_K=want_K, want_M=want_M, status=True)
+        if want_K:
+            self._K_blk = out["K"]
+        if want_M:
+            self._M_blk = out["M"]
+        bad = torch.nonzero(out["status"])
+        if bad.numel():
+            e = int(bad[0])
+            raise ValueError(f"element {int(self._elem_ids[e])}: degenerate geometry "
+                             f"(status bits {int(out['status'][e])})")
+
+    def _compute_sparsity_pattern(self):
+        self._row_nnz = self._plan.row_nnz()
+        lib, p, d = _lib.load(), self._plan, self._plan_d
+        self._indptr = torch.empty(self.dofs_count + 1, dtype=torch.int64, device=self.device)
+        self._indices = torch.empty(p.nnz, dtype=torch.int32, device=self.device)
+        _lib.check(lib.fs_csr_pattern_blk(_lib.ptr(d["nbr_ptr"]), _lib.ptr(d["blk_row"]), _lib.ptr(d["nbr"]),
+                                          p.n_nodes, p.nblk, p.d, _lib.ptr(self._indptr),
+                                          _lib.ptr(self._indices), _lib.stream_ptr()), "fs_csr_pattern_blk")
+
+    # ------------------------------------------------------------------ lazy reference views
+    @property
+    def _dofs_array(self):
+        d = self.dofs_per_node
+        return (self._conn[:, :, None] * d + np.arange(d, dtype=np.int64)).reshape(self._conn.shape[0], -1)
+
+    @property
+    def _ke_array(self):
+        return batch.expand_blocks(self._K_blk, 4, 6).cpu().numpy()
+
+    @property
+    def _me_array(self):
+        return batch.expand_blocks(self._M_blk, 4, 6).cpu().numpy()
+
+    _dofs_list = _ke_list = _me_list = None
+
+    @property
+    def _element_map(self):
+        return _LazyElementMap(self)
+
+    @property
+    def _node_dofs_map(self):
+        d = self.dofs_per_node
+        used = np.unique(self._conn)
+        return {int(n): tuple(range(int(n) * d, int(n) * d + d)) for n in used}
+
+    def _make_element(self, pos):
+        view = self.mesh.elements[pos]
+        prop = self._prop_objects[int(self._prop_id[pos])]
+        extra = {k: v for k, v in self.model.items()
+                 if k not in ("properties", "material", "thickness", "laminate", "element_family")}
+        return ElementFactory.get_element(ElementFamily.SHELL, view, shell_property=prop, **extra)
+
+    # ------------------------------------------------------------------ assembly
+    def _assemble(self, blk):
+        lib, p, d = _lib.load(), self._plan, self._plan_d
+        data = torch.empty(p.nnz, dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_csr_numeric_blk(_lib.ptr(blk), _lib.ptr(d["nbr_ptr"]), _lib.ptr(d["blk_row"]),
+                                          _lib.ptr(d["blk_ptr"]), _lib.ptr(d["contrib"]), p.nblk, p.d,
+                                          _lib.ptr(data), _lib.stream_ptr()), "fs_csr_numeric_blk")
+        return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
+
+    def assemble_stiffness_matrix(self, recompute=False) -> CsrMatrix:
+        """core/assembler.py:269-303."""
+        if recompute or self._K_blk is None:
+            self.refresh_element_matrices(want_K=True, want_M=False)
+        return self._assemble(self._K_blk)
+
+    def assemble_mass_matrix(self, recompute=False) -> CsrMatrix:
+        """core/assembler.py:305-336."""
+        if recompute or self._M_blk is None:
+            self.refresh_element_matrices(want_K=False, want_M=True)
+        return self._assemble(self._M_blk)
+
+    def assemble_load_vector(self, load_condition):
+        """core/assembler.py:338-384: shells have no body_load in the reference (AttributeError)."""
+        raise AttributeError("'MITC4' object has no attribute 'body_load'")
+
+
+class _RangePos:
+    """element id -> position for ArrayMesh-sized meshes without building a 10M-entry dict."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __getitem__(self, k):
+        if not 0 <= k < self.n:
+            raise KeyError(k)
+        return k
+
+    def __contains__(self, k):
+        return 0 <= k < self.n

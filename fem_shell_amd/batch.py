@@ -1,0 +1,80 @@
+"""Array-native batch front-end of the C ABI: torch tensors in, torch tensors out (device
+buffers only -- all arithmetic is in libfemshell_hip.so).  This is what MeshAssembler and the
+per-element classes delegate to; no per-element Python objects are created here."""
+import numpy as np
+import torch
+
+from . import _lib
+from .properties import PROP_DTYPE
+
+NPAIR4 = 10
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.FemShellHipError("no GPU visible: the fem_shell_amd hot path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device_props(props: np.ndarray) -> torch.Tensor:
+    props = np.ascontiguousarray(props)
+    assert props.dtype == PROP_DTYPE
+    raw = torch.from_numpy(props.view(np.uint8).reshape(-1).copy())
+    return raw.to(_dev())
+
+
+def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
+               status=True):
+    """MITC4+ element matrices for E quads.
+
+    xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
+    Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,10,36], or dense [E,24,24]) and 'status'.
+    """
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    assert xyz.dtype == torch.float64 and xyz.shape[1:] == (4, 3) and xyz.is_cuda
+    assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
+    if E:
+        pmin, pmax = int(prop_id.min()), int(prop_id.max())
+        if pmin < 0 or pmax >= n_props:
+            raise ValueError("prop_id out of range of the property table")
+    out = {}
+    K = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev) if want_K else None
+    M = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev) if want_M else None
+    st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
+    want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
+    _lib.check(lib.fs_shell_quad_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
+                                       n_props, None, E, want, _lib.FS_LAYOUT_SYMBLK,
+                                       _lib.ptr(K), _lib.ptr(M), None, None, _lib.ptr(st),
+                                       _lib.stream_ptr()), "fs_shell_quad_batch")
+    if dense:
+        K = expand_blocks(K, 4, 6) if K is not None else None
+        M = expand_blocks(M, 4, 6) if M is not None else None
+    out["K"], out["M"], out["status"] = K, M, st
+    return out
+
+
+def expand_blocks(packed, nn, d):
+    lib = _lib.load()
+    E = packed.shape[0]
+    dense = torch.empty((E, nn * d, nn * d), dtype=torch.float64, device=packed.device)
+    _lib.check(lib.fs_blk_expand(_lib.ptr(packed), E, nn, d, _lib.ptr(dense), _lib.stream_ptr()),
+               "fs_blk_expand")
+    return dense
+
+
+def quad_geom(xyz):
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    frame = torch.empty((E, 3, 3), dtype=torch.float64, device=dev)
+    xl = torch.empty((E, 4, 2), dtype=torch.float64, device=dev)
+    detJ = torch.empty((E, 4), dtype=torch.float64, device=dev)
+    acoef = torch.empty((E, 5), dtype=torch.float64, device=dev)
+    _lib.check(lib.fs_shell_quad_geom(_lib.ptr(xyz), E, _lib.ptr(frame), _lib.ptr(xl),
+                                      _lib.ptr(detJ), _lib.ptr(acoef), _lib.stream_ptr()),
+               "fs_shell_quad_geom")
+    return frame, xl, detJ, acoef

@@ -1,0 +1,168 @@
+"""Element classes with the reference's constructor signatures and members,
+delegating every matrix to the batched HIP kernels (batch of 1).  Boundary types only: the bulk
+path (MeshAssembler) never instantiates these.
+
+Mirrors elements/elements.py:11-259 (ElementFamily, FemElement, ShellElement, ElementFactory),
+elements/MITC4.py:26-99 and elements/MITC4_composite.py:34-120 of the reference.
+"""
+from enum import IntEnum
+from functools import cached_property
+
+import numpy as np
+
+from .laminate import Laminate
+from .material import OrthotropicMaterial
+from .properties import CompositeShellProperty, build_prop_table, iso_row, laminate_row
+
+
+class ElementFamily(IntEnum):
+    SHELL = 2
+    PLANE = 3
+    SOLID = 4
+
+
+class FemElement:
+    _id_counter: int = 0
+    vector_form = {}
+
+    def __init__(self, name, node_coords, node_ids, material, dofs_per_node):
+        self.name = name
+        self.node_coords = node_coords
+        self.node_ids = node_ids
+        self.material = material
+        self.dofs_per_node = dofs_per_node
+        self.node_count = len(self.node_coords)
+        self.dofs_count = self.node_count * self.dofs_per_node
+        self.element_family = None
+        self.id = FemElement._id_counter
+        self.integration_order = 1
+        FemElement._id_counter += 1
+
+    @property
+    def spatial_dimmension(self):  # (sic) elements/elements.py:41-49
+        return 3 if self.element_family in (ElementFamily.SHELL, ElementFamily.SOLID) else 2
+
+    def __repr__(self):
+        return f"<Element id={self.id} name={self.name}>"
+
+
+class ShellElement(FemElement):
+    def __init__(self, name, node_coords, node_ids, material, dofs_per_node, thickness, nonlinear):
+        super().__init__(name, node_coords, node_ids, material, dofs_per_node)
+        self.thickness = thickness
+        self.nonlinear = nonlinear
+        self.element_family = ElementFamily.SHELL
+
+
+def _check_status(st, what):
+    if st:
+        raise ValueError(f"{what}: degenerate element geometry (status bits {int(st)})")
+
+
+class MITC4(ShellElement):
+    """MITC4+ quadrilateral shell, 6 DOF/node (elements/MITC4.py:26-99)."""
+
+    vector_form = {"U": ("Ux", "Uy", "Uz"), "θ": ("θx", "θy", "θz")}
+
+    def __init__(self, node_coords, node_ids, material, thickness, shear_correction_factor=None,
+                 nonlinear=False):
+        super().__init__("MITC4", node_coords=node_coords, node_ids=node_ids, material=material,
+                         dofs_per_node=6, thickness=thickness, nonlinear=nonlinear)
+        self.element_type = "MITC4"
+        self._initial_coords = np.array(node_coords, dtype=float).copy()
+        if self._initial_coords.shape != (4, 3):
+            raise ValueError("MITC4 needs 4 nodes with 3 coordinates each")
+        self._current_displacements = np.zeros(24)
+        self._kappa_arg = shear_correction_factor
+
+    # -- property-table row (host) --------------------------------------------------------
+    def _prop_row(self):
+        return iso_row(self.material, self.thickness, self._kappa_arg, self.nonlinear)
+
+    def _run(self, **want):
+        import torch
+        from . import batch
+        props = np.zeros(1, dtype=self._prop_row().dtype)
+        props[0] = self._prop_row()
+        dev = batch._dev()
+        xyz = torch.from_numpy(self._initial_coords[None]).to(dev)
+        pid = torch.zeros(1, dtype=torch.int32, device=dev)
+        out = batch.quad_batch(xyz, pid, batch.to_device_props(props), 1, dense=True, **want)
+        _check_status(int(out["status"][0]), self.name)
+        return out
+
+    @cached_property
+    def K(self) -> np.ndarray:
+        """Global-axes stiffness [24,24] (elements/MITC4.py:1018-1036)."""
+        return np.ascontiguousarray(self._run(want_K=True)["K"][0].cpu().numpy())
+
+    @cached_property
+    def M(self) -> np.ndarray:
+        """Consistent mass [24,24] (elements/MITC4.py:1038-1061)."""
+        return np.ascontiguousarray(self._run(want_K=False, want_M=True)["M"][0].cpu().numpy())
+
+    def update_configuration(self, displacements):
+        if len(displacements) != 24:
+            raise ValueError(f"Expected 24 DOFs, got {len(displacements)}")
+        self._current_displacements = np.array(displacements, dtype=float)
+
+    def reset_configuration(self):
+        self._current_displacements = np.zeros(24)
+
+
+class MITC4Composite(MITC4):
+    """Laminated MITC4+ (elements/MITC4_composite.py:34-120)."""
+
+    def __init__(self, node_coords, node_ids, laminate: Laminate, kx_mod=1.0, ky_mod=1.0,
+                 nonlinear=False):
+        self.laminate = laminate
+        self._kx_mod, self._ky_mod = kx_mod, ky_mod
+        eq = laminate.get_equivalent_properties()
+        ref = laminate.plies[0].material
+        Ex, Ey, Gxy, nuxy = eq["Ex_membrane"], eq["Ey_membrane"], eq["Gxy_membrane"], eq["nuxy_membrane"]
+        equivalent = OrthotropicMaterial(
+            name=f"Equivalent_{laminate}", E=(Ex, Ey, Ey), G=(Gxy, ref.G[1], ref.G[2]),
+            nu=(nuxy, nuxy * Ey / Ex, nuxy), rho=ref.rho,
+            shear_correction_factor=laminate.shear_correction_factor)
+        super().__init__(node_coords=node_coords, node_ids=node_ids, material=equivalent,
+                         thickness=laminate.total_thickness,
+                         shear_correction_factor=laminate.shear_correction_factor,
+                         nonlinear=nonlinear)
+        self.element_type = "MITC4Composite"
+
+    A = property(lambda self: self.laminate.A)
+    B_coup = property(lambda self: self.laminate.B)
+    D = property(lambda self: self.laminate.D)
+    has_coupling = property(lambda self: not self.laminate.is_symmetric)
+
+    def _prop_row(self):
+        return laminate_row(self.laminate, self.nonlinear)
+
+
+class ElementFactory:
+    """elements/elements.py:107-259: dispatch by family x node count x composite."""
+
+    @staticmethod
+    def get_element(element_family, mesh_element, shell_property=None, **kwargs):
+        if shell_property is not None:
+            prop_kwargs = shell_property.to_element_kwargs()
+            is_composite = isinstance(shell_property, CompositeShellProperty)
+            laminate = prop_kwargs.pop("laminate", None)
+            kwargs.update(prop_kwargs)
+        else:
+            laminate = kwargs.pop("laminate", None)
+            is_composite = laminate is not None
+        shell_map = {4: MITC4}
+        shell_composite_map = {4: MITC4Composite}
+        node_ids = mesh_element.node_ids
+        node_coords = mesh_element.node_coords
+        node_count = mesh_element.node_count
+        try:
+            if element_family == ElementFamily.SHELL:
+                if is_composite:
+                    return shell_composite_map[node_count](node_coords=node_coords, node_ids=node_ids,
+                                                           laminate=laminate, **kwargs)
+                return shell_map[node_count](node_coords=node_coords, node_ids=node_ids, **kwargs)
+            raise NotImplementedError(f"Element family {element_family} not implemented")
+        except KeyError:
+            return False

@@ -1,0 +1,166 @@
+"""Array-native meshes for the hot path.
+
+`ArrayMesh` is the batch-friendly mesh container (coordinates [N,3], connectivity [E,nn]); it also
+exposes the duck-typed protocol MeshAssembler touches in the reference (`elements`, `node_count`,
+`node_id_to_index`, `element_sets`; core/assembler.py:72,107,113-119,220) through lazy views, so
+no per-element Python object exists unless a caller asks for one.
+
+Generators restate the structured mesh builders of the reference's own benchmarks
+(tests/benchmarks/test_ko2017_performance.py:857-893 cylindrical patch, :261-308 flat patch) as
+array code, plus the synthetic C5 plate of SURVEY.md 8(d).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+
+class _ElemView:
+    __slots__ = ("_m", "id")
+
+    def __init__(self, mesh, idx):
+        self._m, self.id = mesh, idx
+
+    @property
+    def node_ids(self):
+        return tuple(int(i) for i in self._m.conn[self.id])
+
+    @property
+    def node_count(self):
+        return self._m.conn.shape[1]
+
+    @property
+    def node_coords(self):
+        return self._m.coords[self._m.conn[self.id]]
+
+    thickness = None
+
+
+class _ElemList:
+    def __init__(self, mesh, index=None):
+        self._m, self._index = mesh, index
+
+    def __len__(self):
+        return self._m.conn.shape[0] if self._index is None else len(self._index)
+
+    def __getitem__(self, i):
+        return _ElemView(self._m, int(i if self._index is None else self._index[i]))
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __bool__(self):
+        return len(self) > 0
+
+
+class ArrayMesh:
+    """coords [N,3] float64, conn [E,nn] int (node indices == node ids), optional element sets
+    given as {name: int array of element indices} or a per-element set-id array + names."""
+
+    def __init__(self, coords, conn, set_id=None, set_names=None):
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int64)
+        self.set_id = None if set_id is None else np.ascontiguousarray(set_id, dtype=np.int32)
+        self.set_names = list(set_names) if set_names is not None else None
+        if self.set_id is not None and self.set_names is None:
+            self.set_names = [f"set_{i}" for i in range(int(self.set_id.max()) + 1)]
+
+    @property
+    def node_count(self):
+        return self.coords.shape[0]
+
+    @property
+    def element_count(self):
+        return self.conn.shape[0]
+
+    @property
+    def elements(self):
+        return _ElemList(self)
+
+    @property
+    def node_id_to_index(self):
+        return _Identity(self.node_count)
+
+    @property
+    def element_sets(self):
+        if self.set_id is None:
+            return {}
+        return {name: SimpleNamespace(elements=_ElemList(self, np.flatnonzero(self.set_id == i)))
+                for i, name in enumerate(self.set_names)}
+
+
+class _Identity:
+    def __init__(self, n):
+        self.n = n
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.n:
+            raise KeyError(i)
+        return i
+
+    def __len__(self):
+        return self.n
+
+
+def hash_uniform(ids, salt):
+    """splitmix64 of (ids, salt) -> float64 in [0,1); counter-based so it is order independent."""
+    with np.errstate(over="ignore"):
+        z = ids.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(salt + 1)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def structured_conn(nx, ny, triangular=False):
+    """Quads (n00,n10,n11,n01), row-major in j then i; triangles split (n00,n10,n11),(n00,n11,n01)
+    exactly like the reference benchmarks (test_ko2017_performance.py:296-306, 882-892)."""
+    ids = np.arange((nx + 1) * (ny + 1), dtype=np.int64).reshape(ny + 1, nx + 1)
+    n00, n10, n11, n01 = ids[:-1, :-1], ids[:-1, 1:], ids[1:, 1:], ids[1:, :-1]
+    if not triangular:
+        return np.stack([n00, n10, n11, n01], -1).reshape(-1, 4)
+    t = np.stack([np.stack([n00, n10, n11], -1), np.stack([n00, n11, n01], -1)], 2)
+    return t.reshape(-1, 3)
+
+
+def cylindrical_patch(radius, length, angle_deg, nx, ny, triangular=False):
+    """test_ko2017_performance.py:857-893 (_build_cylindrical_patch)."""
+    zs = np.linspace(0.0, length, ny + 1)
+    th = np.linspace(0.0, np.radians(angle_deg), nx + 1)
+    x = radius * np.cos(th)
+    y = radius * np.sin(th)
+    coords = np.empty((ny + 1, nx + 1, 3))
+    coords[:, :, 0] = x[None, :]
+    coords[:, :, 1] = y[None, :]
+    coords[:, :, 2] = zs[:, None]
+    return ArrayMesh(coords.reshape(-1, 3), structured_conn(nx, ny, triangular))
+
+
+def flat_patch(x0, x1, y0, y1, nx, ny, triangular=False, surface_z=None):
+    """test_ko2017_performance.py:261-308 (_build_structured_mesh_xy)."""
+    xs = np.linspace(x0, x1, nx + 1)
+    ys = np.linspace(y0, y1, ny + 1)
+    X, Y = np.meshgrid(xs, ys)
+    Z = np.zeros_like(X) if surface_z is None else surface_z(X, Y)
+    return ArrayMesh(np.stack([X, Y, Z], -1).reshape(-1, 3), structured_conn(nx, ny, triangular))
+
+
+def jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=0):
+    """Synthetic C5 laminate plate: nx x ny MITC4+ cells of size `cell`, nodes
+    jittered +-5 % in-plane and +-1 % out-of-plane so every element is distinct and warped;
+    `n_sets` property sets striped by x-band. `x_offset_cells` shifts the strip (rank shards)."""
+    ix = np.arange(nx + 1, dtype=np.int64) + x_offset_cells
+    iy = np.arange(ny + 1, dtype=np.int64)
+    IX, IY = np.meshgrid(ix, iy)
+    X, Y = IX * cell, IY * cell
+    coords = np.stack([X, Y, np.zeros_like(X)], -1).reshape(-1, 3)
+    # jitter is a pure function of the GLOBAL grid position, so shards generated on different
+    # ranks agree bit for bit on their shared interface nodes
+    gid = (IY * (1 << 32) + IX).reshape(-1)
+    coords[:, 0] += (hash_uniform(gid, seed) - 0.5) * 0.1 * cell
+    coords[:, 1] += (hash_uniform(gid, seed + 1) - 0.5) * 0.1 * cell
+    coords[:, 2] += (hash_uniform(gid, seed + 2) - 0.5) * 0.02 * cell
+    conn = structured_conn(nx, ny)
+    band = max(1, -(-nx // n_sets))
+    set_id = np.tile((np.arange(nx) // band).astype(np.int32) % n_sets, ny)
+    return ArrayMesh(coords, conn, set_id, [f"band_{i}" for i in range(n_sets)])

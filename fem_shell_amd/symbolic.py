@@ -1,0 +1,117 @@
+"""Symbolic phase of the CSR assembly (pattern + scatter plan), computed once per mesh.
+
+Restates MeshAssembler._precompute_elements' DOF map and _compute_sparsity_pattern
+(core/assembler.py:166-187, 222-241 of the reference) as array operations on the node graph
+instead of per-DOF Python sets: for meshes whose nodes all carry d DOFs the pattern of row d*I+k
+is {d*J+l : J neighbour of I, l<d}, so it is fully described by the node-pair blocks (I,J).
+
+Outputs (host NumPy; moved to the device by the assembler):
+  nbr_ptr[N+1], nbr[nblk]   node graph in CSR form, neighbours sorted (includes I itself)
+  blk_row[nblk]             block row of each block
+  blk_ptr[nblk+1], contrib  per block, the (source block index << 1 | transposed) of every
+                            contributing element block in FS_LAYOUT_SYMBLK, element order
+"""
+import numpy as np
+
+
+def pair_index(nn):
+    """p(i,j) for i<=j in FS_LAYOUT_SYMBLK and the [nn,nn] lookup (transposed flag for i>j)."""
+    P = np.zeros((nn, nn), dtype=np.int64)
+    T = np.zeros((nn, nn), dtype=np.int64)
+    for i in range(nn):
+        for j in range(nn):
+            a, b = (i, j) if i <= j else (j, i)
+            P[i, j] = a * nn - (a * (a - 1)) // 2 + (b - a)
+            T[i, j] = int(i > j)
+    return P, T
+
+
+class BlockPlan:
+    """Node-pair block scatter plan for one element group (uniform nn nodes, d dofs/node)."""
+
+    def __init__(self, conn: np.ndarray, n_nodes: int, d: int):
+        conn = np.ascontiguousarray(conn, dtype=np.int64)
+        E, nn = conn.shape
+        self.n_nodes, self.d, self.nn, self.E = int(n_nodes), int(d), nn, E
+        npair = nn * (nn + 1) // 2
+        if E and (conn.min() < 0 or conn.max() >= n_nodes):
+            raise ValueError("connectivity refers to nodes outside [0, n_nodes)")
+        # (I, J) key of every local node pair, e-major so a stable sort keeps element order
+        keys = (conn[:, :, None] * n_nodes + conn[:, None, :]).reshape(-1)
+        order = np.argsort(keys, kind="stable")
+        skeys = keys[order]
+        first = np.ones(skeys.shape[0], dtype=bool)
+        first[1:] = skeys[1:] != skeys[:-1]
+        ukeys = skeys[first]
+        nblk = ukeys.shape[0]
+        self.nblk = nblk
+        self.blk_row = (ukeys // n_nodes).astype(np.int32)
+        self.nbr = (ukeys % n_nodes).astype(np.int32)
+        self.nbr_ptr = np.searchsorted(self.blk_row, np.arange(n_nodes + 1), side="left").astype(np.int64)
+        starts = np.flatnonzero(first)
+        self.blk_ptr = np.append(starts, skeys.shape[0]).astype(np.int64)
+        P, T = pair_index(nn)
+        e_of = order // (nn * nn)
+        ab = order % (nn * nn)
+        src_blk = e_of * npair + P.reshape(-1)[ab]
+        self.contrib = ((src_blk << 1) | T.reshape(-1)[ab]).astype(np.int64)
+
+    @property
+    def nnz(self):
+        return self.nblk * self.d * self.d
+
+    def row_nnz(self):
+        """`_row_nnz` of the reference (core/assembler.py:241): int32 [n_nodes*d]."""
+        m = np.diff(self.nbr_ptr)
+        return np.repeat(m * self.d, self.d).astype(np.int32)
+
+    def host_pattern(self):
+        """indptr (int64) / indices (int32) on the host (tests, small meshes)."""
+        d = self.d
+        m = np.diff(self.nbr_ptr)
+        indptr = np.zeros(self.n_nodes * d + 1, dtype=np.int64)
+        indptr[1:] = np.cumsum(np.repeat(m * d, d))
+        indices = np.empty(self.nnz, dtype=np.int32)
+        r0 = self.nbr_ptr[self.blk_row]
+        mb = m[self.blk_row]
+        base = d * d * r0 + d * (np.arange(self.nblk) - r0)
+        for k in range(d):
+            for l in range(d):
+                indices[base + k * d * mb + l] = self.nbr * d + l
+        return indptr, indices
+
+
+def generic_plan(dofs_list, sizes, ndof):
+    """Generic per-entry plan for mixed meshes: returns indptr, indices, seg_ptr, src.
+
+    dofs_list: list of (dofs int64 [E_g, nd_g], global element order int64 [E_g]) per element group;
+    sizes: offset of each group's dense [E_g, nd_g, nd_g] matrices in the concatenated value buffer.
+    Summation order inside a slot == order of appearance == the reference's insertion order when
+    groups are concatenated in element order (core/assembler.py:287-300).
+    """
+    keys_all, src_all, ord_all = [], [], []
+    for dofs, base, order in dofs_list_iter(dofs_list, sizes):
+        E, nd = dofs.shape
+        r = np.repeat(dofs, nd, axis=1).reshape(-1)
+        c = np.tile(dofs, (1, nd)).reshape(-1)
+        keys_all.append(r * ndof + c)
+        src_all.append(base + np.arange(E * nd * nd, dtype=np.int64))
+        ord_all.append(np.repeat(order, nd * nd))
+    keys = np.concatenate(keys_all)
+    src = np.concatenate(src_all)
+    eorder = np.concatenate(ord_all)
+    o = np.lexsort((eorder, keys))
+    keys, src = keys[o], src[o]
+    first = np.ones(keys.shape[0], dtype=bool)
+    first[1:] = keys[1:] != keys[:-1]
+    ukeys = keys[first]
+    seg_ptr = np.append(np.flatnonzero(first), keys.shape[0]).astype(np.int64)
+    urow = ukeys // ndof
+    indices = (ukeys % ndof).astype(np.int32)
+    indptr = np.searchsorted(urow, np.arange(ndof + 1), side="left").astype(np.int64)
+    return indptr, indices, seg_ptr, src
+
+
+def dofs_list_iter(dofs_list, sizes):
+    for (dofs, order), base in zip(dofs_list, sizes):
+        yield np.ascontiguousarray(dofs, dtype=np.int64), int(base), np.asarray(order, dtype=np.int64)
