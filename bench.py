@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- MITC4+ element stiffness matrices assembled into CSR per second (fp64).
+
+One "step" = one pass of the hot path over the rank's shard: HIP element kernel (K of every
+element, FS_LAYOUT_SYMBLK) + node-pair-block CSR assembly (+ interface-row exchange when N > 1).
+Inputs (coordinates, connectivity, property table, scatter plan) are resident in HBM before the
+timed region; the symbolic phase (pattern + plan) is precomputed, as north_star specifies.
+
+Workload (BASELINE.json configs[4], the configuration the metric is quoted on, weak-scaled):
+each rank owns a 400 x 3125 strip (1.25 M elements) of the synthetic 3200 x 3125 = 10 M element
+MITC4+ laminate plate (16 laminates striped by x-band, jittered nodes); at N = 8
+the job is the full 10 M element plate.  configs[1] (256x256 hemisphere / twisted beam) and the
+others are parity-test cases (tests/), not bench lines.
+
+Contract: python bench.py --gpus N --steps K --warmup W  (N > 1: launched by torch.distributed.run,
+one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STRIP_NX, STRIP_NY = 400, 3125
+FLOP_PER_ELEM = 27000.0           # MITC4+ K, structured count
+FLOP_PER_ELEM_COUPLING = 4000.0   # + laminate coupling (asymmetric layups only)
+PEAK_FP64_TFLOPS = 78.6           # MI355X fp64 vector == matrix peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def c5_laminates():
+    """16 laminates of the synthetic plate: UD, cross-ply, biax, QI, sandwich-like thick stacks,
+    ~25 % asymmetric (membrane-bending coupling active)."""
+    import fem_shell_amd as fsa
+    m = fsa.OrthotropicMaterial("T300/5208", (181e9, 10.3e9, 10.3e9), (7.17e9, 3.0e9, 7.17e9),
+                                (0.28, 0.28, 0.28), 1600.0)
+    core = fsa.OrthotropicMaterial("core", (0.13e9, 0.13e9, 0.13e9), (0.05e9, 0.05e9, 0.05e9),
+                                   (0.3, 0.3, 0.3), 100.0)
+    t = 1.25e-6  # ply thickness for a 1e-3 cell plate (t/L ~ 1e-2 total)
+    stacks = [
+        [0] * 4, [0, 90, 90, 0], [45, -45, -45, 45], [0, 45, -45, 90, 90, -45, 45, 0],
+        [0, 90], [0, 45, 90], [0, 90, 0, 90], [30, -30, 30],
+        [0, 90] * 4 + [90, 0] * 4, [0, 45, -45, 90] * 2 + [90, -45, 45, 0] * 2,
+        [60, -60, 0, 0, -60, 60], [0, 0, 90, 90, 0, 0], [15, -15, -15, 15], [90] * 6,
+        [0, 30, 60, 90, 60, 30, 0], [45, -45] * 5 + [-45, 45] * 5,
+    ]
+    lams = []
+    for i, ang in enumerate(stacks):
+        plies = [fsa.Ply(m, t, a) for a in ang]
+        if i in (9, 15):  # sandwich-like: thick soft core in the middle
+            h = len(plies) // 2
+            plies = plies[:h] + [fsa.Ply(core, 8 * t, 0.0)] + plies[h:]
+        lams.append(fsa.CompositeShellProperty(fsa.Laminate(plies)))
+    return lams
+
+
+def cpu_baseline(n_threads):
+    """Oracle (CPU restatement of the reference algorithm, oracle/) on a bounded sample of the same
+    workload: element K for a 200 x 250 piece of the strip on all host threads + element-order
+    CSR summation.  Reported baseline only."""
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from oracle import oracle as O
+    nx, ny = 200, 500
+    mesh = meshes.jittered_plate(nx, ny, n_sets=16)
+    table = fsa.build_prop_table(c5_laminates())
+    pid = mesh.set_id.astype(np.int32)
+    xyz = mesh.coords[mesh.conn]
+    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
+    indptr, indices, _ = O.csr_assemble(dofs, mesh.node_count * 6, None)   # symbolic: untimed
+    O.mitc4_K_batch(xyz[:1000], pid[:1000], table, nthreads=n_threads)    # warm the library
+    t0 = time.perf_counter()
+    Ke, _ = O.mitc4_K_batch(xyz, pid, table, nthreads=n_threads)
+    t1 = time.perf_counter()
+    data = np.zeros(indices.shape[0])
+    import ctypes
+    O.lib().fso_csr_numeric(O._p(dofs), ctypes.c_int64(dofs.shape[0]), ctypes.c_int(24), O._p(Ke),
+                            O._p(indptr), O._p(indices), O._p(data))
+    t2 = time.perf_counter()
+    E = xyz.shape[0]
+    return {"value": E / (t2 - t0), "unit": "elements/s", "cores": n_threads, "kind": "port",
+            "sample": f"{nx}x{ny}={E} element piece of the same jittered laminate plate; oracle C "
+                      f"element K on {n_threads} OpenMP threads ({E / (t1 - t0):.3e} el/s) + "
+                      f"single-thread element-order CSR summation ({E / (t2 - t1):.3e} el/s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+
+    lams = c5_laminates()
+    # x-bands of 25 columns cycling through the 16 laminates: every rank's strip sees all 16
+    mesh = meshes.jittered_plate(STRIP_NX, STRIP_NY, cell=1e-3, seed=11, n_sets=16,
+                                 x_offset_cells=rank * STRIP_NX)
+    names = mesh.set_names
+    model = {"elements": {"element_family": ElementFamily.SHELL,
+                          "properties": {names[i]: lams[i] for i in range(16)}}}
+    if world > 1:
+        from fem_shell_amd.dist import DistributedAssembler
+        asm = DistributedAssembler(mesh, model, strip=(rank, world, STRIP_NX, STRIP_NY))
+    else:
+        asm = MeshAssembler(mesh, model)
+    E = mesh.element_count
+    coupled_frac = float(np.mean((asm._prop_table["flags"][asm._prop_id] & 1) != 0))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        asm.assemble_stiffness_matrix(recompute=True)
+    barrier()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
+        ev[1].record()
+        K = asm.assemble_stiffness_matrix(recompute=False)
+        ev[2].record()
+        evs.append(ev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    a_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+
+    if rank == 0:
+        total_E = E * world
+        value = total_E * args.steps / dt
+        flop = FLOP_PER_ELEM + coupled_frac * FLOP_PER_ELEM_COUPLING
+        tflops = E * flop / (k_ms * 1e-3) / 1e12
+        k_bytes = 96 + 4 + 2880            # coords + prop id + 10 symmetric 6x6 blocks
+        a_bytes = 2880 + 16 * 8 + 2592     # packed Ke read + block descriptors + CSR values written
+        k_gbs = E * k_bytes / (k_ms * 1e-3) / 1e9
+        a_gbs = E * a_bytes / (a_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("mitc4_k_kernel", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MITC4+ element stiffness matrices assembled into CSR per second (fp64)",
+            "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C5 synthetic jittered MITC4+ laminate plate, {STRIP_NX}x{STRIP_NY}="
+                                   f"{E} elements per GPU ({total_E} total; 10M at 8 GPUs), 16 laminates "
+                                   f"striped by x-band, {coupled_frac:.0%} of this rank's elements coupled; "
+                                   "step = element K kernel + CSR assembly"
+                                   + (" + RCCL interface-row exchange" if world > 1 else ""),
+                       "elements_per_gpu": E, "nnz_per_gpu": int(K.nnz), "partition": f"x-strips x{world}"},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "kernel": "mitc4_k_kernel", "kernel_ms": k_ms,
+                         "flop_per_element": flop, "note": "fp64 VALU kernel priced against the fp64 "
+                         "peak (vector == matrix peak on MI355X); HBM view of the same kernel: "
+                         f"{k_gbs:.0f} GB/s of {PEAK_HBM_GBS:.0f}"},
+            "assembly": {"kernel": "csr_numeric_blk_kernel<6>", "kernel_ms": a_ms, "bound": "hbm",
+                         "achieved": a_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBS,
+                         "bytes_per_element": a_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            nt = min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(nt)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

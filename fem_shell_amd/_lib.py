@@ -41,6 +41,10 @@ def load():
         raise FemShellHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch ships its own libamdhip64 (same soname as /opt/rocm's): load torch FIRST so that this
+    # library binds to the HIP runtime that owns torch's device buffers and streams -- two HIP
+    # runtimes in one process do not share devices ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here == header/library mismatch

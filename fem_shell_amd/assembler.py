@@ -218,15 +218,22 @@ class MeshAssembler:
                         for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
         self.refresh_element_matrices()
 
-    def refresh_element_matrices(self, want_K=True, want_M=True):
+    def refresh_element_matrices(self, want_K=True, want_M=True, check=True):
         """(Re)run the element kernels: K and M of every element, like the element loop of
-        core/assembler.py:121-193 (which always evaluates both)."""
+        core/assembler.py:121-193 (which always evaluates both).  `check=False` skips the
+        host-synchronising status test (call check_status() later)."""
         out = batch.quad_batch(self._xyz_d, self._pid_d, self._props_d, len(self._prop_table),
                                want_K=want_K, want_M=want_M, status=True)
         if want_K:
             self._K_blk = out["K"]
         if want_M:
             self._M_blk = out["M"]
+        self._status = out["status"]
+        if check:
+            self.check_status()
+
+    def check_status(self):
+        out = {"status": self._status}
         bad = torch.nonzero(out["status"])
         if bad.numel():
             e = int(bad[0])
