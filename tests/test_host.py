@@ -1,0 +1,142 @@
+"""CPU: host logic -- property table and laminate rows bit-identical to the reference's, C-ABI
+library loads and exports every declared symbol, symbolic CSR plan equals the oracle pattern."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fem_shell_amd as fsa
+from fem_shell_amd import meshes, symbolic
+from tests.util_golden import golden, golden_props
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T300 = dict(E=(181e9, 10.3e9, 10.3e9), G=(7.17e9, 3.0e9, 7.17e9), nu=(0.28, 0.28, 0.28), rho=1600.0)
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "femshell_hip.h")).read()
+    names = set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", hdr))
+    assert {"fs_shell_quad_batch", "fs_csr_numeric_blk", "fs_csr_numeric", "fs_last_error"} <= names
+    lib = ctypes.CDLL(os.path.join(ROOT, "fem_shell_amd", "csrc", "libfemshell_hip.so"))
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/femshell_hip.h but not exported"
+    from fem_shell_amd import _lib
+    assert set(_lib.SIGNATURES) == names
+    assert ctypes.sizeof(ctypes.c_double) * 44 + 8 == fsa.properties.PROP_DTYPE.itemsize == 360
+
+
+def test_laminate_rows_bitwise():
+    g = golden("laminate")
+    m = fsa.OrthotropicMaterial("T300/5208", **T300)
+    for i in range(g["n"].shape[0]):
+        ang = g["angles"][i][: int(g["n"][i])].tolist()
+        lam = fsa.create_laminate_from_angles(m, float(g["t"][i]), ang)
+        row = fsa.properties.laminate_row(lam)
+        for k, ref in (("A", g["A"][i]), ("B", g["B"][i]), ("D", g["D"][i]), ("Cs", g["Cs"][i])):
+            assert np.array_equal(row[k], np.asarray(ref).ravel()), (i, k)
+        for k in ("h", "m_t", "m_r", "k_drill"):
+            assert row[k] == g[k][i], (i, k)
+        assert lam.is_symmetric == bool(g["sym"][i])
+        assert bool(row["flags"] & 1) == (not bool(g["sym"][i]))
+    core = fsa.OrthotropicMaterial("core", (0.13e9,) * 3, (0.05e9,) * 3, (0.3,) * 3, 100.0)
+    lam = fsa.Laminate([fsa.Ply(m, 1e-3, 0.0), fsa.Ply(core, 8e-3, 0.0), fsa.Ply(m, 1e-3, 90.0)], 0.4)
+    for k in "ABD":
+        assert np.array_equal(getattr(lam, k), g["hyb_" + k])
+    assert np.array_equal(lam.Cs, g["hyb_Cs"])
+
+
+def test_isotropic_rows_bitwise_vs_reference_elements():
+    """Rows rebuilt from (E, nu, rho, h, kappa) equal what the reference element evaluates."""
+    g = golden("elem_mitc4")
+    ref = golden_props(g)
+    iso = [(2.1e11, 0.3, 7800.0), (4.32e8, 0.0, 360.0), (6.825e7, 0.3, 1.0), (3.0e6, 0.3, 1.0),
+           (29.0e6, 0.22, 1.0), (1.7472e7, 0.3, 1.0)]
+    n = 0
+    for i in range(ref.shape[0]):
+        if g["kind"][i] != 0:
+            continue
+        E, nu, rho = iso[i % len(iso)]
+        kap = [None, 0.8][i % 2] if i % 5 == 0 else None
+        row = fsa.properties.iso_row(fsa.IsotropicMaterial("m", E, nu, rho), float(ref["h"][i]), kap)
+        for k in ("A", "B", "D", "Cs", "h", "m_t", "m_r", "k_drill", "C_raw", "flags"):
+            assert np.array_equal(row[k], ref[k][i]), (i, k)
+        n += 1
+    assert n > 30
+    with pytest.raises(NotImplementedError):   # MITC4.py:673-674
+        fsa.properties.iso_row(fsa.OrthotropicMaterial("o", **T300), 0.01)
+
+
+def test_material_factory():
+    assert isinstance(fsa.Material(E=1.0, nu=0.3, rho=1.0), fsa.IsotropicMaterial)
+    assert isinstance(fsa.Material(E=(1, 1, 1), nu=(.1, .1, .1), G=(1, 1, 1), rho=1.0), fsa.OrthotropicMaterial)
+    with pytest.raises(ValueError):
+        fsa.Material(E=(1, 1, 1), nu=(.1, .1, .1), rho=1.0)
+    with pytest.raises(ValueError):
+        fsa.Laminate([])
+
+
+@pytest.mark.parametrize("tri", [False])
+def test_block_plan_matches_oracle_pattern(oracle, tri):
+    rng = np.random.default_rng(3)
+    mesh = meshes.jittered_plate(13, 9)
+    conn = mesh.conn.copy()
+    conn = conn[rng.permutation(conn.shape[0])]           # element order must not matter for pattern
+    plan = symbolic.BlockPlan(conn, mesh.node_count, 6)
+    ip, ix = plan.host_pattern()
+    dofs = (conn[:, :, None] * 6 + np.arange(6)).reshape(conn.shape[0], -1)
+    oip, oix, _ = oracle.csr_assemble(dofs, mesh.node_count * 6, None)
+    assert np.array_equal(ip, oip) and np.array_equal(ix, oix)
+    assert np.array_equal(plan.row_nnz(), np.diff(oip).astype(np.int32))
+    # contributions inside a block are in element order (== reference insertion order)
+    for b in range(0, plan.nblk, 17):
+        c = plan.contrib[plan.blk_ptr[b]:plan.blk_ptr[b + 1]] >> 1
+        assert (np.diff(c // 10) > 0).all()
+    # numeric emulation of fs_csr_numeric_blk on the host == oracle element-order sum
+    vals = rng.standard_normal((conn.shape[0], 24, 24))
+    vals = vals + vals.transpose(0, 2, 1)
+    _, _, data = oracle.csr_assemble(dofs, mesh.node_count * 6, vals)
+    P, _ = symbolic.pair_index(4)
+    packed = np.empty((conn.shape[0], 10, 36))
+    for i in range(4):
+        for j in range(i, 4):
+            packed[:, P[i, j]] = vals[:, 6 * i:6 * i + 6, 6 * j:6 * j + 6].reshape(-1, 36)
+    flat = packed.reshape(-1, 6, 6)
+    out = np.zeros(plan.nnz)
+    m = np.diff(plan.nbr_ptr)
+    for b in range(plan.nblk):
+        acc = np.zeros((6, 6))
+        for c in plan.contrib[plan.blk_ptr[b]:plan.blk_ptr[b + 1]]:
+            blk = flat[c >> 1]
+            acc = acc + (blk.T if c & 1 else blk)
+        I = plan.blk_row[b]; r0 = plan.nbr_ptr[I]
+        for k in range(6):
+            s = 36 * r0 + k * 6 * m[I] + 6 * (b - r0)
+            out[s:s + 6] = acc[k]
+    assert np.array_equal(out, data)
+
+
+def test_generic_plan_matches_oracle(oracle):
+    mesh = meshes.cylindrical_patch(1.0, 1.0, 40.0, 5, 4)
+    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
+    ip, ix, seg, src = symbolic.generic_plan([(dofs, np.arange(dofs.shape[0]))], [0], mesh.node_count * 6)
+    vals = np.random.default_rng(0).standard_normal((dofs.shape[0], 24, 24))
+    oip, oix, od = oracle.csr_assemble(dofs, mesh.node_count * 6, vals)
+    assert np.array_equal(ip, oip) and np.array_equal(ix, oix)
+    flat = vals.reshape(-1)
+    data = np.array([np.sum(flat[src[seg[s]:seg[s + 1]]]) for s in range(len(ix))])
+    assert np.allclose(data, od, rtol=1e-13, atol=1e-13)
+
+
+def test_mesh_protocol():
+    mesh = meshes.jittered_plate(4, 3, n_sets=2)
+    assert mesh.node_count == 20 and len(mesh.elements) == 12
+    el = mesh.elements[5]
+    assert el.node_count == 4 and len(el.node_ids) == 4 and el.node_coords.shape == (4, 3)
+    assert mesh.node_id_to_index[7] == 7
+    assert set(mesh.element_sets) == {"band_0", "band_1"}
+    assert sum(len(s.elements) for s in mesh.element_sets.values()) == 12
+    a = meshes.jittered_plate(4, 3, x_offset_cells=0).coords.reshape(4, 5, 3)
+    b = meshes.jittered_plate(4, 3, x_offset_cells=4).coords.reshape(4, 5, 3)
+    assert np.array_equal(a[:, 4], b[:, 0])      # shards agree bit for bit on interface nodes
