@@ -89,6 +89,7 @@ class _LazyElementMap:
 
 
 class MeshAssembler:
+    use_descriptors = True   # fs_csr_numeric_desc (False: fs_csr_numeric_blk, same result)
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
@@ -216,6 +217,7 @@ class MeshAssembler:
         p = self._plan
         self._plan_d = {k: torch.from_numpy(getattr(p, k)).to(dev)
                         for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
+        self._desc_d = torch.from_numpy(p.descriptors().view(np.uint8).reshape(-1)).to(dev)
         self.refresh_element_matrices()
 
     def refresh_element_matrices(self, want_K=True, want_M=True, check=True):
@@ -223,7 +225,7 @@ class MeshAssembler:
         core/assembler.py:121-193 (which always evaluates both).  `check=False` skips the
         host-synchronising status test (call check_status() later)."""
         out = batch.quad_batch(self._xyz_d, self._pid_d, self._props_d, len(self._prop_table),
-                               want_K=want_K, want_M=want_M, status=True)
+                               want_K=want_K, want_M=want_M, status=True, validate=False)
         if want_K:
             self._K_blk = out["K"]
         if want_M:
@@ -286,9 +288,14 @@ class MeshAssembler:
     def _assemble(self, blk):
         lib, p, d = _lib.load(), self._plan, self._plan_d
         data = torch.empty(p.nnz, dtype=torch.float64, device=self.device)
-        _lib.check(lib.fs_csr_numeric_blk(_lib.ptr(blk), _lib.ptr(d["nbr_ptr"]), _lib.ptr(d["blk_row"]),
-                                          _lib.ptr(d["blk_ptr"]), _lib.ptr(d["contrib"]), p.nblk, p.d,
-                                          _lib.ptr(data), _lib.stream_ptr()), "fs_csr_numeric_blk")
+        if self.use_descriptors:
+            _lib.check(lib.fs_csr_numeric_desc(_lib.ptr(blk), _lib.ptr(self._desc_d), _lib.ptr(d["contrib"]),
+                                               p.nblk, p.d, _lib.ptr(data), _lib.stream_ptr()),
+                       "fs_csr_numeric_desc")
+        else:
+            _lib.check(lib.fs_csr_numeric_blk(_lib.ptr(blk), _lib.ptr(d["nbr_ptr"]), _lib.ptr(d["blk_row"]),
+                                              _lib.ptr(d["blk_ptr"]), _lib.ptr(d["contrib"]), p.nblk, p.d,
+                                              _lib.ptr(data), _lib.stream_ptr()), "fs_csr_numeric_blk")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
 
     def assemble_stiffness_matrix(self, recompute=False) -> CsrMatrix:

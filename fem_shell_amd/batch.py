@@ -24,7 +24,7 @@ def to_device_props(props: np.ndarray) -> torch.Tensor:
 
 
 def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
-               status=True):
+               status=True, validate=True):
     """MITC4+ element matrices for E quads.
 
     xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
@@ -36,7 +36,7 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
     E = xyz.shape[0]
     assert xyz.dtype == torch.float64 and xyz.shape[1:] == (4, 3) and xyz.is_cuda
     assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
-    if E:
+    if E and validate:   # host-synchronising range check; callers in hot loops validate once
         pmin, pmax = int(prop_id.min()), int(prop_id.max())
         if pmin < 0 or pmax >= n_props:
             raise ValueError("prop_id out of range of the property table")

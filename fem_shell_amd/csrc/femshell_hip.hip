@@ -698,6 +698,43 @@ __global__ __launch_bounds__(256) void csr_numeric_blk_kernel(const double *__re
     data[DD * r0 + (int64_t)k * D * m + D * (b - r0) + l] = v;
 }
 
+
+// node-pair block assembly, descriptor form: one 48-byte descriptor per block carries the output
+// position and up to 4 inline contributions, so the dependent-load chain is descriptor -> values
+// (two round trips) and the value loads of a thread are independent of each other.
+template <int D>
+__global__ __launch_bounds__(256) void csr_numeric_desc_kernel(const double *__restrict__ vals,
+                                                               const fs_blk_desc *__restrict__ desc,
+                                                               const int64_t *__restrict__ contrib,
+                                                               int64_t nblk, double *__restrict__ data) {
+    constexpr int DD = D * D;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * DD) return;
+    const int64_t b = t / DD;
+    const int kl = (int)(t - b * DD);
+    const int k = kl / D, l = kl - k * D;
+    const int lk = l * D + k;
+    const fs_blk_desc dsc = desc[b];
+    double v;
+    if (dsc.cnt <= 4) {
+        double x[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int64_t cc = dsc.c[c];
+            x[c] = (c < dsc.cnt) ? vals[(cc >> 1) * DD + ((cc & 1) ? lk : kl)] : 0.0;
+        }
+        v = ((x[0] + x[1]) + x[2]) + x[3];  // element order == reference insertion order
+    } else {
+        v = 0.0;
+        const int64_t lo = dsc.c[0];
+        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
+            const int64_t cc = contrib[q];
+            v = v + vals[(cc >> 1) * DD + ((cc & 1) ? lk : kl)];
+        }
+    }
+    data[dsc.dst + (int64_t)k * dsc.stride + l] = v;
+}
+
 template <int D>
 __global__ void csr_pattern_blk_kernel(const int64_t *__restrict__ nbr_ptr, const int32_t *__restrict__ blk_row,
                                        const int32_t *__restrict__ nbr, int64_t n_nodes, int64_t nblk,
@@ -827,6 +864,23 @@ int fs_csr_numeric_blk(const double *vals, const int64_t *nbr_ptr, const int32_t
         return fail(FS_EINVAL, "fs_csr_numeric_blk: d must be 3 or 6");
     }
     FS_LAUNCH_CHECK("csr_numeric_blk_kernel");
+    return FS_OK;
+}
+
+int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64_t *contrib,
+                        int64_t nblk, int32_t d, double *data, void *stream) {
+    if (nblk <= 0) return nblk == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric_desc: nblk < 0");
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 6) {
+        hipLaunchKernelGGL(csr_numeric_desc_kernel<6>, dim3(grid_for(nblk * 36, 256, INT32_MAX)), dim3(256), 0, s,
+                           vals, desc, contrib, nblk, data);
+    } else if (d == 3) {
+        hipLaunchKernelGGL(csr_numeric_desc_kernel<3>, dim3(grid_for(nblk * 9, 256, INT32_MAX)), dim3(256), 0, s,
+                           vals, desc, contrib, nblk, data);
+    } else {
+        return fail(FS_EINVAL, "fs_csr_numeric_desc: d must be 3 or 6");
+    }
+    FS_LAUNCH_CHECK("csr_numeric_desc_kernel");
     return FS_OK;
 }
 

@@ -14,6 +14,10 @@ Outputs (host NumPy; moved to the device by the assembler):
 import numpy as np
 
 
+BLK_DESC_DTYPE = np.dtype([("dst", "i8"), ("stride", "i4"), ("cnt", "i4"), ("c", "i8", (4,))])
+assert BLK_DESC_DTYPE.itemsize == 48
+
+
 def pair_index(nn):
     """p(i,j) for i<=j in FS_LAYOUT_SYMBLK and the [nn,nn] lookup (transposed flag for i>j)."""
     P = np.zeros((nn, nn), dtype=np.int64)
@@ -59,6 +63,24 @@ class BlockPlan:
     @property
     def nnz(self):
         return self.nblk * self.d * self.d
+
+    def descriptors(self):
+        """fs_blk_desc rows (include/femshell_hip.h): output position + inline contributions."""
+        d = self.d
+        m = np.diff(self.nbr_ptr)
+        r0 = self.nbr_ptr[self.blk_row]
+        desc = np.zeros(self.nblk, dtype=BLK_DESC_DTYPE)
+        desc["dst"] = d * d * r0 + d * (np.arange(self.nblk) - r0)
+        desc["stride"] = d * m[self.blk_row]
+        cnt = np.diff(self.blk_ptr)
+        desc["cnt"] = cnt
+        start = self.blk_ptr[:-1]
+        for c in range(4):
+            has = (cnt > c) & (cnt <= 4)
+            desc["c"][has, c] = self.contrib[start[has] + c]
+        big = cnt > 4
+        desc["c"][big, 0] = start[big]
+        return desc
 
     def row_nnz(self):
         """`_row_nnz` of the reference (core/assembler.py:241): int32 [n_nodes*d]."""

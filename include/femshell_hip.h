@@ -121,6 +121,22 @@ int fs_csr_numeric_blk(const double *vals, const int64_t *nbr_ptr, const int32_t
                        const int64_t *blk_ptr, const int64_t *contrib, int64_t nblk, int32_t d,
                        double *data, void *stream);
 
+/* Descriptor form of fs_csr_numeric_blk (same result, same summation order; shorter dependent
+ * load chain).  One descriptor per node-pair block, blocks in any order:
+ *   dst     index in `data` of entry (k=0,l=0) of the block
+ *   stride  distance between consecutive rows k of the block in `data` (= d * m_I)
+ *   cnt     number of contributions; cnt <= 4: c[0..cnt) hold them inline
+ *           ((source block index << 1) | transposed, element order); cnt > 4: c[0] is the offset
+ *           of the cnt contributions in `contrib`. */
+typedef struct fs_blk_desc {
+    int64_t dst;
+    int32_t stride;
+    int32_t cnt;
+    int64_t c[4];
+} fs_blk_desc; /* 48 bytes */
+int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64_t *contrib,
+                        int64_t nblk, int32_t d, double *data, void *stream);
+
 /* Symbolic companion of fs_csr_numeric_blk (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph.
  * nbr[nblk] = neighbour node J of each block. */
