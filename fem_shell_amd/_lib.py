@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfemshell_hip.so")
+LIB_PATH = os.environ.get("FEMSHELL_HIP_LIB") or os.path.join(_HERE, "csrc", "libfemshell_hip.so")
 
 FS_WANT_K, FS_WANT_M, FS_WANT_KT, FS_WANT_FINT = 1, 2, 4, 8
 FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK = 0, 1

@@ -735,6 +735,44 @@ __global__ __launch_bounds__(256) void csr_numeric_desc_kernel(const double *__r
     data[dsc.dst + (int64_t)k * dsc.stride + l] = v;
 }
 
+// 16-byte-per-lane variant for even D: thread = (block, k, pair of columns).  Non-transposed
+// contributions are one aligned double2 load; transposed ones two 8-byte loads.
+template <int D>
+__global__ __launch_bounds__(256) void csr_numeric_desc2_kernel(const double *__restrict__ vals,
+                                                                const fs_blk_desc *__restrict__ desc,
+                                                                const int64_t *__restrict__ contrib,
+                                                                int64_t nblk, double *__restrict__ data) {
+    static_assert(D % 2 == 0, "needs an even block size");
+    constexpr int DD = D * D, H = D / 2, TPB = D * H;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * TPB) return;
+    const int64_t b = t / TPB;
+    const int r = (int)(t - b * TPB);
+    const int k = r / H, l = 2 * (r - k * H);
+    const fs_blk_desc dsc = desc[b];
+    auto fetch = [&](int64_t cc) -> double2 {
+        const double *base = vals + (cc >> 1) * DD;
+        if (cc & 1) return make_double2(base[l * D + k], base[(l + 1) * D + k]);
+        return *reinterpret_cast<const double2 *>(base + k * D + l);
+    };
+    double2 v;
+    if (dsc.cnt <= 4) {
+        double2 x[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) x[c] = (c < dsc.cnt) ? fetch(dsc.c[c]) : make_double2(0.0, 0.0);
+        v.x = ((x[0].x + x[1].x) + x[2].x) + x[3].x;  // element order == reference insertion order
+        v.y = ((x[0].y + x[1].y) + x[2].y) + x[3].y;
+    } else {
+        v = make_double2(0.0, 0.0);
+        const int64_t lo = dsc.c[0];
+        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
+            const double2 x = fetch(contrib[q]);
+            v.x = v.x + x.x; v.y = v.y + x.y;
+        }
+    }
+    *reinterpret_cast<double2 *>(data + dsc.dst + (int64_t)k * dsc.stride + l) = v;
+}
+
 template <int D>
 __global__ void csr_pattern_blk_kernel(const int64_t *__restrict__ nbr_ptr, const int32_t *__restrict__ blk_row,
                                        const int32_t *__restrict__ nbr, int64_t n_nodes, int64_t nblk,
@@ -872,7 +910,7 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
     if (nblk <= 0) return nblk == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric_desc: nblk < 0");
     hipStream_t s = (hipStream_t)stream;
     if (d == 6) {
-        hipLaunchKernelGGL(csr_numeric_desc_kernel<6>, dim3(grid_for(nblk * 36, 256, INT32_MAX)), dim3(256), 0, s,
+        hipLaunchKernelGGL(csr_numeric_desc2_kernel<6>, dim3(grid_for(nblk * 18, 256, INT32_MAX)), dim3(256), 0, s,
                            vals, desc, contrib, nblk, data);
     } else if (d == 3) {
         hipLaunchKernelGGL(csr_numeric_desc_kernel<3>, dim3(grid_for(nblk * 9, 256, INT32_MAX)), dim3(256), 0, s,
