@@ -93,7 +93,8 @@ class MeshAssembler:
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
-    def __init__(self, mesh, model: Dict, comm=None, device=None):
+    def __init__(self, mesh, model: Dict, comm=None, device=None, plan=None):
+        self._given_plan = plan   # precomputed BlockPlan (distributed runs add ghost columns)
         self.mesh = mesh
         self.model = model["elements"]
         self.comm = comm
@@ -213,7 +214,7 @@ class MeshAssembler:
         self._xyz_d = torch.from_numpy(coords).to(dev)[self._conn_d]          # [E,4,3] gather (plumbing)
         self._pid_d = torch.from_numpy(self._prop_id).to(dev)
         self._props_d = batch.to_device_props(self._prop_table)
-        self._plan = BlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node)
+        self._plan = self._given_plan or BlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node)
         p = self._plan
         self._plan_d = {k: torch.from_numpy(getattr(p, k)).to(dev)
                         for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}

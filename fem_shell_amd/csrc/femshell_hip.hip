@@ -803,6 +803,21 @@ __global__ void gather_dofs_kernel(const double *__restrict__ u, const int64_t *
         ue[t] = u[dofs[t]];
 }
 
+// interface-row exchange helpers: pack ghost-row values, add received values
+__global__ void halo_pack_kernel(const double *__restrict__ data, const int64_t *__restrict__ idx,
+                                 int64_t n, double *__restrict__ buf) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (int64_t)gridDim.x * blockDim.x)
+        buf[t] = data[idx[t]];
+}
+__global__ void halo_add_kernel(const double *__restrict__ buf, const int64_t *__restrict__ idx,
+                                int64_t n, double *__restrict__ data) {
+    // idx holds each destination at most once per message, so plain read-modify-write is race-free
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (int64_t)gridDim.x * blockDim.x)
+        data[idx[t]] = data[idx[t]] + buf[t];
+}
+
 inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -938,6 +953,22 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
         return fail(FS_EINVAL, "fs_csr_pattern_blk: d must be 3 or 6");
     }
     FS_LAUNCH_CHECK("csr_pattern_blk_kernel");
+    return FS_OK;
+}
+
+int fs_halo_pack(const double *data, const int64_t *idx, int64_t n, double *buf, void *stream) {
+    if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_halo_pack: n < 0");
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, data,
+                       idx, n, buf);
+    FS_LAUNCH_CHECK("halo_pack_kernel");
+    return FS_OK;
+}
+
+int fs_halo_add(const double *buf, const int64_t *idx, int64_t n, double *data, void *stream) {
+    if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_halo_add: n < 0");
+    hipLaunchKernelGGL(halo_add_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, buf,
+                       idx, n, data);
+    FS_LAUNCH_CHECK("halo_add_kernel");
     return FS_OK;
 }
 

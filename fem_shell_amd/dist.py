@@ -1,0 +1,242 @@
+"""Multi-GPU assembly: element-block partition + interface-row exchange.
+
+One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI on the GPU box, "gloo"
+for the CPU rehearsal of the host-side plan).  Every rank holds a block of elements with the
+nodes they touch.  Block rows (nodes) are owned by the lowest rank that holds them.  Per matrix:
+
+    local assembly (fs_csr_numeric_desc)  ->  fs_halo_pack of the rows this rank does not own
+    ->  grouped ncclSend/ncclRecv (batch_isend_irecv)  ->  fs_halo_add on the owner, neighbours
+    in ascending rank order (deterministic).
+
+The pattern of owned interface rows is completed once, at symbolic time, with the ghost columns the
+neighbours contribute (exchange of (I,J) global node pairs), so the numeric exchange moves values
+only.  The reference has no counterpart: its assembler is serial (core/assembler.py:37,257-262).
+
+`DistributedPlan` is pure host/NumPy + torch.distributed and runs on CPU (gloo) -- that is what the
+world_size-2 tests exercise; `DistributedAssembler` adds the device buffers and HIP kernels.
+"""
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .symbolic import BlockPlan
+
+
+def _comm_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _allgather_arrays(arr: np.ndarray):
+    """all_gather of variable-length int64 arrays (padded tensor collective; no pickling)."""
+    dev = _comm_device()
+    world = dist.get_world_size()
+    n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.int64, device=dev)
+    buf[: arr.shape[0]] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
+    out = [torch.zeros(mx, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
+
+
+def _exchange(send: Dict[int, np.ndarray], peers, dtype=torch.int64):
+    """Point-to-point exchange of 1-D arrays with every rank in `peers` (sizes first)."""
+    dev = _comm_device()
+    rank = dist.get_rank()
+    peers = sorted(p for p in peers if p != rank)
+    if not peers:
+        return {}
+    nsend = {p: torch.tensor([send[p].shape[0] if p in send else 0], dtype=torch.int64, device=dev) for p in peers}
+    nrecv = {p: torch.zeros(1, dtype=torch.int64, device=dev) for p in peers}
+    ops = [dist.P2POp(dist.isend, nsend[p], p) for p in peers] + [dist.P2POp(dist.irecv, nrecv[p], p) for p in peers]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    sbuf = {p: torch.from_numpy(np.ascontiguousarray(send[p])).to(dev) for p in peers if p in send and send[p].shape[0]}
+    rbuf = {p: torch.zeros(int(nrecv[p].item()), dtype=dtype, device=dev) for p in peers if int(nrecv[p].item())}
+    ops = [dist.P2POp(dist.isend, sbuf[p], p) for p in sbuf] + [dist.P2POp(dist.irecv, rbuf[p], p) for p in rbuf]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return {p: rbuf[p].cpu().numpy() for p in rbuf}
+
+
+class DistributedPlan:
+    """Symbolic phase of the distributed assembly for one rank.
+
+    conn [E,nn]   local connectivity in LOCAL node indices
+    l2g  [Nloc]   global node id of every local node
+    d             dofs per node
+    After construction:
+      nodes_g      sorted global ids of the extended local node set (local nodes + ghost columns)
+      conn_x       connectivity renumbered into that set
+      plan         BlockPlan over the extended set (owned interface rows carry their ghost columns)
+      owned        bool per extended node: this rank owns the block row
+      send_idx[q]  indices into the local CSR values to ship to owner q (rows I do not own)
+      recv_idx[q]  indices into the local CSR values where the values received from q are added
+    """
+
+    def __init__(self, conn, l2g, d):
+        rank, world = dist.get_rank(), dist.get_world_size()
+        self.rank, self.world, self.d = rank, world, int(d)
+        conn = np.asarray(conn, dtype=np.int64)
+        l2g = np.asarray(l2g, dtype=np.int64)
+        gconn = l2g[conn]
+        mine = np.unique(gconn)
+        # --- who else holds my nodes?  owner = lowest rank holding the node
+        all_nodes = _allgather_arrays(mine)
+        owner = np.full(mine.shape[0], rank, dtype=np.int64)
+        sharers = {}
+        for q in range(world):
+            if q == rank:
+                continue
+            shared = np.isin(mine, all_nodes[q], assume_unique=True)
+            if shared.any():
+                sharers[q] = shared
+                owner = np.where(shared & (q < owner), q, owner)
+        self.neighbors = sorted(sharers)
+        # --- local node graph in global ids (provisional plan on the compact local numbering)
+        loc = np.searchsorted(mine, gconn)
+        p0 = BlockPlan(loc, mine.shape[0], d)
+        gI, gJ = mine[p0.blk_row], mine[p0.nbr]
+        ghost_row = owner[p0.blk_row] != rank
+        # --- ship the (I,J) pairs of rows I do not own to their owners
+        send_pairs = {}
+        for q in self.neighbors:
+            sel = ghost_row & (owner[p0.blk_row] == q)
+            if sel.any():
+                send_pairs[q] = np.stack([gI[sel], gJ[sel]], 1).reshape(-1)   # sorted by (I,J)
+        recv_pairs = _exchange(send_pairs, self.neighbors)
+        recv_pairs = {q: v.reshape(-1, 2) for q, v in recv_pairs.items()}
+        # --- extended node set and final plan
+        extra_nodes = [v[:, 1] for v in recv_pairs.values()]
+        self.nodes_g = np.unique(np.concatenate([mine] + extra_nodes)) if extra_nodes else mine
+        X = self.nodes_g
+        self.conn_x = np.searchsorted(X, gconn)
+        extra = [np.searchsorted(X, v) for v in recv_pairs.values()]
+        self.plan = BlockPlan(self.conn_x, X.shape[0], d, np.concatenate(extra) if extra else None)
+        own_x = np.zeros(X.shape[0], dtype=bool)
+        own_x[np.searchsorted(X, mine[owner == rank])] = True
+        self.owned = own_x
+        self.local_of_ext = np.searchsorted(X, mine)        # compact local -> extended index
+        # --- value-exchange index lists.  Message layout (both sides): rows sorted by global I,
+        #     inside a row k-major, then the sender's neighbours sorted by global J, then l.
+        P = self.plan
+        m = np.diff(P.nbr_ptr)
+        self.send_idx, self.recv_idx = {}, {}
+        kk, ll = np.meshgrid(np.arange(d), np.arange(d), indexing="ij")
+        for q, pairs in send_pairs.items():
+            pr = pairs.reshape(-1, 2)
+            self.send_idx[q] = self._value_index(pr, pr, X, P, m, kk, ll)
+        for q, pr in recv_pairs.items():
+            self.recv_idx[q] = self._value_index(pr, pr, X, P, m, kk, ll)
+
+    @staticmethod
+    def _value_index(pairs, _unused, X, P, m, kk, ll):
+        """CSR value indices of the blocks `pairs` (global (I,J), sorted) in message order."""
+        d = P.d
+        I = np.searchsorted(X, pairs[:, 0])
+        J = np.searchsorted(X, pairs[:, 1])
+        # block index of (I,J): binary search inside the row
+        key = I.astype(np.int64) * P.n_nodes + J
+        allkey = P.blk_row.astype(np.int64) * P.n_nodes + P.nbr
+        b = np.searchsorted(allkey, key)
+        assert np.array_equal(allkey[b], key), "exchange pair missing from the local pattern"
+        r0 = P.nbr_ptr[I]
+        base = d * d * r0 + d * (b - r0)                       # entry (k=0,l=0)
+        stride = d * m[I]
+        # message order: row I, k, sender-rank-of-J r, l  -> sort blocks by (I, k) with r inside
+        rows, start = np.unique(pairs[:, 0], return_index=True)
+        cnt = np.diff(np.append(start, pairs.shape[0]))
+        out = []
+        for s, c in zip(start, cnt):
+            bb, ss = base[s:s + c], stride[s:s + c]
+            idx = bb[None, :, None] + np.arange(d)[:, None, None] * ss[None, :, None] + np.arange(d)[None, None, :]
+            out.append(idx.reshape(-1))
+        return np.concatenate(out).astype(np.int64) if out else np.zeros(0, dtype=np.int64)
+
+    # ------------------------------------------------------------------ host emulation (tests)
+    def exchange_host(self, data: np.ndarray) -> np.ndarray:
+        """NumPy stand-in of pack -> send/recv -> add (what DistributedAssembler does on the GPU)."""
+        send = {q: data[idx] for q, idx in self.send_idx.items()}
+        recv = _exchange(send, self.neighbors, dtype=torch.float64)
+        out = data.copy()
+        for q in sorted(recv):
+            out[self.recv_idx[q]] = out[self.recv_idx[q]] + recv[q]
+        return out
+
+
+class DistributedAssembler:
+    """MeshAssembler over this rank's element block + RCCL interface exchange.
+
+    `mesh` is the rank's local ArrayMesh; `l2g` its global node ids.  For the bench's x-strip
+    partition pass strip=(rank, world, nx, ny) and l2g is derived."""
+
+    def __init__(self, mesh, model, l2g=None, strip=None):
+        from . import _lib, batch
+        from .assembler import MeshAssembler
+        if l2g is None:
+            if strip is None:
+                raise ValueError("need l2g or strip")
+            rank, world, nx, ny = strip
+            gx = np.arange(nx + 1, dtype=np.int64) + rank * nx
+            gy = np.arange(ny + 1, dtype=np.int64)
+            l2g = (gy[:, None] * (world * nx + 1) + gx[None, :]).reshape(-1)
+        self.dplan = DistributedPlan(mesh.conn, l2g, 6)
+        # the local assembler works on the extended node set (ghost columns appended in id order)
+        from .meshes import ArrayMesh
+        X = self.dplan.nodes_g
+        coords = np.full((X.shape[0], 3), np.nan)
+        order = np.argsort(np.asarray(l2g), kind="stable")
+        coords[np.searchsorted(X, np.asarray(l2g)[order])] = mesh.coords[order]
+        ext = ArrayMesh(coords, self.dplan.conn_x, mesh.set_id, mesh.set_names)
+        self.local = MeshAssembler(ext, model, plan=self.dplan.plan)
+        dev = self.local.device
+        self._send = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.send_idx.items()}
+        self._recv = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.recv_idx.items()}
+        self._sbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._send.items()}
+        self._rbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._recv.items()}
+        self._lib, self._libmod = _lib.load(), _lib
+        self._prop_table, self._prop_id = self.local._prop_table, self.local._prop_id
+        self.owned_rows = np.repeat(self.dplan.owned, 6)
+
+    def refresh_element_matrices(self, **kw):
+        return self.local.refresh_element_matrices(**kw)
+
+    def check_status(self):
+        return self.local.check_status()
+
+    def _exchange(self, A):
+        L, lib = self._libmod, self._lib
+        s = L.stream_ptr()
+        for q, idx in self._send.items():
+            L.check(lib.fs_halo_pack(L.ptr(A.data), L.ptr(idx), idx.numel(), L.ptr(self._sbuf[q]), s), "fs_halo_pack")
+        if dist.get_backend() == "nccl":     # RCCL: grouped ncclSend/ncclRecv on device buffers
+            sb, rb = self._sbuf, self._rbuf
+        else:                                # gloo rehearsal (one-GPU box): stage through the host
+            sb = {q: b.cpu() for q, b in self._sbuf.items()}
+            rb = {q: torch.empty(b.numel(), dtype=torch.float64) for q, b in self._rbuf.items()}
+        ops = [dist.P2POp(dist.isend, sb[q], q) for q in sorted(sb)] + \
+              [dist.P2POp(dist.irecv, rb[q], q) for q in sorted(rb)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if rb is not self._rbuf:
+            for q in rb:
+                self._rbuf[q].copy_(rb[q])
+        for q in sorted(self._recv):
+            idx = self._recv[q]
+            L.check(lib.fs_halo_add(L.ptr(self._rbuf[q]), L.ptr(idx), idx.numel(), L.ptr(A.data), s), "fs_halo_add")
+        return A
+
+    def assemble_stiffness_matrix(self, recompute=False):
+        """Owned rows of the returned CSR (see `owned_rows`) hold the globally assembled values;
+        column j of the local matrix is global DOF 6*nodes_g[j//6] + j%6."""
+        return self._exchange(self.local.assemble_stiffness_matrix(recompute=recompute))
+
+    def assemble_mass_matrix(self, recompute=False):
+        return self._exchange(self.local.assemble_mass_matrix(recompute=recompute))

@@ -33,7 +33,9 @@ def pair_index(nn):
 class BlockPlan:
     """Node-pair block scatter plan for one element group (uniform nn nodes, d dofs/node)."""
 
-    def __init__(self, conn: np.ndarray, n_nodes: int, d: int):
+    def __init__(self, conn: np.ndarray, n_nodes: int, d: int, extra_pairs=None):
+        """extra_pairs: optional int64 [n,2] node pairs (I,J) that must exist in the pattern even
+        without a local contribution (ghost columns of interface rows in a distributed run)."""
         conn = np.ascontiguousarray(conn, dtype=np.int64)
         E, nn = conn.shape
         self.n_nodes, self.d, self.nn, self.E = int(n_nodes), int(d), nn, E
@@ -47,13 +49,15 @@ class BlockPlan:
         first = np.ones(skeys.shape[0], dtype=bool)
         first[1:] = skeys[1:] != skeys[:-1]
         ukeys = skeys[first]
+        if extra_pairs is not None and len(extra_pairs):
+            ep = np.asarray(extra_pairs, dtype=np.int64)
+            ukeys = np.union1d(ukeys, ep[:, 0] * n_nodes + ep[:, 1])
         nblk = ukeys.shape[0]
         self.nblk = nblk
         self.blk_row = (ukeys // n_nodes).astype(np.int32)
         self.nbr = (ukeys % n_nodes).astype(np.int32)
         self.nbr_ptr = np.searchsorted(self.blk_row, np.arange(n_nodes + 1), side="left").astype(np.int64)
-        starts = np.flatnonzero(first)
-        self.blk_ptr = np.append(starts, skeys.shape[0]).astype(np.int64)
+        self.blk_ptr = np.append(np.searchsorted(skeys, ukeys, side="left"), skeys.shape[0]).astype(np.int64)
         P, T = pair_index(nn)
         e_of = order // (nn * nn)
         ab = order % (nn * nn)

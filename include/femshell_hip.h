@@ -149,6 +149,14 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
 int fs_vec_gather_sum(const double *vals, const int64_t *src, const int64_t *seg_ptr,
                       int64_t n, double *out, void *stream);
 
+/* Multi-GPU interface exchange (new; the reference is serial, core/assembler.py:37,257-262 only
+ * stores a communicator).  Ranks own block rows; a rank packs the partial sums of the rows it
+ * does not own (fs_halo_pack: buf[t] = data[idx[t]]), ships them to the owner over RCCL, and the
+ * owner adds them in ascending neighbour-rank order (fs_halo_add: data[idx[t]] += buf[t]; idx
+ * unique within one message). */
+int fs_halo_pack(const double *data, const int64_t *idx, int64_t n, double *buf, void *stream);
+int fs_halo_add(const double *buf, const int64_t *idx, int64_t n, double *data, void *stream);
+
 /* u_e[e][a] = u[dofs[e][a]]  (gather for KT / f_int re-assembly) */
 int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream);
 

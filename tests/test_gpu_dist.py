@@ -1,0 +1,66 @@
+"""GPU: DistributedAssembler with 2 ranks sharing the one GPU of the box (gloo transport; the
+8-GPU RCCL run is the driver's).  Owned rows must equal the serial single-GPU assembly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, nx, ny, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fem_shell_amd import meshes
+        from fem_shell_amd.assembler import MeshAssembler
+        from fem_shell_amd.dist import DistributedAssembler
+        from fem_shell_amd.elements import ElementFamily
+        from tests import util
+        props = util.standard_props()
+        model = {"elements": {"element_family": ElementFamily.SHELL,
+                              "properties": {f"band_{i}": props[i] for i in range(8)}}}
+        g = meshes.jittered_plate(nx * world, ny, n_sets=8)
+        ref = MeshAssembler(g, model).assemble_stiffness_matrix().to_scipy()
+        loc = meshes.jittered_plate(nx, ny, n_sets=8, x_offset_cells=rank * nx)
+        # the strip must use the GLOBAL band of each element
+        loc.set_id = g.set_id.reshape(ny, nx * world)[:, rank * nx:(rank + 1) * nx].reshape(-1).copy()
+        da = DistributedAssembler(loc, model, strip=(rank, world, nx, ny))
+        A = da.assemble_stiffness_matrix(recompute=True)
+        ip, ix, data = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy()
+        X = da.dplan.nodes_g
+        worst = 0.0
+        for r in np.flatnonzero(da.owned_rows):
+            gr = 6 * X[r // 6] + r % 6
+            cols = 6 * X[ix[ip[r]:ip[r + 1]] // 6] + ix[ip[r]:ip[r + 1]] % 6
+            assert np.array_equal(cols, ref.indices[ref.indptr[gr]:ref.indptr[gr + 1]])
+            worst = max(worst, np.abs(data[ip[r]:ip[r + 1]] - ref.data[ref.indptr[gr]:ref.indptr[gr + 1]]).max())
+        assert worst <= 1e-13 * np.abs(ref.data).max(), worst
+        q.put((rank, int(da.owned_rows.sum()), None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 9, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 6 * 19 * 8

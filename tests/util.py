@@ -42,3 +42,36 @@ def random_quads(n, seed=0, far=True):
             q = np.array([[0, 0, 0], [2, 0, 0], [2.5, 1, 0], [.5, 1, 0]], float)    # parallelogram
         xyz[t] = q * scale + off
     return xyz
+
+
+def pack_symblk(dense, nn=4, d=6):
+    """dense [E, nn*d, nn*d] -> FS_LAYOUT_SYMBLK [E, npair, d*d] (host, tests only)."""
+    from fem_shell_amd.symbolic import pair_index
+    P, _ = pair_index(nn)
+    out = np.empty((dense.shape[0], nn * (nn + 1) // 2, d * d))
+    for i in range(nn):
+        for j in range(i, nn):
+            out[:, P[i, j]] = dense[:, d * i:d * i + d, d * j:d * j + d].reshape(-1, d * d)
+    return out
+
+
+def host_block_assemble(plan, packed):
+    """NumPy emulation of fs_csr_numeric_desc (same element-order summation); tests only."""
+    d = plan.d
+    flat = packed.reshape(-1, d, d)
+    cnt = np.diff(plan.blk_ptr)
+    acc = np.zeros((plan.nblk, d, d))
+    for c in range(int(cnt.max()) if cnt.size else 0):
+        has = cnt > c
+        cc = plan.contrib[plan.blk_ptr[:-1][has] + c]
+        blk = flat[cc >> 1]
+        blk = np.where((cc & 1)[:, None, None].astype(bool), blk.transpose(0, 2, 1), blk)
+        acc[has] = acc[has] + blk
+    m = np.diff(plan.nbr_ptr)
+    r0 = plan.nbr_ptr[plan.blk_row]
+    base = d * d * r0 + d * (np.arange(plan.nblk) - r0)
+    stride = d * m[plan.blk_row]
+    idx = base[:, None, None] + np.arange(d)[None, :, None] * stride[:, None, None] + np.arange(d)[None, None, :]
+    data = np.zeros(plan.nnz)
+    data[idx.reshape(-1)] = acc.reshape(-1)
+    return data
