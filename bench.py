@@ -106,9 +106,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    backend = os.environ.get("FEMSHELL_DIST_BACKEND", "nccl")   # "gloo": one-GPU rehearsal only
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import fem_shell_amd as fsa
     from fem_shell_amd import meshes
@@ -163,17 +169,29 @@ def main():
         value = total_E * args.steps / dt
         flop = FLOP_PER_ELEM + coupled_frac * FLOP_PER_ELEM_COUPLING
         tflops = E * flop / (k_ms * 1e-3) / 1e12
-        k_bytes = 96 + 4 + 2880            # coords + prop id + 10 symmetric 6x6 blocks
-        a_bytes = 2880 + 16 * 8 + 2592     # packed Ke read + block descriptors + CSR values written
+        # algorithmic bytes per element (DESIGN.md "Kernels"): K kernel reads 12 coords + prop id and
+        # writes the 10 symmetric 6x6 blocks; the assembly kernel reads those blocks once and writes
+        # the amortised 324 CSR values (block descriptors are overhead, not counted).
+        k_bytes = 96 + 4 + 2880
+        a_bytes = 2880 + 2592
         k_gbs = E * k_bytes / (k_ms * 1e-3) / 1e9
         a_gbs = E * a_bytes / (a_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("mitc4_k_kernel", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        except Exception:
+            pmc = {}
+        k_obj = {"kernel": "mitc4_k_kernel", "kernel_ms": k_ms, "bound": "mfma", "achieved": tflops,
+                 "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
+                 "traffic": pmc.get("mitc4_k_kernel", {}).get("hbm_bytes_per_launch"),
+                 "flop_per_element": flop,
+                 "note": "fp64 VALU kernel priced against the fp64 peak (vector == matrix peak on "
+                         f"MI355X); HBM view of the same launch: {k_gbs:.0f} GB/s of {PEAK_HBM_GBS:.0f}"}
+        a_obj = {"kernel": "csr_numeric_desc2_kernel<6>", "kernel_ms": a_ms, "bound": "hbm",
+                 "achieved": a_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBS,
+                 "traffic": pmc.get("csr_numeric_desc2_kernel", {}).get("hbm_bytes_per_launch"),
+                 "bytes_per_element": a_bytes}
+        dominant, other = (k_obj, a_obj) if k_ms >= a_ms else (a_obj, k_obj)
         line = {
             "metric": "MITC4+ element stiffness matrices assembled into CSR per second (fp64)",
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,
@@ -185,15 +203,8 @@ def main():
                                    "step = element K kernel + CSR assembly"
                                    + (" + RCCL interface-row exchange" if world > 1 else ""),
                        "elements_per_gpu": E, "nnz_per_gpu": int(K.nnz), "partition": f"x-strips x{world}"},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "kernel": "mitc4_k_kernel", "kernel_ms": k_ms,
-                         "flop_per_element": flop, "note": "fp64 VALU kernel priced against the fp64 "
-                         "peak (vector == matrix peak on MI355X); HBM view of the same kernel: "
-                         f"{k_gbs:.0f} GB/s of {PEAK_HBM_GBS:.0f}"},
-            "assembly": {"kernel": "csr_numeric_blk_kernel<6>", "kernel_ms": a_ms, "bound": "hbm",
-                         "achieved": a_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBS,
-                         "bytes_per_element": a_bytes},
+            "roofline": dominant,          # the kernel with the longer average launch
+            "roofline_other_kernel": other,
         }
         if not args.no_cpu_baseline and world == 1:
             nt = min(16, os.cpu_count() or 1)
