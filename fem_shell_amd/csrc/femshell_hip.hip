@@ -192,11 +192,12 @@ __device__ __forceinline__ double jacobian(const QuadGeom &g, const double *dxi,
 // makes every stage-2 read (uniform component and Gauss point, per-lane node) conflict-free:
 // within a 32-lane group the 8 quads x 4 nodes map to 32 distinct double-banks.
 // ------------------------------------------------------------------------------------------
-constexpr int NC = 17;  // per (node, gp): Bm[3][3] | dNdx dNdy | Bs[2][3]
-constexpr int C_BM = 0, C_DN = 9, C_BS = 11;
+constexpr int NC = 8;  // per (node, gp): dNdx dNdy | Bs[2][3]
+constexpr int C_DN = 0, C_BS = 2;
 constexpr int LDS_DET = NC * 4 * 64;       // detJ[g][Q]
 constexpr int LDS_KNB = LDS_DET + 64;      // condensation rows Knb[c<6][node][Q]
-constexpr int LDS_WAVE = LDS_KNB + 6 * 64; // 4800 doubles = 38400 B
+constexpr int LDS_U = LDS_KNB + 6 * 64;    // coupling U[c<10][node][Q] (only written when coupled)
+constexpr int LDS_WAVE = LDS_U + 10 * 64;  // 3136 doubles = 25088 B
 
 __device__ __forceinline__ int lds_slot(int c, int g, int node, int Q) {
     return ((c * 4 + g) << 6) + ((Q >> 3) << 5) + (node << 3) + (Q & 7);
@@ -208,8 +209,25 @@ __device__ __forceinline__ double quad_sum(double v) {
     return v;
 }
 
+// tying shape-derivative weights of node i: dN/dxi at A,B ; dN/deta at C,D ; dN/deta, dN/dxi at E
+__device__ __forceinline__ void tying_weights(int i, double *w) {
+    w[0] = (i == 2) ? 0.5 : ((i == 3) ? -0.5 : 0.0);    // A (0, 1)
+    w[1] = (i == 0) ? -0.5 : ((i == 1) ? 0.5 : 0.0);    // B (0,-1)
+    w[2] = (i == 1) ? -0.5 : ((i == 2) ? 0.5 : 0.0);    // C ( 1,0)
+    w[3] = (i == 0) ? -0.5 : ((i == 3) ? 0.5 : 0.0);    // D (-1,0)
+    w[4] = (i >= 2) ? 0.125 : -0.125;                   // E: 0.5 * dN/deta
+    w[5] = (i == 1 || i == 2) ? 0.125 : -0.125;         // E: 0.5 * dN/dxi
+}
+
 // ------------------------------------------------------------------------------------------
 // MITC4+ stiffness, FS_LAYOUT_SYMBLK output
+//
+// Membrane (and membrane-bending coupling) are PRE-CONTRACTED: with Y (5 x 12) the tying-row
+// matrix (constant over the element) and W_g (3 x 5) = T_eps(g) * blend(g), B_m(g) = W_g Y, so
+//   K_m = Y^T S Y,  S = sum_g detJ_g W_g^T C_m W_g   (5 x 5, symmetric)
+//   K_c = Y^T U + U^T Y,  U_j = sum_g detJ_g W_g^T (B_lam B_kappa_j(g))   (5 x 2 per node)
+// which is the same sum of products as MITC4.py:934-944 re-associated (eps-level difference) and
+// removes B_m from LDS and from the Gauss-point loop of every node-pair task.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
                                                      const int32_t *__restrict__ prop_id,
@@ -233,6 +251,8 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         }
     }
     const fs_shell_prop *pr = props + prop_id[e];
+    const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
+    const bool any_coupled = __any(coupled);
 
     QuadGeom geo;
     quad_geometry(x, geo);
@@ -247,26 +267,27 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     int st = geo.status | ((detJ > 0.0) ? 0 : FS_ST_BAD_JAC);
 
     // tangent vectors at the 5 tying points (MITC4.py:589-612 evaluated at A,B,C,D,E; the zero
-    // shape-derivative terms are dropped, which is exact), projected on the frame (:287-296)
-    double grA[3], grB[3], gsC[3], gsD[3], grE[3], gsE[3];
+    // shape-derivative terms are dropped, which is exact), projected on the frame (:287-296).
+    // gt[0..3] = g_r(A), g_r(B), g_s(C), g_s(D); gt[4], gt[5] = g_r(E), g_s(E)
+    double gt[6][3];
     {
         double t3[3];
         for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
-        grA[0] = dot3(t3, geo.e1); grA[1] = dot3(t3, geo.e2); grA[2] = dot3(t3, geo.e3);
+        gt[0][0] = dot3(t3, geo.e1); gt[0][1] = dot3(t3, geo.e2); gt[0][2] = dot3(t3, geo.e3);
         for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
-        grB[0] = dot3(t3, geo.e1); grB[1] = dot3(t3, geo.e2); grB[2] = dot3(t3, geo.e3);
+        gt[1][0] = dot3(t3, geo.e1); gt[1][1] = dot3(t3, geo.e2); gt[1][2] = dot3(t3, geo.e3);
         for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
-        gsC[0] = dot3(t3, geo.e1); gsC[1] = dot3(t3, geo.e2); gsC[2] = dot3(t3, geo.e3);
+        gt[2][0] = dot3(t3, geo.e1); gt[2][1] = dot3(t3, geo.e2); gt[2][2] = dot3(t3, geo.e3);
         for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
-        gsD[0] = dot3(t3, geo.e1); gsD[1] = dot3(t3, geo.e2); gsD[2] = dot3(t3, geo.e3);
+        gt[3][0] = dot3(t3, geo.e1); gt[3][1] = dot3(t3, geo.e2); gt[3][2] = dot3(t3, geo.e3);
         for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
-        grE[0] = dot3(t3, geo.e1); grE[1] = dot3(t3, geo.e2); grE[2] = dot3(t3, geo.e3);
+        gt[4][0] = dot3(t3, geo.e1); gt[4][1] = dot3(t3, geo.e2); gt[4][2] = dot3(t3, geo.e3);
         for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
-        gsE[0] = dot3(t3, geo.e1); gsE[1] = dot3(t3, geo.e2); gsE[2] = dot3(t3, geo.e3);
+        gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
     }
 
     const int qoff = ((Q >> 3) << 5) + (Q & 7);
-    double knb[4][3][2];  // partial Knb of this Gauss point: node, (w,thx,thy), bubble
+    double S[15];         // upper triangle of the 5x5 membrane core, row-major (t <= u)
     double kbb00, kbb01, kbb11;
     {
 #pragma clang fp contract(fast)
@@ -275,6 +296,8 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         for (int i = 0; i < 4; i++) {
             dNx[i] = ia * dxi[i] + ib * deta[i];
             dNy[i] = ic * dxi[i] + id * deta[i];
+            lds[lds_slot(C_DN + 0, g, i, 0) + qoff] = dNx[i];
+            lds[lds_slot(C_DN + 1, g, i, 0) + qoff] = dNy[i];
         }
         // ---- MITC4+ membrane (MITC4.py:351-392): W = T_eps * blend (3x5) ----
         const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
@@ -307,30 +330,33 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         double W[3][5];
         for (int a = 0; a < 3; a++)
             for (int t = 0; t < 5; t++) W[a][t] = Te[a][0] * bl[0][t] + Te[a][1] * bl[1][t] + Te[a][2] * bl[2][t];
-        // tying shape-derivative constants: dN/dxi at A,B ; dN/deta at C,D ; both at E
-        const double dA[4] = {0.0, 0.0, 0.5, -0.5}, dB[4] = {-0.5, 0.5, 0.0, 0.0};
-        const double dC[4] = {0.0, -0.5, 0.5, 0.0}, dD[4] = {-0.5, 0.0, 0.0, 0.5};
-        const double dEx[4] = {-0.25, 0.25, 0.25, -0.25}, dEe[4] = {-0.25, -0.25, 0.25, 0.25};
-        for (int i = 0; i < 4; i++) {
-            double Y[5][3];
-            for (int k = 0; k < 3; k++) {
-                Y[0][k] = grA[k] * dA[i];
-                Y[1][k] = grB[k] * dB[i];
-                Y[2][k] = gsC[k] * dC[i];
-                Y[3][k] = gsD[k] * dD[i];
-                Y[4][k] = 0.5 * (grE[k] * dEe[i] + gsE[k] * dEx[i]);
-            }
+        // S partial = detJ W^T Cm W
+        {
+            double CW[3][5];
             for (int a = 0; a < 3; a++)
-                for (int k = 0; k < 3; k++) {
-                    double v = W[a][0] * Y[0][k];
-                    v += W[a][1] * Y[1][k];
-                    v += W[a][2] * Y[2][k];
-                    v += W[a][3] * Y[3][k];
-                    v += W[a][4] * Y[4][k];
-                    lds[lds_slot(C_BM + a * 3 + k, g, i, 0) + qoff] = v;
+                for (int t = 0; t < 5; t++)
+                    CW[a][t] = detJ * (pr->A[a * 3 + 0] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
+            int n = 0;
+            for (int t = 0; t < 5; t++)
+                for (int u = t; u < 5; u++) S[n++] = W[0][t] * CW[0][u] + W[1][t] * CW[1][u] + W[2][t] * CW[2][u];
+        }
+        // coupling cores U_j = detJ W^T (Bl Bk_j)  (MITC4_composite.py:210-248, nodal-only form)
+        if (any_coupled) {
+            double Bl[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? detJ * pr->B[a * 3 + b] : 0.0;
+            for (int j = 0; j < 4; j++) {
+                double LK[3][2];
+                for (int a = 0; a < 3; a++) {
+                    LK[a][0] = -(Bl[a][1] * dNy[j] + Bl[a][2] * dNx[j]);
+                    LK[a][1] = Bl[a][0] * dNx[j] + Bl[a][2] * dNy[j];
                 }
-            lds[lds_slot(C_DN + 0, g, i, 0) + qoff] = dNx[i];
-            lds[lds_slot(C_DN + 1, g, i, 0) + qoff] = dNy[i];
+                for (int t = 0; t < 5; t++)
+                    for (int c = 0; c < 2; c++) {
+                        const double u = quad_sum(W[0][t] * LK[0][c] + W[1][t] * LK[1][c] + W[2][t] * LK[2][c]);
+                        if (j == g) lds[LDS_U + ((2 * t + c) << 6) + (j << 3) + qoff] = u;
+                    }
+            }
         }
         // ---- MITC4 edge-tied shear (MITC4.py:792-878) ----
         const auto &xl = geo.xl;
@@ -367,20 +393,6 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         const double w0[4] = {me, me, pe, pe}, w1[4] = {mx, px, px, mx};
         const double h0[4] = {-0.5, 0.5, 0.5, -0.5};  // G row of eta-edges: w coefficient
         const double h1[4] = {-0.5, -0.5, 0.5, 0.5};  // G row of xi-edges: w coefficient
-        double Bs[4][2][3];
-        for (int i = 0; i < 4; i++) {
-            const double a0 = w0[i] * f1, a1 = w1[i] * f2;
-            const double v0[3] = {a0 * h0[i], a0 * (-ey[e0[i]] * 0.25), a0 * (ex[e0[i]] * 0.25)};
-            const double v1[3] = {a1 * h1[i], a1 * (-ey[e1[i]] * 0.25), a1 * (ex[e1[i]] * 0.25)};
-            for (int k = 0; k < 3; k++) {
-                Bs[i][0][k] = sb * v0[k] - sa * v1[k];
-                Bs[i][1][k] = -cb * v0[k] + ca * v1[k];
-                lds[lds_slot(C_BS + k, g, i, 0) + qoff] = Bs[i][0][k];
-                lds[lds_slot(C_BS + 3 + k, g, i, 0) + qoff] = Bs[i][1][k];
-            }
-        }
-        lds[LDS_DET + g * 16 + Q] = detJ;
-
         // ---- bubble enrichment (MITC4.py:214-222, 880-907): partial Knb, Kbb of this GP ----
         const double Cb00 = pr->D[0], Cb01 = pr->D[1], Cb02 = pr->D[2];
         const double Cb10 = pr->D[3], Cb11 = pr->D[4], Cb12 = pr->D[5];
@@ -396,39 +408,40 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         // Bsb = [[0,Nb],[-Nb,0]] ; Cs*Bsb (2x2)
         const double s00 = -Cs01 * Nb, s01 = Cs00 * Nb, s10 = -Cs11 * Nb, s11 = Cs10 * Nb;
         for (int i = 0; i < 4; i++) {
+            const double a0 = w0[i] * f1, a1 = w1[i] * f2;
+            const double v0[3] = {a0 * h0[i], a0 * (-ey[e0[i]] * 0.25), a0 * (ex[e0[i]] * 0.25)};
+            const double v1[3] = {a1 * h1[i], a1 * (-ey[e1[i]] * 0.25), a1 * (ex[e1[i]] * 0.25)};
             // Bk_i columns: thx = (0,-dNy,-dNx) ; thy = (dNx,0,dNy) ; w = 0
             const double kx0 = -dNy[i] * q10 - dNx[i] * q20, kx1 = -dNy[i] * q11 - dNx[i] * q21;
             const double ky0 = dNx[i] * q00 + dNy[i] * q20, ky1 = dNx[i] * q01 + dNy[i] * q21;
             for (int k = 0; k < 3; k++) {
-                double v0 = Bs[i][0][k] * s00 + Bs[i][1][k] * s10;
-                double v1 = Bs[i][0][k] * s01 + Bs[i][1][k] * s11;
-                if (k == 1) { v0 += kx0; v1 += kx1; }
-                if (k == 2) { v0 += ky0; v1 += ky1; }
-                knb[i][k][0] = detJ * v0;
-                knb[i][k][1] = detJ * v1;
+                const double b0 = sb * v0[k] - sa * v1[k];
+                const double b1 = -cb * v0[k] + ca * v1[k];
+                lds[lds_slot(C_BS + k, g, i, 0) + qoff] = b0;
+                lds[lds_slot(C_BS + 3 + k, g, i, 0) + qoff] = b1;
+                double n0 = b0 * s00 + b1 * s10;
+                double n1 = b0 * s01 + b1 * s11;
+                if (k == 1) { n0 += kx0; n1 += kx1; }
+                if (k == 2) { n0 += ky0; n1 += ky1; }
+                // reduce over the 4 Gauss points of the quad; lane g publishes the rows of node g
+                n0 = quad_sum(detJ * n0);
+                n1 = quad_sum(detJ * n1);
+                if (i == g) {
+                    lds[LDS_KNB + ((2 * k) << 6) + (i << 3) + qoff] = n0;
+                    lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 3) + qoff] = n1;
+                }
             }
         }
+        lds[LDS_DET + g * 16 + Q] = detJ;
         // Kbb = Bkb^T Cb Bkb + Bsb^T Cs Bsb
         kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
         kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
         kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
     }
-    // reduce the bubble blocks over the 4 Gauss points of the quad (every lane gets the sums)
-    for (int i = 0; i < 4; i++)
-        for (int k = 0; k < 3; k++) {
-            knb[i][k][0] = quad_sum(knb[i][k][0]);
-            knb[i][k][1] = quad_sum(knb[i][k][1]);
-        }
+    for (int n = 0; n < 15; n++) S[n] = quad_sum(S[n]);
     kbb00 = quad_sum(kbb00); kbb01 = quad_sum(kbb01); kbb11 = quad_sum(kbb11);
     st |= __shfl_xor(st, 1);
     st |= __shfl_xor(st, 2);
-    // lane g publishes Knb rows of node g
-    for (int i = 0; i < 4; i++)
-        if (i == g)
-            for (int k = 0; k < 3; k++) {
-                lds[LDS_KNB + ((2 * k) << 6) + (i << 3) + qoff] = knb[i][k][0];
-                lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 3) + qoff] = knb[i][k][1];
-            }
     // Kbb^-1 (MITC4.py:994-998; singular -> no condensation)
     const double kdet = kbb00 * kbb11 - kbb01 * kbb01;
     const bool cond_ok = (kdet != 0.0) && (kdet == kdet);
@@ -439,16 +452,17 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     __syncthreads();
 
     // ---------------- stage 2: node-pair tasks ----------------
-    const double Cm[3][3] = {{pr->A[0], pr->A[1], pr->A[2]}, {pr->A[3], pr->A[4], pr->A[5]}, {pr->A[6], pr->A[7], pr->A[8]}};
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
-    const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
-    double Bl[3][3];
-    for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? pr->B[a * 3 + b] : 0.0;
-    const bool any_coupled = __any(coupled);
     const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    // full symmetric 5x5 view of S
+    double Sf[5][5];
+    {
+        int n = 0;
+        for (int t = 0; t < 5; t++)
+            for (int u = t; u < 5; u++) { Sf[t][u] = S[n]; Sf[u][t] = S[n]; n++; }
+    }
 
     for (int round = 0; round < 3; round++) {
 #pragma clang fp contract(fast)
@@ -466,13 +480,50 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         for (int a = 0; a < 6; a++)
             for (int b = 0; b < 6; b++) L[a][b] = 0.0;
 
+        // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j   (MITC4.py:934-944 pre-contracted)
+        double Yi[5][3], Yj[5][3];
+        {
+            double wi[6], wj[6];
+            tying_weights(ti, wi);
+            tying_weights(tj, wj);
+            for (int k = 0; k < 3; k++) {
+                for (int t = 0; t < 4; t++) { Yi[t][k] = wi[t] * gt[t][k]; Yj[t][k] = wj[t] * gt[t][k]; }
+                Yi[4][k] = wi[4] * gt[4][k] + wi[5] * gt[5][k];
+                Yj[4][k] = wj[4] * gt[4][k] + wj[5] * gt[5][k];
+            }
+            for (int b = 0; b < 3; b++) {
+                double SY[5];
+                for (int t = 0; t < 5; t++) {
+                    double v = Sf[t][0] * Yj[0][b];
+                    for (int u = 1; u < 5; u++) v = FMA(Sf[t][u], Yj[u][b], v);
+                    SY[t] = v;
+                }
+                for (int a = 0; a < 3; a++) {
+                    double v = Yi[0][a] * SY[0];
+                    for (int t = 1; t < 5; t++) v = FMA(Yi[t][a], SY[t], v);
+                    L[a][b] = v;
+                }
+            }
+        }
+        // membrane-bending coupling: L[uvw_i][th_j] += Y_i^T U_j ; L[th_i][uvw_j] += U_i^T Y_j
+        if (any_coupled) {
+            for (int c = 0; c < 2; c++) {
+                double Ui[5], Uj[5];
+                for (int t = 0; t < 5; t++) {
+                    Ui[t] = lds[LDS_U + ((2 * t + c) << 6) + oi];
+                    Uj[t] = lds[LDS_U + ((2 * t + c) << 6) + oj];
+                }
+                for (int a = 0; a < 3; a++) {
+                    double v = L[a][3 + c], w2 = L[3 + c][a];
+                    for (int t = 0; t < 5; t++) { v = FMA(Yi[t][a], Uj[t], v); w2 = FMA(Ui[t], Yj[t][a], w2); }
+                    L[a][3 + c] = v; L[3 + c][a] = w2;
+                }
+            }
+        }
+
         for (int gg = 0; gg < 4; gg++) {
             const double w = lds[LDS_DET + gg * 16 + Q];
-            double bmi[3][3], bmj[3][3], bsi[2][3], bsj[2][3];
-            for (int c = 0; c < 9; c++) {
-                (&bmi[0][0])[c] = w * lds[((c * 4 + gg) << 6) + oi];
-                (&bmj[0][0])[c] = lds[((c * 4 + gg) << 6) + oj];
-            }
+            double bsi[2][3], bsj[2][3];
             const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + oi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + oi];
             const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + oj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + oj];
             for (int c = 0; c < 6; c++) {
@@ -480,30 +531,22 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
                 (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + oj];
             }
             const double wdxi = w * dxi_, wdyi = w * dyi_;
-            // membrane: L[u,v,w][u,v,w] += w Bm_i^T Cm Bm_j            (MITC4.py:934-944)
-            double CB[3][3];
-            for (int rr = 0; rr < 3; rr++)
-                for (int b = 0; b < 3; b++)
-                    CB[rr][b] = Cm[rr][0] * bmj[0][b] + Cm[rr][1] * bmj[1][b] + Cm[rr][2] * bmj[2][b];
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++)
-                    L[a][b] += bmi[0][a] * CB[0][b] + bmi[1][a] * CB[1][b] + bmi[2][a] * CB[2][b];
             // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
             double CK[3][2];
             for (int rr = 0; rr < 3; rr++) {
-                CK[rr][0] = -(Cb[rr][1] * dyj + Cb[rr][2] * dxj);
-                CK[rr][1] = Cb[rr][0] * dxj + Cb[rr][2] * dyj;
+                CK[rr][0] = -FMA(Cb[rr][1], dyj, Cb[rr][2] * dxj);
+                CK[rr][1] = FMA(Cb[rr][0], dxj, Cb[rr][2] * dyj);
             }
             for (int c = 0; c < 2; c++) {
-                L[3][3 + c] += -(wdyi * CK[1][c] + wdxi * CK[2][c]);
-                L[4][3 + c] += wdxi * CK[0][c] + wdyi * CK[2][c];
+                L[3][3 + c] = FMA(-wdyi, CK[1][c], FMA(-wdxi, CK[2][c], L[3][3 + c]));
+                L[4][3 + c] = FMA(wdxi, CK[0][c], FMA(wdyi, CK[2][c], L[4][3 + c]));
             }
             // shear: L[w,thx,thy][w,thx,thy] += w Bs_i^T Cs Bs_j        (MITC4.py:986)
             double CS[2][3];
             for (int rr = 0; rr < 2; rr++)
-                for (int b = 0; b < 3; b++) CS[rr][b] = Cs[rr][0] * bsj[0][b] + Cs[rr][1] * bsj[1][b];
+                for (int b = 0; b < 3; b++) CS[rr][b] = FMA(Cs[rr][0], bsj[0][b], Cs[rr][1] * bsj[1][b]);
             for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) L[2 + a][2 + b] += bsi[0][a] * CS[0][b] + bsi[1][a] * CS[1][b];
+                for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(bsi[0][a], CS[0][b], FMA(bsi[1][a], CS[1][b], L[2 + a][2 + b]));
             // drilling: k w outer(Bd_i, Bd_j) on (u,v,thz)                (MITC4.py:909-928,1014)
             const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
             const double Ni = 0.25 * (1.0 + sxi * xg) * (1.0 + syi * yg);
@@ -512,22 +555,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
             const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
             const int dm[3] = {0, 1, 5};
             for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) L[dm[a]][dm[b]] += bdi[a] * bdj[b];
-            // membrane-bending coupling (MITC4_composite.py:210-248, nodal-only form)
-            if (any_coupled) {
-                double LKj[3][2], LKi[3][2];
-                for (int rr = 0; rr < 3; rr++) {
-                    LKj[rr][0] = -(Bl[rr][1] * dyj + Bl[rr][2] * dxj);
-                    LKj[rr][1] = Bl[rr][0] * dxj + Bl[rr][2] * dyj;
-                    LKi[rr][0] = -(Bl[rr][1] * wdyi + Bl[rr][2] * wdxi);
-                    LKi[rr][1] = Bl[rr][0] * wdxi + Bl[rr][2] * wdyi;
-                }
-                for (int a = 0; a < 3; a++)
-                    for (int c = 0; c < 2; c++) {
-                        L[a][3 + c] += bmi[0][a] * LKj[0][c] + bmi[1][a] * LKj[1][c] + bmi[2][a] * LKj[2][c];
-                        L[3 + c][a] += LKi[0][c] * bmj[0][a] + LKi[1][c] * bmj[1][a] + LKi[2][c] * bmj[2][a];
-                    }
-            }
+                for (int b = 0; b < 3; b++) L[dm[a]][dm[b]] = FMA(bdi[a], bdj[b], L[dm[a]][dm[b]]);
         }
         // bubble condensation: L[w,thx,thy][w,thx,thy] -= (Knb_i Kbb^-1) Knb_j^T (MITC4.py:996)
         {
@@ -538,7 +566,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
             }
             for (int a = 0; a < 3; a++) {
                 const double h0 = ki[a][0] * i00 + ki[a][1] * i01, h1 = ki[a][0] * i01 + ki[a][1] * i11;
-                for (int b = 0; b < 3; b++) L[2 + a][2 + b] -= h0 * kj[b][0] + h1 * kj[b][1];
+                for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(-h0, kj[b][0], FMA(-h1, kj[b][1], L[2 + a][2 + b]));
             }
         }
         // rotation to global axes, 3x3 block-wise: G = R^T X R  (MITC4.py:634-640,1032-1033)
@@ -548,10 +576,10 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
                 double Y[3][3];
                 for (int p = 0; p < 3; p++)
                     for (int q = 0; q < 3; q++)
-                        Y[p][q] = R[0][p] * L[3 * ba][3 * bb + q] + R[1][p] * L[3 * ba + 1][3 * bb + q] + R[2][p] * L[3 * ba + 2][3 * bb + q];
+                        Y[p][q] = FMA(R[2][p], L[3 * ba + 2][3 * bb + q], FMA(R[1][p], L[3 * ba + 1][3 * bb + q], R[0][p] * L[3 * ba][3 * bb + q]));
                 for (int p = 0; p < 3; p++)
                     for (int q = 0; q < 3; q++)
-                        G[3 * ba + p][3 * bb + q] = Y[p][0] * R[0][q] + Y[p][1] * R[1][q] + Y[p][2] * R[2][q];
+                        G[3 * ba + p][3 * bb + q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], Y[p][0] * R[0][q]));
             }
         if (round == 0) {  // diagonal block: K = 0.5 (K + K^T)  (MITC4.py:1034)
             for (int a = 0; a < 6; a++)

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc/*/ counter_collection.csv -> per-kernel averages per launch; writes
+profiles/pmc_summary.json (hbm bytes per launch with the gfx950 FETCH_SIZE x2 correction of
+MI355X_MICROARCH.md 'HBM')."""
+import csv, glob, json, collections, sys, os
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        short = "mitc4_k_kernel" if "mitc4_k_kernel" in k else "csr_numeric_desc2_kernel" if "csr_numeric_desc2" in k else \
+                "mitc4_m_kernel" if "mitc4_m_kernel" in k else None
+        if short:
+            acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, cs in acc.items():
+    d = {c: sum(v) / len(v) for c, v in cs.items()}
+    # FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B? rocprofv3 reports KB; guide: bytes = value*1024, FETCH x2 on gfx950
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_read_bytes_per_launch"] = d["FETCH_SIZE"] * 1024 * 2
+        d["hbm_write_bytes_per_launch"] = d["WRITE_SIZE"] * 1024
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    out[k] = d
+print(json.dumps(out, indent=1))
+if "--write" in sys.argv:
+    json.dump(out, open("profiles/pmc_summary.json", "w"), indent=1)
