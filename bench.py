@@ -173,7 +173,7 @@ def main():
         # writes the 10 symmetric 6x6 blocks; the assembly kernel reads those blocks once and writes
         # the amortised 324 CSR values (block descriptors are overhead, not counted).
         k_bytes = 96 + 4 + 2880
-        a_bytes = 2880 + 2592
+        a_bytes = 4608 + 2592   # off-diagonal blocks are read twice (as (I,J) and transposed as (J,I))
         k_gbs = E * k_bytes / (k_ms * 1e-3) / 1e9
         a_gbs = E * a_bytes / (a_ms * 1e-3) / 1e9
         pmc = {}
