@@ -24,7 +24,7 @@ def to_device_props(props: np.ndarray) -> torch.Tensor:
 
 
 def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
-               status=True, validate=True):
+               status=True, validate=True, u_e=None, want_KT=False, want_F=False):
     """MITC4+ element matrices for E quads.
 
     xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
@@ -45,14 +45,26 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
     M = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev) if want_M else None
     st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
     want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
+    KT = F = None
+    if want_KT or want_F:
+        if u_e is None:
+            raise ValueError("KT / f_int need the element displacement vectors u_e [E,24]")
+        u_e = u_e.contiguous()
+        assert u_e.dtype == torch.float64 and u_e.shape == (E, 24) and u_e.is_cuda
+        KT = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev)   # also the FINT workspace
+        F = torch.empty((E, 24), dtype=torch.float64, device=dev) if want_F else None
+        want |= (_lib.FS_WANT_KT if want_KT else 0) | (_lib.FS_WANT_FINT if want_F else 0)
     _lib.check(lib.fs_shell_quad_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
-                                       n_props, None, E, want, _lib.FS_LAYOUT_SYMBLK,
-                                       _lib.ptr(K), _lib.ptr(M), None, None, _lib.ptr(st),
+                                       n_props, _lib.ptr(u_e), E, want, _lib.FS_LAYOUT_SYMBLK,
+                                       _lib.ptr(K), _lib.ptr(M), _lib.ptr(KT), _lib.ptr(F), _lib.ptr(st),
                                        _lib.stream_ptr()), "fs_shell_quad_batch")
+    if not want_KT:
+        KT = None
     if dense:
         K = expand_blocks(K, 4, 6) if K is not None else None
         M = expand_blocks(M, 4, 6) if M is not None else None
-    out["K"], out["M"], out["status"] = K, M, st
+        KT = expand_blocks(KT, 4, 6) if KT is not None else None
+    out["K"], out["M"], out["KT"], out["f_int"], out["status"] = K, M, KT, F, st
     return out
 
 

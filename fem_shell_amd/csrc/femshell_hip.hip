@@ -597,6 +597,263 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// MITC4 total-Lagrangian tangent and internal force (MITC4.py:1067-1341, composite overrides
+// MITC4_composite.py:499-621).  One lane per element; runs AFTER mitc4_k_kernel has written the
+// linear blocks K into `kt` (FS_LAYOUT_SYMBLK):
+//   f_int = K u + T^T( sum_g detJ h (B_L+B_NL)^T C_raw e_GL  -  K_m u_loc )     [nonlinear rows]
+//         = K u                                                                 [linear rows]
+//   K_T   = K + T^T sym( K_L + K_sigma ) T   -- only the translational 3x3 sub-blocks change.
+// (K_bs + K_drill + K_c) u_loc of the reference is evaluated as K0 u_loc - K_m u_loc, with
+// K_m = Y^T S Y from the same pre-contracted core as the stiffness kernel.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void membrane_W(const QuadGeom &geo, double xi, double eta, double detJ, double ia,
+                                           double ib, double ic, double id, double (&W)[3][5]) {
+#pragma clang fp contract(fast)
+    const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
+    const double r = xi, s = eta;
+    double bl[3][5];
+    bl[0][0] = 0.5 * (1.0 - 2.0 * aA + s + 2.0 * aA * s * s);
+    bl[0][1] = 0.5 * (1.0 - 2.0 * aB - s + 2.0 * aB * s * s);
+    bl[0][2] = aC * (-1.0 + s * s);
+    bl[0][3] = aD * (-1.0 + s * s);
+    bl[0][4] = aE * (-1.0 + s * s);
+    bl[1][0] = aA * (-1.0 + r * r);
+    bl[1][1] = aB * (-1.0 + r * r);
+    bl[1][2] = 0.5 * (1.0 - 2.0 * aC + r + 2.0 * aC * r * r);
+    bl[1][3] = 0.5 * (1.0 - 2.0 * aD - r + 2.0 * aD * r * r);
+    bl[1][4] = aE * (-1.0 + r * r);
+    bl[2][0] = 2.0 * (0.25 * (r + 4.0 * aA * r * s));
+    bl[2][1] = 2.0 * (0.25 * (-r + 4.0 * aB * r * s));
+    bl[2][2] = 2.0 * (0.25 * (s + 4.0 * aC * r * s));
+    bl[2][3] = 2.0 * (0.25 * (-s + 4.0 * aD * r * s));
+    bl[2][4] = 2.0 * (1.0 + aE * r * s);
+    double Te[3][3];
+    if (__builtin_fabs(detJ) < 1e-12) {
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) Te[a][b] = (a == b) ? 1.0 : 0.0;
+    } else {
+        Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
+        Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
+        Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
+    }
+    for (int a = 0; a < 3; a++)
+        for (int t = 0; t < 5; t++) W[a][t] = Te[a][0] * bl[0][t] + Te[a][1] * bl[1][t] + Te[a][2] * bl[2][t];
+}
+
+__global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__ xyz,
+                                                      const int32_t *__restrict__ prop_id,
+                                                      const fs_shell_prop *__restrict__ props,
+                                                      const double *__restrict__ ue, int64_t E,
+                                                      double *__restrict__ kt, int want_kt,
+                                                      double *__restrict__ fe) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double x[4][3], u[4][6];
+    for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
+    for (int c = 0; c < 24; c++) (&u[0][0])[c] = ue[e * 24 + c];
+    const fs_shell_prop *pr = props + prop_id[e];
+    QuadGeom geo;
+    quad_geometry(x, geo);
+    const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    double *blk = kt + e * 360;
+    const int pidx[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+
+    {
+#pragma clang fp contract(fast)
+    // ---- f = K u with the linear blocks (global axes) ----
+    double f[4][6];
+    for (int c = 0; c < 24; c++) (&f[0][0])[c] = 0.0;
+    if (fe) {
+        for (int i = 0; i < 4; i++)
+            for (int j = i; j < 4; j++) {
+                const double *B = blk + pidx[i][j] * 36;
+                for (int a = 0; a < 6; a++)
+                    for (int b = 0; b < 6; b++) {
+                        const double v = B[a * 6 + b];
+                        f[i][a] += v * u[j][b];
+                        if (i != j) f[j][b] += v * u[i][a];
+                    }
+            }
+    }
+    if (pr->nonlinear) {
+        const double h = pr->h;
+        double C[3][3];
+        for (int a = 0; a < 9; a++) (&C[0][0])[a] = pr->C_raw[a];
+        // local displacements
+        double ul[4][3], rl[4][3];
+        for (int i = 0; i < 4; i++)
+            for (int a = 0; a < 3; a++) {
+                ul[i][a] = R[a][0] * u[i][0] + R[a][1] * u[i][1] + R[a][2] * u[i][2];
+                rl[i][a] = R[a][0] * u[i][3] + R[a][1] * u[i][4] + R[a][2] * u[i][5];
+            }
+        // membrane stress at the centre (MITC4.py:1227-1240; laminate MITC4_composite.py:499-508)
+        double Sm00, Sm01, Sm11;
+        {
+            double dxi[4], deta[4], ia, ib, ic, id;
+            dshape(0.0, 0.0, dxi, deta);
+            jacobian(geo, dxi, deta, ia, ib, ic, id);
+            double eps[3] = {0, 0, 0}, kap[3] = {0, 0, 0};
+            for (int i = 0; i < 4; i++) {
+                const double nx = ia * dxi[i] + ib * deta[i], ny = ic * dxi[i] + id * deta[i];
+                eps[0] += nx * ul[i][0]; eps[1] += ny * ul[i][1]; eps[2] += ny * ul[i][0] + nx * ul[i][1];
+                kap[0] += nx * rl[i][1]; kap[1] += -ny * rl[i][0]; kap[2] += ny * rl[i][1] - nx * rl[i][0];
+            }
+            double sig[3];
+            if (pr->flags & FS_PROP_LAMINATE) {
+                for (int a = 0; a < 3; a++)
+                    sig[a] = ((pr->A[a * 3] * eps[0] + pr->A[a * 3 + 1] * eps[1] + pr->A[a * 3 + 2] * eps[2]) +
+                              (pr->B[a * 3] * kap[0] + pr->B[a * 3 + 1] * kap[1] + pr->B[a * 3 + 2] * kap[2])) / h;
+            } else {
+                for (int a = 0; a < 3; a++) sig[a] = C[a][0] * eps[0] + C[a][1] * eps[1] + C[a][2] * eps[2];
+            }
+            Sm00 = sig[0] * h; Sm11 = sig[1] * h; Sm01 = sig[2] * h;
+        }
+        // tying vectors (as in mitc4_k_kernel) for K_m u_loc
+        double gt[6][3];
+        {
+#pragma clang fp contract(off)
+            double t3[3];
+            for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
+            gt[0][0] = dot3(t3, geo.e1); gt[0][1] = dot3(t3, geo.e2); gt[0][2] = dot3(t3, geo.e3);
+            for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
+            gt[1][0] = dot3(t3, geo.e1); gt[1][1] = dot3(t3, geo.e2); gt[1][2] = dot3(t3, geo.e3);
+            for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
+            gt[2][0] = dot3(t3, geo.e1); gt[2][1] = dot3(t3, geo.e2); gt[2][2] = dot3(t3, geo.e3);
+            for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
+            gt[3][0] = dot3(t3, geo.e1); gt[3][1] = dot3(t3, geo.e2); gt[3][2] = dot3(t3, geo.e3);
+            for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
+            gt[4][0] = dot3(t3, geo.e1); gt[4][1] = dot3(t3, geo.e2); gt[4][2] = dot3(t3, geo.e3);
+            for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
+            gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
+        }
+        double Sf[5][5];
+        for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = 0.0;
+        double dL[10][3][3];   // K_L + K_sigma, translational sub-blocks of pairs i<=j (local axes)
+        for (int t = 0; t < 90; t++) (&dL[0][0][0])[t] = 0.0;
+        double fm[4][3];       // membrane internal force (local axes)
+        for (int t = 0; t < 12; t++) (&fm[0][0])[t] = 0.0;
+        for (int g = 0; g < 4; g++) {
+            const double xi = (g == 1 || g == 2) ? kGP : -kGP, eta = (g >= 2) ? kGP : -kGP;
+            double dxi[4], deta[4], ia, ib, ic, id;
+            dshape(xi, eta, dxi, deta);
+            const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
+            double nx[4], ny[4];
+            for (int i = 0; i < 4; i++) { nx[i] = ia * dxi[i] + ib * deta[i]; ny[i] = ic * dxi[i] + id * deta[i]; }
+            double W[3][5];
+            membrane_W(geo, xi, eta, detJ, ia, ib, ic, id, W);
+            for (int t = 0; t < 5; t++)
+                for (int a = 0; a < 3; a++) {
+                    const double cw = detJ * (pr->A[a * 3] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
+                    for (int v = 0; v < 5; v++) Sf[v][t] += W[a][v] * cw;
+                }
+            // displacement gradient: GLOBAL components, local derivatives (MITC4.py:1092-1107)
+            double H[3][2];
+            for (int c = 0; c < 3; c++) {
+                H[c][0] = dots4(u[0][c], u[1][c], u[2][c], u[3][c], nx[0], nx[1], nx[2], nx[3]);
+                H[c][1] = dots4(u[0][c], u[1][c], u[2][c], u[3][c], ny[0], ny[1], ny[2], ny[3]);
+            }
+            // Green-Lagrange membrane strain (third column of H is zero)
+            const double E00 = 0.5 * (2.0 * H[0][0] + (H[0][0] * H[0][0] + H[1][0] * H[1][0] + H[2][0] * H[2][0]));
+            const double E11 = 0.5 * (2.0 * H[1][1] + (H[0][1] * H[0][1] + H[1][1] * H[1][1] + H[2][1] * H[2][1]));
+            const double E01 = 0.5 * ((H[0][1] + H[1][0]) + (H[0][0] * H[0][1] + H[1][0] * H[1][1] + H[2][0] * H[2][1]));
+            const double eg[3] = {E00, E11, 2.0 * E01};
+            double sg[3];
+            for (int a = 0; a < 3; a++) sg[a] = C[a][0] * eg[0] + C[a][1] * eg[1] + C[a][2] * eg[2];
+            const double wh = detJ * h;
+            double Bt[4][3][3], BL[4][3][3], CBt[4][3][3], CBL[4][3][3];
+            for (int i = 0; i < 4; i++) {
+                for (int k = 0; k < 3; k++) {
+                    BL[i][0][k] = (k == 0) ? nx[i] : 0.0;
+                    BL[i][1][k] = (k == 1) ? ny[i] : 0.0;
+                    BL[i][2][k] = (k == 0) ? ny[i] : ((k == 1) ? nx[i] : 0.0);
+                    Bt[i][0][k] = BL[i][0][k] + H[k][0] * nx[i];
+                    Bt[i][1][k] = BL[i][1][k] + H[k][1] * ny[i];
+                    Bt[i][2][k] = BL[i][2][k] + (H[k][0] * ny[i] + H[k][1] * nx[i]);
+                }
+                for (int a = 0; a < 3; a++)
+                    for (int k = 0; k < 3; k++) {
+                        CBt[i][a][k] = wh * (C[a][0] * Bt[i][0][k] + C[a][1] * Bt[i][1][k] + C[a][2] * Bt[i][2][k]);
+                        CBL[i][a][k] = wh * (C[a][0] * BL[i][0][k] + C[a][1] * BL[i][1][k] + C[a][2] * BL[i][2][k]);
+                    }
+                for (int k = 0; k < 3; k++)
+                    fm[i][k] += wh * (Bt[i][0][k] * sg[0] + Bt[i][1][k] * sg[1] + Bt[i][2][k] * sg[2]);
+            }
+            if (want_kt) {
+                for (int i = 0; i < 4; i++)
+                    for (int j = i; j < 4; j++) {
+                        const int p = pidx[i][j];
+                        const double ks = detJ * (nx[i] * (Sm00 * nx[j] + Sm01 * ny[j]) + ny[i] * (Sm01 * nx[j] + Sm11 * ny[j]));
+                        for (int k = 0; k < 3; k++)
+                            for (int l = 0; l < 3; l++) {
+                                double v = Bt[i][0][k] * CBt[j][0][l] + Bt[i][1][k] * CBt[j][1][l] + Bt[i][2][k] * CBt[j][2][l];
+                                v -= BL[i][0][k] * CBL[j][0][l] + BL[i][1][k] * CBL[j][1][l] + BL[i][2][k] * CBL[j][2][l];
+                                if (k == l) v += ks;
+                                dL[p][k][l] += v;
+                            }
+                    }
+            }
+        }
+        // f_loc = f_memb - K_m u_loc ;  K_m u_loc = Y^T S (Y u_loc)
+        if (fe) {
+            double Y[4][5][3];
+            for (int i = 0; i < 4; i++) {
+                double w[6];
+                tying_weights(i, w);
+                for (int k = 0; k < 3; k++) {
+                    for (int t = 0; t < 4; t++) Y[i][t][k] = w[t] * gt[t][k];
+                    Y[i][4][k] = w[4] * gt[4][k] + w[5] * gt[5][k];
+                }
+            }
+            double z[5], Sz[5];
+            for (int t = 0; t < 5; t++) {
+                double v = 0.0;
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 3; k++) v += Y[i][t][k] * ul[i][k];
+                z[t] = v;
+            }
+            for (int t = 0; t < 5; t++) Sz[t] = Sf[t][0] * z[0] + Sf[t][1] * z[1] + Sf[t][2] * z[2] + Sf[t][3] * z[3] + Sf[t][4] * z[4];
+            for (int i = 0; i < 4; i++) {
+                double fl[3];
+                for (int k = 0; k < 3; k++) {
+                    double v = fm[i][k];
+                    for (int t = 0; t < 5; t++) v -= Y[i][t][k] * Sz[t];
+                    fl[k] = v;
+                }
+                for (int a = 0; a < 3; a++) f[i][a] += R[0][a] * fl[0] + R[1][a] * fl[1] + R[2][a] * fl[2];
+            }
+        }
+        // K_T = K + R^T sym(dL) R on the translational sub-blocks
+        if (want_kt) {
+            for (int i = 0; i < 4; i++)
+                for (int j = i; j < 4; j++) {
+                    const int p = pidx[i][j];
+                    double Xs[3][3];
+                    for (int k = 0; k < 3; k++)
+                        for (int l = 0; l < 3; l++) Xs[k][l] = (i == j) ? 0.5 * (dL[p][k][l] + dL[p][l][k]) : dL[p][k][l];
+                    double Yt[3][3];
+                    for (int a = 0; a < 3; a++)
+                        for (int l = 0; l < 3; l++) Yt[a][l] = R[0][a] * Xs[0][l] + R[1][a] * Xs[1][l] + R[2][a] * Xs[2][l];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) {
+                            const double v = Yt[a][0] * R[0][b] + Yt[a][1] * R[1][b] + Yt[a][2] * R[2][b];
+                            blk[p * 36 + a * 6 + b] += v;
+                        }
+                    if (i == j) {  // keep the diagonal block exactly symmetric
+                        for (int a = 0; a < 3; a++)
+                            for (int b = a + 1; b < 3; b++) {
+                                const double m = 0.5 * (blk[p * 36 + a * 6 + b] + blk[p * 36 + b * 6 + a]);
+                                blk[p * 36 + a * 6 + b] = m; blk[p * 36 + b * 6 + a] = m;
+                            }
+                    }
+                }
+        }
+    }
+    if (fe)
+        for (int c = 0; c < 24; c++) fe[e * 24 + c] = (&f[0][0])[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // MITC4 consistent mass (MITC4.py:1038-1061), FS_LAYOUT_SYMBLK: one thread per (element, pair)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__ xyz,
@@ -878,11 +1135,17 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
     if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_shell_quad_batch: null input");
     if (layout != FS_LAYOUT_SYMBLK)
         return fail(FS_EINVAL, "fs_shell_quad_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
-    if (want & (FS_WANT_KT | FS_WANT_FINT)) {
-        (void)u_e; (void)KTe; (void)fe;
-        return fail(FS_ENOSYS, "fs_shell_quad_batch: KT/FINT not built yet");
-    }
     hipStream_t s = (hipStream_t)stream;
+    if (want & (FS_WANT_KT | FS_WANT_FINT)) {
+        if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_quad_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
+        if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_quad_batch: fe is null");
+        const unsigned grid = (unsigned)((E + 15) / 16);
+        hipLaunchKernelGGL(mitc4_k_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+        FS_LAUNCH_CHECK("mitc4_k_kernel");
+        hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
+                           E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+        FS_LAUNCH_CHECK("mitc4_nl_kernel");
+    }
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_quad_batch: Ke is null");
         const unsigned grid = (unsigned)((E + 15) / 16);

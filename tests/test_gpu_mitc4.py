@@ -92,3 +92,44 @@ def test_K_M_vs_reference_golden():
     assert eK < TOL and eM < TOL
     fr, xl, dj, ac = [t.cpu().numpy() for t in batch.quad_geom(torch.from_numpy(g["xyz"]).to(dev))]
     assert np.array_equal(fr, g["frame"]) and np.array_equal(xl, g["xl"]) and np.array_equal(dj, g["detJ"])
+
+
+def test_nonlinear_KT_fint_vs_reference_golden_and_oracle(oracle):
+    """update_configuration + compute_tangent_stiffness + compute_internal_forces
+    (MITC4.py:1067-1341, MITC4_composite.py:514-621) through fs_shell_quad_batch(KT|FINT)."""
+    import torch
+    from fem_shell_amd import batch
+    from tests.util_golden import golden, golden_props
+    g = golden("elem_nl")
+    props = golden_props(g)
+    n = g["xyz"].shape[0]
+    dev = torch.device("cuda:0")
+    out = batch.quad_batch(torch.from_numpy(g["xyz"]).to(dev), torch.arange(n, dtype=torch.int32, device=dev),
+                           batch.to_device_props(props), n, want_K=False, dense=True,
+                           u_e=torch.from_numpy(g["u"]).to(dev), want_KT=True, want_F=True)
+    KT, F = out["KT"].cpu().numpy(), out["f_int"].cpu().numpy()
+    eK = _rel(KT, g["KT"])
+    eF = (np.abs(F - g["f_int"]).max(axis=1) / np.abs(g["f_int"]).max(axis=1)).max()
+    print("HIP vs reference: KT", eK, "f_int", eF)
+    assert eK < 1e-12 and eF < 1e-11
+    # larger seeded batch vs the oracle (mixed linear / nonlinear rows, iso + laminates)
+    ptab = fsa.build_prop_table(util.standard_props(), nonlinear=True)
+    ptab2 = fsa.build_prop_table(util.standard_props(), nonlinear=False)
+    table = np.concatenate([ptab, ptab2])
+    xyz = util.random_quads(300, seed=7, far=False)
+    pid = (np.arange(300) % len(table)).astype(np.int32)
+    rng = np.random.default_rng(3)
+    size = np.linalg.norm(xyz[:, 1] - xyz[:, 0], axis=1)
+    u = rng.standard_normal((300, 24)) * 1e-3
+    u[:, 0::6] *= size[:, None]; u[:, 1::6] *= size[:, None]; u[:, 2::6] *= size[:, None]
+    out = batch.quad_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(pid).to(dev),
+                           batch.to_device_props(table), len(table), want_K=False, dense=True,
+                           u_e=torch.from_numpy(u).to(dev), want_KT=True, want_F=True)
+    KT, F = out["KT"].cpu().numpy(), out["f_int"].cpu().numpy()
+    worstK = worstF = 0.0
+    for e in range(300):
+        ko, fo, _ = oracle.mitc4_NL(xyz[e], table[pid[e]:pid[e] + 1], u[e])
+        worstK = max(worstK, np.abs(KT[e] - ko).max() / np.abs(ko).max())
+        worstF = max(worstF, np.abs(F[e] - fo).max() / np.abs(fo).max())
+    print("HIP vs oracle: KT", worstK, "f_int", worstF)
+    assert worstK < 1e-12 and worstF < 1e-11
