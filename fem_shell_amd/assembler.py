@@ -22,7 +22,7 @@ from . import _lib, batch
 from .elements import ElementFactory, ElementFamily
 from .properties import (CompositeShellProperty, ShellProperty, build_prop_table, iso_row,
                          laminate_row, PROP_DTYPE)
-from .symbolic import BlockPlan
+from .symbolic import BlockPlan, vector_plan
 
 
 class CsrMatrix:
@@ -310,6 +310,51 @@ class MeshAssembler:
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True)
         return self._assemble(self._M_blk)
+
+    # --- new (SURVEY.md 8a "New"): Newton re-assembly of K_T(u) and f_int(u) -----------------
+    def _element_displacements(self, u):
+        lib = _lib.load()
+        u = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
+        if u.numel() != self.dofs_count:
+            raise ValueError(f"Expected {self.dofs_count} DOFs, got {u.numel()}")
+        if not hasattr(self, "_dofs_d"):
+            self._dofs_d = torch.from_numpy(self._dofs_array).to(self.device)
+        E = self._conn.shape[0]
+        ue = torch.empty((E, 24), dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_gather_dofs(_lib.ptr(u), _lib.ptr(self._dofs_d), E * 24, _lib.ptr(ue),
+                                      _lib.stream_ptr()), "fs_gather_dofs")
+        return ue
+
+    def _nl_pass(self, u, want_KT, want_F):
+        ue = self._element_displacements(u)
+        return batch.quad_batch(self._xyz_d, self._pid_d, self._props_d, len(self._prop_table),
+                                want_K=False, status=False, validate=False, u_e=ue,
+                                want_KT=want_KT, want_F=want_F)
+
+    def _scatter_vector(self, fe):
+        lib = _lib.load()
+        if not hasattr(self, "_vplan_d"):
+            seg, src = vector_plan(self._conn, int(self.mesh.node_count), self.dofs_per_node)
+            self._vplan_d = (torch.from_numpy(seg).to(self.device), torch.from_numpy(src).to(self.device))
+        seg, src = self._vplan_d
+        f = torch.empty(self.dofs_count, dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_vec_gather_sum(_lib.ptr(fe), _lib.ptr(src), _lib.ptr(seg), self.dofs_count,
+                                         _lib.ptr(f), _lib.stream_ptr()), "fs_vec_gather_sum")
+        return f
+
+    def assemble_tangent_stiffness(self, u) -> CsrMatrix:
+        """K_T(u): per element update_configuration(u[dofs]); compute_tangent_stiffness()
+        (elements/MITC4.py:1067-1084,1246-1298), scatter-added like K."""
+        return self._assemble(self._nl_pass(u, True, False)["KT"])
+
+    def assemble_internal_forces(self, u):
+        """f_int(u): per element compute_internal_forces() (elements/MITC4.py:1300-1341),
+        scatter-added in element order. Returns a device vector [dofs_count]."""
+        return self._scatter_vector(self._nl_pass(u, False, True)["f_int"])
+
+    def assemble_tangent_and_forces(self, u):
+        out = self._nl_pass(u, True, True)
+        return self._assemble(out["KT"]), self._scatter_vector(out["f_int"])
 
     def assemble_load_vector(self, load_condition):
         """core/assembler.py:338-384: shells have no body_load in the reference (AttributeError)."""

@@ -102,12 +102,35 @@ class MITC4(ShellElement):
         return np.ascontiguousarray(self._run(want_K=False, want_M=True)["M"][0].cpu().numpy())
 
     def update_configuration(self, displacements):
+        """elements/MITC4.py:1067-1084 (the directors it also updates are unused by K_T / f_int)."""
         if len(displacements) != 24:
             raise ValueError(f"Expected 24 DOFs, got {len(displacements)}")
         self._current_displacements = np.array(displacements, dtype=float)
 
     def reset_configuration(self):
         self._current_displacements = np.zeros(24)
+
+    def _run_nl(self, want_KT, want_F):
+        import torch
+        from . import batch
+        dev = batch._dev()
+        u = torch.from_numpy(self._current_displacements[None].copy()).to(dev)
+        return self._run(want_K=False, u_e=u, want_KT=want_KT, want_F=want_F)
+
+    def compute_tangent_stiffness(self, sigma=None, transform_to_global=True):
+        """K_T = T^T sym(K0 + K_L + K_sigma) T (elements/MITC4.py:1246-1298); global axes only."""
+        if sigma is not None or not transform_to_global:
+            raise NotImplementedError("only sigma=None, transform_to_global=True are on the GPU path")
+        return np.ascontiguousarray(self._run_nl(True, False)["KT"][0].cpu().numpy())
+
+    def compute_internal_forces(self, transform_to_global=True):
+        """elements/MITC4.py:1300-1341; global axes only."""
+        if not transform_to_global:
+            raise NotImplementedError("only transform_to_global=True is on the GPU path")
+        return np.ascontiguousarray(self._run_nl(False, True)["f_int"][0].cpu().numpy())
+
+    def compute_residual(self, f_ext, transform_to_global=True):
+        return f_ext - self.compute_internal_forces(transform_to_global=transform_to_global)
 
 
 class MITC4Composite(MITC4):

@@ -141,3 +141,15 @@ def generic_plan(dofs_list, sizes, ndof):
 def dofs_list_iter(dofs_list, sizes):
     for (dofs, order), base in zip(dofs_list, sizes):
         yield np.ascontiguousarray(dofs, dtype=np.int64), int(base), np.asarray(order, dtype=np.int64)
+
+
+def vector_plan(conn, n_nodes, d):
+    """Segmented gather plan for vectors (f_int, load vectors): for DOF r the entries
+    src[seg_ptr[r]:seg_ptr[r+1]] index the flattened [E, nn*d] element vectors, element order
+    (== the reference's setValuesLocal insertion order, core/assembler.py:369-381)."""
+    conn = np.ascontiguousarray(conn, dtype=np.int64)
+    E, nn = conn.shape
+    dofs = (conn[:, :, None] * d + np.arange(d, dtype=np.int64)).reshape(-1)
+    order = np.argsort(dofs, kind="stable").astype(np.int64)
+    seg_ptr = np.searchsorted(dofs[order], np.arange(n_nodes * d + 1), side="left").astype(np.int64)
+    return seg_ptr, order

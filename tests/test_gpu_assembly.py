@@ -71,3 +71,50 @@ def test_element_classes_match_batch(oracle):
     bad = np.zeros((4, 3))
     with pytest.raises(ValueError):
         MITC4(bad, (0, 1, 2, 3), mat, 0.01).K
+
+
+def test_newton_reassembly_matches_oracle_loop(oracle):
+    """config 4: K_T(u) and f_int(u) re-assembled from u -- oracle = the Python loop 'for each
+    element: update_configuration(u[dofs]); compute_tangent_stiffness(); compute_internal_forces()'."""
+    from fem_shell_amd.assembler import MeshAssembler
+    mesh = meshes.flat_patch(0.0, 10.0, 0.0, 1.0, 40, 4)
+    mesh.coords[:, 2] = 0.02 * np.sin(mesh.coords[:, 0])          # slightly curved strip
+    mat = fsa.IsotropicMaterial("cant", 1.2e6, 0.0, 1.0)
+    model = {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.1,
+                          "nonlinear": True}}
+    asm = MeshAssembler(mesh, model)
+    assert asm._prop_table["nonlinear"][0] == 1
+    rng = np.random.default_rng(2)
+    xs = mesh.coords[:, 0]
+    u = np.zeros((mesh.node_count, 6))
+    u[:, 2] = 1e-2 * xs**2
+    u[:, 0] = -1e-3 * xs
+    u[:, 4] = -2e-2 * xs
+    u += 1e-5 * rng.standard_normal(u.shape)
+    u = u.reshape(-1)
+    KT, f = asm.assemble_tangent_and_forces(u)
+    dofs = asm._dofs_array
+    E = mesh.conn.shape[0]
+    kt_e = np.empty((E, 24, 24)); f_e = np.empty((E, 24))
+    for e in range(E):
+        kt_e[e], f_e[e], _ = oracle.mitc4_NL(mesh.coords[mesh.conn[e]], asm._prop_table[:1], u[dofs[e]])
+    ip, ix, data = oracle.csr_assemble(dofs, mesh.node_count * 6, kt_e)
+    assert np.array_equal(KT.indptr.cpu().numpy(), ip) and np.array_equal(KT.indices.cpu().numpy(), ix)
+    errK = np.abs(KT.data.cpu().numpy() - data).max() / np.abs(data).max()
+    fo = np.zeros(mesh.node_count * 6)
+    for e in range(E):
+        fo[dofs[e]] += f_e[e]
+    errF = np.abs(f.cpu().numpy() - fo).max() / np.abs(fo).max()
+    print("newton reassembly: KT", errK, "f_int", errF)
+    assert errK < 1e-12 and errF < 1e-12
+    assert np.abs(asm.assemble_internal_forces(np.zeros_like(u)).cpu().numpy()).max() == 0.0
+    with pytest.raises(ValueError):
+        asm.assemble_internal_forces(np.zeros(5))
+    # element-class route
+    from fem_shell_amd.elements import MITC4
+    el = MITC4(mesh.coords[mesh.conn[3]], tuple(mesh.conn[3]), mat, 0.1, nonlinear=True)
+    el.update_configuration(u[dofs[3]])
+    assert np.abs(el.compute_tangent_stiffness() - kt_e[3]).max() < 1e-12 * np.abs(kt_e[3]).max()
+    assert np.abs(el.compute_internal_forces() - f_e[3]).max() < 1e-12 * np.abs(f_e[3]).max()
+    with pytest.raises(ValueError):
+        el.update_configuration(np.zeros(3))
