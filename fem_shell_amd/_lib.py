@@ -17,6 +17,8 @@ SIGNATURES = {
                                       ctypes.POINTER(ctypes.c_int)]),
     "fs_shell_quad_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
                                            _vp, _vp, _vp, _vp]),
+    "fs_shell_tri_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
+                                          _vp, _vp, _vp, _vp]),
     "fs_shell_quad_geom": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_blk_expand": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "fs_csr_numeric": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

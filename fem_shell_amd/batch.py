@@ -68,6 +68,51 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
     return out
 
 
+NPAIR3 = 6
+
+
+def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
+              status=True, validate=True):
+    """MITC3+ element matrices for E triangles (fs_shell_tri_batch).
+
+    xyz [E,3,3] f64 device.  Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,6,36] or dense
+    [E,18,18]) and 'status'."""
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    assert xyz.dtype == torch.float64 and xyz.shape[1:] == (3, 3) and xyz.is_cuda
+    assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
+    if E and validate:
+        pmin, pmax = int(prop_id.min()), int(prop_id.max())
+        if pmin < 0 or pmax >= n_props:
+            raise ValueError("prop_id out of range of the property table")
+    K = torch.empty((E, NPAIR3, 36), dtype=torch.float64, device=dev) if want_K else None
+    M = torch.empty((E, NPAIR3, 36), dtype=torch.float64, device=dev) if want_M else None
+    st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
+    want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
+    _lib.check(lib.fs_shell_tri_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
+                                      n_props, None, E, want, _lib.FS_LAYOUT_SYMBLK,
+                                      _lib.ptr(K), _lib.ptr(M), None, None, _lib.ptr(st),
+                                      _lib.stream_ptr()), "fs_shell_tri_batch")
+    if dense:
+        K = expand_blocks(K, 3, 6) if K is not None else None
+        M = expand_blocks(M, 3, 6) if M is not None else None
+    return {"K": K, "M": M, "KT": None, "f_int": None, "status": st}
+
+
+def shell_batch(nn, *args, **kw):
+    """Dispatch on nodes per element (4 -> MITC4+, 3 -> MITC3+)."""
+    if nn == 4:
+        return quad_batch(*args, **kw)
+    if nn == 3:
+        kw.pop("u_e", None)
+        if kw.pop("want_KT", False) or kw.pop("want_F", False):
+            raise NotImplementedError("K_T / f_int are not available for MITC3 yet")
+        return tri_batch(*args, **kw)
+    raise ValueError(f"unsupported shell element with {nn} nodes")
+
+
 def expand_blocks(packed, nn, d):
     lib = _lib.load()
     E = packed.shape[0]

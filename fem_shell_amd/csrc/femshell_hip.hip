@@ -904,6 +904,318 @@ __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__
     for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
 }
 
+// ------------------------------------------------------------------------------------------
+// MITC3+ (elements/MITC3.py, MITC3_composite.py).  One thread per (element, node pair i<=j):
+// each thread rebuilds the (cheap) triangle geometry, evaluates the shape data of functions
+// i, j and the cubic bubble at the 3 Hammer points, forms its 6x6 block including the bubble
+// condensation term, rotates it and writes 288 contiguous bytes (FS_LAYOUT_SYMBLK, 6 pairs).
+// ------------------------------------------------------------------------------------------
+struct TriGeom {
+    double e1[3], e2[3], e3[3];
+    double x2, x3, y3, area, J00, J10, J11;
+    int status;
+};
+
+// MITC3.py:375-418 (_compute_local_coordinates), :427-469 (area, J), :527-558 (dH)
+__device__ __forceinline__ void tri_geometry(const double (&x)[3][3], TriGeom &t) {
+    double v12[3], v13[3], n[3];
+    for (int k = 0; k < 3; k++) { v12[k] = x[1][k] - x[0][k]; v13[k] = x[2][k] - x[0][k]; }
+    const double L12 = norm3(v12);
+    for (int k = 0; k < 3; k++) t.e1[k] = v12[k] / L12;
+    cross3(v12, v13, n);
+    const double nl = norm3(n);
+    t.status = (nl >= 1e-12) ? 0 : FS_ST_NAN_FRAME;  // ValueError("Degenerate triangle")
+    for (int k = 0; k < 3; k++) t.e3[k] = n[k] / nl;
+    cross3(t.e3, t.e1, t.e2);
+    t.x2 = L12; t.x3 = dot3(v13, t.e1); t.y3 = dot3(v13, t.e2);
+    const double det = t.x2 * t.y3;      // J = [[x2, 0], [x3, y3]]
+    t.area = 0.5 * __builtin_fabs(det);
+    t.J00 = t.y3 / det; t.J10 = -t.x3 / det; t.J11 = t.x2 / det;   // J^-1, J01^-1 == 0
+}
+
+constexpr double kTriR[3] = {1.0 / 6.0, 2.0 / 3.0, 1.0 / 6.0};
+constexpr double kTriS[3] = {1.0 / 6.0, 1.0 / 6.0, 2.0 / 3.0};
+constexpr double kTyD = 1.0e-4;
+// tying points A,B,C,D,E,F (MITC3.py:897-905)
+constexpr double kTyR[6] = {1.0 / 6.0, 2.0 / 3.0, 1.0 / 6.0, 1.0 / 3.0 + kTyD, 1.0 / 3.0 - 2.0 * kTyD, 1.0 / 3.0 + kTyD};
+constexpr double kTyS[6] = {2.0 / 3.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 3.0 - 2.0 * kTyD, 1.0 / 3.0 + kTyD, 1.0 / 3.0 + kTyD};
+
+struct TriFn {          // shape data of one function (node 0..2 or bubble 3) at the 3 Hammer points
+    double fx[3], fy[3];    // d f / dx, d f / dy (enriched)            MITC3.py:853-887
+    double gx[3][2];        // assumed shear column of theta_x          MITC3.py:796-933
+    double gy[3][2];        // assumed shear column of theta_y
+    double h[3];            // linear shape value (drilling row)
+    double dhx, dhy;        // linear derivatives (w column of the shear, membrane)
+};
+
+__device__ __forceinline__ double tri_f(int i, double r, double s) {
+    const double f4 = 27.0 * r * s * (1.0 - r - s);
+    const double h = (i == 0) ? (1.0 - r - s) : ((i == 1) ? r : s);
+    return (i == 3) ? f4 : h - f4 / 3.0;
+}
+
+__device__ __forceinline__ void tri_fn(const TriGeom &t, int i, TriFn &F) {
+#pragma clang fp contract(fast)
+    const double dr = (i == 0) ? -1.0 : ((i == 1) ? 1.0 : 0.0);
+    const double ds = (i == 0) ? -1.0 : ((i == 2) ? 1.0 : 0.0);
+    F.dhx = t.J00 * dr;
+    F.dhy = t.J10 * dr + t.J11 * ds;
+    double f[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) f[p] = tri_f(i, kTyR[p], kTyS[p]);
+    const double fA = f[0], fB = f[1], fC = f[2], fD = f[3], fE = f[4], fF = f[5];
+    // theta_y: covariant strains f(P)*(x2, x3); theta_x: f(P)*(0, -y3)   (g_r = (x2,0), g_s = (x3,y3))
+    const double yr = t.x2, ys = t.x3, xs = -t.y3;
+    const double ertc_y = (2.0 / 3.0) * (fB * yr - 0.5 * (fB * ys)) + (1.0 / 3.0) * (fC * yr + fC * ys);
+    const double estc_y = (2.0 / 3.0) * (fA * ys - 0.5 * (fA * yr)) + (1.0 / 3.0) * (fC * yr + fC * ys);
+    const double chat_y = (fF * yr - fD * yr) - (fF * ys - fE * ys);
+    const double ertc_x = (2.0 / 3.0) * (-0.5 * (fB * xs)) + (1.0 / 3.0) * (fC * xs);
+    const double estc_x = (2.0 / 3.0) * (fA * xs) + (1.0 / 3.0) * (fC * xs);
+    const double chat_x = -(fF * xs - fE * xs);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const double r = kTriR[g], s = kTriS[g];
+        const double df4r = 27.0 * s * (1.0 - 2.0 * r - s), df4s = 27.0 * r * (1.0 - r - 2.0 * s);
+        const double fr = (i == 3) ? df4r : dr - df4r / 3.0;
+        const double fs = (i == 3) ? df4s : ds - df4s / 3.0;
+        F.fx[g] = t.J00 * fr;
+        F.fy[g] = t.J10 * fr + t.J11 * fs;
+        const double ls = (1.0 / 3.0) * (3.0 * s - 1.0), lr = (1.0 / 3.0) * (1.0 - 3.0 * r);
+        const double ert_y = ertc_y + chat_y * ls, est_y = estc_y + chat_y * lr;
+        const double ert_x = ertc_x + chat_x * ls, est_x = estc_x + chat_x * lr;
+        F.gy[g][0] = t.J00 * ert_y; F.gy[g][1] = t.J10 * ert_y + t.J11 * est_y;
+        F.gx[g][0] = t.J00 * ert_x; F.gx[g][1] = t.J10 * ert_x + t.J11 * est_x;
+        F.h[g] = (i == 0) ? (1.0 - r - s) : ((i == 1) ? r : s);
+    }
+}
+
+// C5 * S for the three generalised-strain columns (w, theta_x, theta_y) of one function at one GP.
+// S = (kxx, kyy, kxy, gxz, gyz);  w: (0,0,0,dhx,dhy)  tx: (0,-fy,-fx,gx)  ty: (fx,0,fy,gy)
+struct TriCS { double w[2], x[5], y[5]; };
+__device__ __forceinline__ void tri_cs(const double *D, const double *Cs, const TriFn &F, int g, bool nodal, TriCS &c) {
+#pragma clang fp contract(fast)
+    const double fx = F.fx[g], fy = F.fy[g];
+    c.x[0] = -(D[1] * fy + D[2] * fx); c.x[1] = -(D[4] * fy + D[5] * fx); c.x[2] = -(D[7] * fy + D[8] * fx);
+    c.y[0] = D[0] * fx + D[2] * fy;    c.y[1] = D[3] * fx + D[5] * fy;    c.y[2] = D[6] * fx + D[8] * fy;
+    c.x[3] = Cs[0] * F.gx[g][0] + Cs[1] * F.gx[g][1]; c.x[4] = Cs[2] * F.gx[g][0] + Cs[3] * F.gx[g][1];
+    c.y[3] = Cs[0] * F.gy[g][0] + Cs[1] * F.gy[g][1]; c.y[4] = Cs[2] * F.gy[g][0] + Cs[3] * F.gy[g][1];
+    c.w[0] = nodal ? Cs[0] * F.dhx + Cs[1] * F.dhy : 0.0;
+    c.w[1] = nodal ? Cs[2] * F.dhx + Cs[3] * F.dhy : 0.0;
+}
+__device__ __forceinline__ double tri_dot_w(const TriFn &F, const double *c5) {
+#pragma clang fp contract(fast)
+    return F.dhx * c5[3] + F.dhy * c5[4];
+}
+__device__ __forceinline__ double tri_dot_x(const TriFn &F, int g, const double *c5) {
+#pragma clang fp contract(fast)
+    return -F.fy[g] * c5[1] - F.fx[g] * c5[2] + F.gx[g][0] * c5[3] + F.gx[g][1] * c5[4];
+}
+__device__ __forceinline__ double tri_dot_y(const TriFn &F, int g, const double *c5) {
+#pragma clang fp contract(fast)
+    return F.fx[g] * c5[0] + F.fy[g] * c5[2] + F.gy[g][0] * c5[3] + F.gy[g][1] * c5[4];
+}
+
+// G = blockwise R^T L R of a 6x6 node-pair block (T of MITC3.py:471-497 is block-diagonal in R)
+__device__ __forceinline__ void rotate_block6(const double (&L)[6][6], const double (&R)[3][3], double (&G)[6][6]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int bi = 0; bi < 2; bi++)
+#pragma unroll
+        for (int bj = 0; bj < 2; bj++) {
+            double Y[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) s += R[k][a] * L[3 * bi + k][3 * bj + b];
+                    Y[a][b] = s;
+                }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) s += Y[a][k] * R[k][b];
+                    G[3 * bi + a][3 * bj + b] = s;
+                }
+        }
+}
+
+__global__ __launch_bounds__(256) void mitc3_k_kernel(const double *__restrict__ xyz,
+                                                      const int32_t *__restrict__ prop_id,
+                                                      const fs_shell_prop *__restrict__ props,
+                                                      int64_t E, double *__restrict__ out,
+                                                      int32_t *__restrict__ status) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * 6) return;
+    const int64_t e = t / 6;
+    const int p = (int)(t - e * 6);
+    const int ti = (p < 3) ? 0 : ((p < 5) ? 1 : 2);
+    const int tj = (p < 3) ? p : ((p < 5) ? p - 2 : 2);
+    double x[3][3];
+    for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+    TriGeom geo;
+    tri_geometry(x, geo);
+    if (p == 0 && status) status[e] = geo.status;
+    const fs_shell_prop *pr = props + prop_id[e];
+    double L[6][6], G[6][6];
+    {
+#pragma clang fp contract(fast)
+        TriFn Fi, Fj, Fb;
+        tri_fn(geo, ti, Fi);
+        tri_fn(geo, tj, Fj);
+        tri_fn(geo, 3, Fb);
+        double D[9], A[9], Cs[4];
+        for (int c = 0; c < 9; c++) { D[c] = pr->D[c]; A[c] = pr->A[c]; }
+        for (int c = 0; c < 4; c++) Cs[c] = pr->Cs[c];
+        const double kd = pr->k_drill;
+        const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) L[a][b] = 0.0;
+        double Kij[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        double Ni[3][2] = {{0, 0}, {0, 0}, {0, 0}}, Nj[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        double Kbb[2][2] = {{0, 0}, {0, 0}};
+        double dr[2][2] = {{0, 0}, {0, 0}}, drz[2] = {0, 0}, dzr[2] = {0, 0}, dzz = 0.0;
+        double cpl_ij[2][2] = {{0, 0}, {0, 0}}, cpl_ji[2][2] = {{0, 0}, {0, 0}};
+        const double bdi[2] = {-0.5 * Fi.dhy, 0.5 * Fi.dhx}, bdj[2] = {-0.5 * Fj.dhy, 0.5 * Fj.dhx};
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const double wA = (1.0 / 3.0) * geo.area;
+            TriCS cj, cb;
+            tri_cs(D, Cs, Fj, g, true, cj);
+            tri_cs(D, Cs, Fb, g, false, cb);
+            const double cjw[5] = {0.0, 0.0, 0.0, cj.w[0], cj.w[1]};
+            // bending + shear, nodal block (rows of i, columns of j)
+            Kij[0][0] += wA * tri_dot_w(Fi, cjw);      Kij[0][1] += wA * tri_dot_w(Fi, cj.x);      Kij[0][2] += wA * tri_dot_w(Fi, cj.y);
+            Kij[1][0] += wA * (Fi.gx[g][0] * cj.w[0] + Fi.gx[g][1] * cj.w[1]);
+            Kij[1][1] += wA * tri_dot_x(Fi, g, cj.x);  Kij[1][2] += wA * tri_dot_x(Fi, g, cj.y);
+            Kij[2][0] += wA * (Fi.gy[g][0] * cj.w[0] + Fi.gy[g][1] * cj.w[1]);
+            Kij[2][1] += wA * tri_dot_y(Fi, g, cj.x);  Kij[2][2] += wA * tri_dot_y(Fi, g, cj.y);
+            // bubble columns
+            Ni[0][0] += wA * tri_dot_w(Fi, cb.x);     Ni[0][1] += wA * tri_dot_w(Fi, cb.y);
+            Ni[1][0] += wA * tri_dot_x(Fi, g, cb.x);  Ni[1][1] += wA * tri_dot_x(Fi, g, cb.y);
+            Ni[2][0] += wA * tri_dot_y(Fi, g, cb.x);  Ni[2][1] += wA * tri_dot_y(Fi, g, cb.y);
+            Nj[0][0] += wA * tri_dot_w(Fj, cb.x);     Nj[0][1] += wA * tri_dot_w(Fj, cb.y);
+            Nj[1][0] += wA * tri_dot_x(Fj, g, cb.x);  Nj[1][1] += wA * tri_dot_x(Fj, g, cb.y);
+            Nj[2][0] += wA * tri_dot_y(Fj, g, cb.x);  Nj[2][1] += wA * tri_dot_y(Fj, g, cb.y);
+            Kbb[0][0] += wA * tri_dot_x(Fb, g, cb.x); Kbb[0][1] += wA * tri_dot_x(Fb, g, cb.y);
+            Kbb[1][0] += wA * tri_dot_y(Fb, g, cb.x); Kbb[1][1] += wA * tri_dot_y(Fb, g, cb.y);
+            // drilling (MITC3.py:1024-1035, row 5 of _compute_B_drill :1905-1939)
+            const double wk = wA * kd;
+            dr[0][0] += wk * bdi[0] * bdj[0]; dr[0][1] += wk * bdi[0] * bdj[1];
+            dr[1][0] += wk * bdi[1] * bdj[0]; dr[1][1] += wk * bdi[1] * bdj[1];
+            drz[0] += wk * bdi[0] * (-Fj.h[g]); drz[1] += wk * bdi[1] * (-Fj.h[g]);
+            dzr[0] += wk * (-Fi.h[g]) * bdj[0]; dzr[1] += wk * (-Fi.h[g]) * bdj[1];
+            dzz += wk * Fi.h[g] * Fj.h[g];
+            if (coupled) {  // MITC3_composite.py:204-240 (nodal-only form: the bubble block of K_qq is zero)
+                const double *B = pr->B;
+                {
+                    const double fx = Fj.fx[g], fy = Fj.fy[g];
+                    const double bx[3] = {-(B[1] * fy + B[2] * fx), -(B[4] * fy + B[5] * fx), -(B[7] * fy + B[8] * fx)};
+                    const double by[3] = {B[0] * fx + B[2] * fy, B[3] * fx + B[5] * fy, B[6] * fx + B[8] * fy};
+                    cpl_ij[0][0] += wA * (Fi.dhx * bx[0] + Fi.dhy * bx[2]); cpl_ij[0][1] += wA * (Fi.dhx * by[0] + Fi.dhy * by[2]);
+                    cpl_ij[1][0] += wA * (Fi.dhy * bx[1] + Fi.dhx * bx[2]); cpl_ij[1][1] += wA * (Fi.dhy * by[1] + Fi.dhx * by[2]);
+                }
+                {
+                    const double fx = Fi.fx[g], fy = Fi.fy[g];
+                    const double bx[3] = {-(B[1] * fy + B[2] * fx), -(B[4] * fy + B[5] * fx), -(B[7] * fy + B[8] * fx)};
+                    const double by[3] = {B[0] * fx + B[2] * fy, B[3] * fx + B[5] * fy, B[6] * fx + B[8] * fy};
+                    cpl_ji[0][0] += wA * (Fj.dhx * bx[0] + Fj.dhy * bx[2]); cpl_ji[0][1] += wA * (Fj.dhx * by[0] + Fj.dhy * by[2]);
+                    cpl_ji[1][0] += wA * (Fj.dhy * bx[1] + Fj.dhx * bx[2]); cpl_ji[1][1] += wA * (Fj.dhy * by[1] + Fj.dhx * by[2]);
+                }
+            }
+        }
+        // static condensation of the two bubble rotations (MITC3.py:958-1007)
+        const double det = Kbb[0][0] * Kbb[1][1] - Kbb[0][1] * Kbb[1][0];
+        const double i00 = Kbb[1][1] / det, i01 = -Kbb[0][1] / det, i10 = -Kbb[1][0] / det, i11 = Kbb[0][0] / det;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+                Kij[a][b] -= Ni[a][0] * (i00 * Nj[b][0] + i01 * Nj[b][1]) + Ni[a][1] * (i10 * Nj[b][0] + i11 * Nj[b][1]);
+        if (ti == tj) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (Kij[a][b] + Kij[b][a]); Kij[a][b] = m; Kij[b][a] = m; }
+        }
+        // membrane CST (MITC3.py:1009-1022): area * Bm_i^T A Bm_j
+        {
+            const double ar = geo.area;
+            const double cu[3] = {A[0] * Fj.dhx + A[2] * Fj.dhy, A[3] * Fj.dhx + A[5] * Fj.dhy, A[6] * Fj.dhx + A[8] * Fj.dhy};
+            const double cv[3] = {A[1] * Fj.dhy + A[2] * Fj.dhx, A[4] * Fj.dhy + A[5] * Fj.dhx, A[7] * Fj.dhy + A[8] * Fj.dhx};
+            L[0][0] = ar * (Fi.dhx * cu[0] + Fi.dhy * cu[2]) + dr[0][0]; L[0][1] = ar * (Fi.dhx * cv[0] + Fi.dhy * cv[2]) + dr[0][1];
+            L[1][0] = ar * (Fi.dhy * cu[1] + Fi.dhx * cu[2]) + dr[1][0]; L[1][1] = ar * (Fi.dhy * cv[1] + Fi.dhx * cv[2]) + dr[1][1];
+        }
+        L[0][5] = drz[0]; L[1][5] = drz[1]; L[5][0] = dzr[0]; L[5][1] = dzr[1]; L[5][5] = dzz;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) L[2 + a][2 + b] = Kij[a][b];
+        if (coupled) {
+            L[0][3] = cpl_ij[0][0]; L[0][4] = cpl_ij[0][1]; L[1][3] = cpl_ij[1][0]; L[1][4] = cpl_ij[1][1];
+            L[3][0] = cpl_ji[0][0]; L[4][0] = cpl_ji[0][1]; L[3][1] = cpl_ji[1][0]; L[4][1] = cpl_ji[1][1];
+        }
+        const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+        rotate_block6(L, R, G);
+        if (ti == tj) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a + 1; b < 6; b++) { const double m = 0.5 * (G[a][b] + G[b][a]); G[a][b] = m; G[b][a] = m; }
+        }
+    }
+    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
+#pragma unroll
+    for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
+}
+
+// MITC3 consistent mass (MITC3.py:1105-1138): one thread per (element, pair)
+__global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__ xyz,
+                                                      const int32_t *__restrict__ prop_id,
+                                                      const fs_shell_prop *__restrict__ props,
+                                                      int64_t E, double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * 6) return;
+    const int64_t e = t / 6;
+    const int p = (int)(t - e * 6);
+    const int ti = (p < 3) ? 0 : ((p < 5) ? 1 : 2);
+    const int tj = (p < 3) ? p : ((p < 5) ? p - 2 : 2);
+    double x[3][3];
+    for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+    TriGeom geo;
+    tri_geometry(x, geo);
+    const fs_shell_prop *pr = props + prop_id[e];
+    const double mt = pr->m_t, mr = pr->m_r;
+    double ct = 0.0, cr = 0.0;
+    for (int g = 0; g < 3; g++) {
+        const double r = kTriR[g], s = kTriS[g];
+        const double hi = (ti == 0) ? (1.0 - r - s) : ((ti == 1) ? r : s);
+        const double hj = (tj == 0) ? (1.0 - r - s) : ((tj == 1) ? r : s);
+        ct = ct + hi * hj * mt * (1.0 / 3.0) * geo.area;
+        cr = cr + hi * hj * mr * (1.0 / 3.0) * geo.area;
+    }
+    const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    double G[6][6];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) G[a][b] = 0.0;
+    for (int p3 = 0; p3 < 3; p3++)
+        for (int q = 0; q < 3; q++) {
+            double st = 0.0, sr = 0.0;
+            for (int k = 0; k < 3; k++) {
+                st = FMA(R[k][p3] * ct, R[k][q], st);
+                sr = FMA(R[k][p3] * cr, R[k][q], sr);
+            }
+            G[p3][q] = st;
+            G[3 + p3][3 + q] = sr;
+        }
+    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
+    for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
+}
+
 // geometry probe for bit-exactness tests
 __global__ void mitc4_geom_kernel(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
                                   double *acoef) {
@@ -1157,6 +1469,33 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
         hipLaunchKernelGGL(mitc4_m_kernel, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz,
                            prop_id, props, E, Me);
         FS_LAUNCH_CHECK("mitc4_m_kernel");
+    }
+    return FS_OK;
+}
+
+int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                       int32_t n_props, const double *u_e, int64_t E, uint32_t want, uint32_t layout,
+                       double *Ke, double *Me, double *KTe, double *fe, int32_t *status, void *stream) {
+    (void)u_e; (void)KTe; (void)fe;
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_tri_batch: bad sizes");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_shell_tri_batch: null input");
+    if (layout != FS_LAYOUT_SYMBLK)
+        return fail(FS_EINVAL, "fs_shell_tri_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
+    if (want & (FS_WANT_KT | FS_WANT_FINT))
+        return fail(FS_ENOSYS, "fs_shell_tri_batch: KT / FINT not implemented for MITC3 yet");
+    hipStream_t s = (hipStream_t)stream;
+    if (want & FS_WANT_K) {
+        if (!Ke) return fail(FS_EINVAL, "fs_shell_tri_batch: Ke is null");
+        hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
+                           props, E, Ke, status);
+        FS_LAUNCH_CHECK("mitc3_k_kernel");
+    }
+    if (want & FS_WANT_M) {
+        if (!Me) return fail(FS_EINVAL, "fs_shell_tri_batch: Me is null");
+        hipLaunchKernelGGL(mitc3_m_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
+                           props, E, Me);
+        FS_LAUNCH_CHECK("mitc3_m_kernel");
     }
     return FS_OK;
 }

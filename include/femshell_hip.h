@@ -88,6 +88,19 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
                         uint32_t layout, double *Ke, double *Me, double *KTe, double *fe,
                         int32_t *status, void *stream);
 
+/*
+ * MITC3+ batch (3-node shells).  Replaces, per element, MITC3.__init__/_compute_local_coordinates
+ * (elements/MITC3.py:103-210,375-418), K (:1077-1103 with k_m :1009-1037, _k_bs_condensed :935-1007,
+ * tying :796-933, MITC3Composite._coupling_stiffness MITC3_composite.py:204-240) and M (:1105-1138).
+ * Same arguments as fs_shell_quad_batch with xyz [E][3][3]; FS_LAYOUT_SYMBLK has 6 pair blocks per
+ * element.  FS_WANT_KT / FS_WANT_FINT return FS_ENOSYS (u_e, KTe, fe reserved).
+ * status: FS_ST_NAN_FRAME where the reference raises ValueError("Degenerate triangle").
+ */
+int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                       int32_t n_props, const double *u_e, int64_t E, uint32_t want,
+                       uint32_t layout, double *Ke, double *Me, double *KTe, double *fe,
+                       int32_t *status, void *stream);
+
 /* Geometry stage only, for bit-exactness tests against the oracle:
  * frame[E][9] (e1,e2,e3), xl[E][8], detJ[E][4], acoef[E][5] (a_A..a_E). */
 int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,

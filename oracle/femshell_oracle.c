@@ -751,3 +751,230 @@ int fso_csr_numeric(const int64_t *dofs, int64_t E, int nd, const double *vals_e
     }
     return 0;
 }
+
+/* ====================================================================================
+ * MITC3+ (elements/MITC3.py): CST membrane + drilling, enriched-rotation bending, 6-tying-point
+ * assumed shear, cubic bubble condensed 20 -> 18.  Literal dense restatement.
+ * ==================================================================================== */
+typedef struct {
+    double x[3][3];
+    double e1[3], e2[3], e3[3];
+    double x2, x3, y3;      /* local coords: (0,0), (x2,0), (x3,y3) */
+    double area, Ji[2][2];
+    double dhx[3], dhy[3];
+    int status;
+} tri_t;
+
+static void tri_init(tri_t *t, const double *xyz) { /* MITC3.py:375-418, 427-469, 527-558 */
+    memcpy(t->x, xyz, 9 * sizeof(double));
+    t->status = 0;
+    double v12[3], v13[3], n[3];
+    for (int k = 0; k < 3; k++) { v12[k] = t->x[1][k] - t->x[0][k]; v13[k] = t->x[2][k] - t->x[0][k]; }
+    double L12 = norm3(v12);
+    for (int k = 0; k < 3; k++) t->e1[k] = v12[k] / L12;
+    cross3(v12, v13, n);
+    double nl = norm3(n);
+    if (!(nl >= 1e-12)) t->status |= 1; /* ValueError("Degenerate triangle") */
+    for (int k = 0; k < 3; k++) t->e3[k] = n[k] / nl;
+    cross3(t->e3, t->e1, t->e2);
+    t->x2 = L12; t->x3 = dot3(v13, t->e1); t->y3 = dot3(v13, t->e2);
+    double x1 = 0.0, y1 = 0.0, x2 = L12, y2 = 0.0, x3 = t->x3, y3 = t->y3;
+    t->area = 0.5 * fabs(x1 * (y2 - y3) + x2 * (y3 - y1) + x3 * (y1 - y2));
+    double J[2][2] = {{x2 - x1, y2 - y1}, {x3 - x1, y3 - y1}};
+    double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    inv2(J, det, t->Ji);
+    const double dr[3] = {-1.0, 1.0, 0.0}, ds[3] = {-1.0, 0.0, 1.0};
+    for (int i = 0; i < 3; i++) {
+        t->dhx[i] = t->Ji[0][0] * dr[i] + t->Ji[0][1] * ds[i];
+        t->dhy[i] = t->Ji[1][0] * dr[i] + t->Ji[1][1] * ds[i];
+    }
+}
+
+static void tri_shear_point(const tri_t *t, double r, double s, double *ert, double *est) {
+    /* MITC3.py:796-851 (_evaluate_covariant_shear_at_point_ext), 20-vectors */
+    const double dr[3] = {-1.0, 1.0, 0.0}, ds[3] = {-1.0, 0.0, 1.0};
+    double h[3] = {1.0 - r - s, r, s};
+    double f4 = 27.0 * r * s * (1.0 - r - s);
+    double f[4] = {h[0] - f4 / 3.0, h[1] - f4 / 3.0, h[2] - f4 / 3.0, f4};
+    double gr[2] = {t->x2 - 0.0, 0.0 - 0.0}, gs[2] = {t->x3 - 0.0, t->y3 - 0.0};
+    memset(ert, 0, 20 * sizeof(double)); memset(est, 0, 20 * sizeof(double));
+    for (int i = 0; i < 3; i++) {
+        ert[6 * i + 2] = dr[i]; est[6 * i + 2] = ds[i];
+        ert[6 * i + 4] = f[i] * gr[0]; ert[6 * i + 3] = -f[i] * gr[1];
+        est[6 * i + 4] = f[i] * gs[0]; est[6 * i + 3] = -f[i] * gs[1];
+    }
+    ert[19] = f[3] * gr[0]; ert[18] = -f[3] * gr[1];
+    est[19] = f[3] * gs[0]; est[18] = -f[3] * gs[1];
+}
+
+static void tri_Bgamma_ext(const tri_t *t, double r, double s, double Bg[2][20]) { /* MITC3.py:889-933 */
+    const double d = 1.0e-4;
+    double eA[2][20], eB[2][20], eC[2][20], eD[2][20], eE[2][20], eF[2][20];
+    tri_shear_point(t, 1.0 / 6.0, 2.0 / 3.0, eA[0], eA[1]);
+    tri_shear_point(t, 2.0 / 3.0, 1.0 / 6.0, eB[0], eB[1]);
+    tri_shear_point(t, 1.0 / 6.0, 1.0 / 6.0, eC[0], eC[1]);
+    tri_shear_point(t, 1.0 / 3.0 + d, 1.0 / 3.0 - 2.0 * d, eD[0], eD[1]);
+    tri_shear_point(t, 1.0 / 3.0 - 2.0 * d, 1.0 / 3.0 + d, eE[0], eE[1]);
+    tri_shear_point(t, 1.0 / 3.0 + d, 1.0 / 3.0 + d, eF[0], eF[1]);
+    for (int c = 0; c < 20; c++) {
+        double ertc = (2.0 / 3.0) * (eB[0][c] - 0.5 * eB[1][c]) + (1.0 / 3.0) * (eC[0][c] + eC[1][c]);
+        double estc = (2.0 / 3.0) * (eA[1][c] - 0.5 * eA[0][c]) + (1.0 / 3.0) * (eC[0][c] + eC[1][c]);
+        double chat = (eF[0][c] - eD[0][c]) - (eF[1][c] - eE[1][c]);
+        double ert = ertc + (1.0 / 3.0) * chat * (3.0 * s - 1.0);
+        double est = estc + (1.0 / 3.0) * chat * (1.0 - 3.0 * r);
+        Bg[0][c] = t->Ji[0][0] * ert + t->Ji[0][1] * est;
+        Bg[1][c] = t->Ji[1][0] * ert + t->Ji[1][1] * est;
+    }
+}
+
+static void tri_Bkappa_ext(const tri_t *t, double r, double s, double Bk[3][20]) { /* MITC3.py:853-887 */
+    double df4r = 27.0 * s * (1.0 - 2.0 * r - s), df4s = 27.0 * r * (1.0 - r - 2.0 * s);
+    const double dr[3] = {-1.0, 1.0, 0.0}, ds[3] = {-1.0, 0.0, 1.0};
+    double fr[4] = {dr[0] - df4r / 3.0, dr[1] - df4r / 3.0, dr[2] - df4r / 3.0, df4r};
+    double fs[4] = {ds[0] - df4s / 3.0, ds[1] - df4s / 3.0, ds[2] - df4s / 3.0, df4s};
+    memset(Bk, 0, 60 * sizeof(double));
+    for (int i = 0; i < 4; i++) {
+        double fx = t->Ji[0][0] * fr[i] + t->Ji[0][1] * fs[i];
+        double fy = t->Ji[1][0] * fr[i] + t->Ji[1][1] * fs[i];
+        int thx = (i < 3) ? 6 * i + 3 : 18, thy = (i < 3) ? 6 * i + 4 : 19;
+        Bk[0][thy] = fx; Bk[1][thx] = -fy; Bk[2][thy] = fy; Bk[2][thx] = -fx;
+    }
+}
+
+static void btcb_n(double *acc, int n, double s, const double *Ba, int ra, const double *C, const double *Bb, int rb) {
+    /* acc[n][n] += s * Ba^T (ra x n) C (ra x rb) Bb (rb x n) */
+    for (int i = 0; i < n; i++) {
+        double tt[6];
+        int any = 0;
+        for (int b = 0; b < rb; b++) {
+            double v = 0;
+            for (int a = 0; a < ra; a++) v += (s * Ba[a * n + i]) * C[a * rb + b];
+            tt[b] = v; any |= (v != 0.0);
+        }
+        if (!any) continue;
+        for (int j = 0; j < n; j++) {
+            double v = 0;
+            for (int b = 0; b < rb; b++) v += tt[b] * Bb[b * n + j];
+            acc[i * n + j] += v;
+        }
+    }
+}
+
+static const double TRI_GP[3][2] = {{1.0 / 6.0, 1.0 / 6.0}, {2.0 / 3.0, 1.0 / 6.0}, {1.0 / 6.0, 2.0 / 3.0}};
+
+static void tri_rotate(const tri_t *t, const double *Kl, double *Kg) { /* T^T K T, 6 blocks of 3 */
+    double R[3][3];
+    memcpy(R[0], t->e1, 24); memcpy(R[1], t->e2, 24); memcpy(R[2], t->e3, 24);
+    for (int bi = 0; bi < 6; bi++)
+        for (int bj = 0; bj < 6; bj++) {
+            double X[3][3], Y[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) X[a][b] = Kl[(3 * bi + a) * 18 + 3 * bj + b];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += R[k][a] * X[k][b];
+                    Y[a][b] = s;
+                }
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += Y[a][k] * R[k][b];
+                    Kg[(3 * bi + a) * 18 + 3 * bj + b] = s;
+                }
+        }
+}
+
+int fso_mitc3_K(const double *xyz, const fso_shell_prop *p, double *Ke) { /* MITC3.py:1077-1103 */
+    tri_t t;
+    tri_init(&t, xyz);
+    double km[324], Kext[400], Kl[324], Kg[324];
+    memset(km, 0, sizeof km); memset(Kext, 0, sizeof Kext);
+    double Bm[3][18], kc[324];
+    memset(Bm, 0, sizeof Bm); memset(kc, 0, sizeof kc);
+    for (int i = 0; i < 3; i++) {
+        Bm[0][6 * i] = t.dhx[i]; Bm[1][6 * i + 1] = t.dhy[i];
+        Bm[2][6 * i] = t.dhy[i]; Bm[2][6 * i + 1] = t.dhx[i];
+    }
+    for (int g = 0; g < 3; g++) { /* MITC3.py:1009-1037 */
+        double w = (1.0 / 3.0) * t.area;
+        btcb_n(km, 18, w, &Bm[0][0], 3, p->A, &Bm[0][0], 3);
+    }
+    for (int g = 0; g < 3; g++) {
+        double r = TRI_GP[g][0], s = TRI_GP[g][1], w = (1.0 / 3.0) * t.area;
+        double h[3] = {1.0 - r - s, r, s}, Bd[18];
+        memset(Bd, 0, sizeof Bd);
+        for (int i = 0; i < 3; i++) { Bd[6 * i] = -0.5 * t.dhy[i]; Bd[6 * i + 1] = 0.5 * t.dhx[i]; Bd[6 * i + 5] = -h[i]; }
+        for (int i = 0; i < 18; i++)
+            for (int j = 0; j < 18; j++) km[i * 18 + j] += w * p->k_drill * Bd[i] * Bd[j];
+        double Bk[3][20], Bg[2][20];
+        tri_Bkappa_ext(&t, r, s, Bk);
+        tri_Bgamma_ext(&t, r, s, Bg);
+        btcb_n(Kext, 20, w, &Bk[0][0], 3, p->D, &Bk[0][0], 3);   /* MITC3.py:935-956 */
+        btcb_n(Kext, 20, w, &Bg[0][0], 2, p->Cs, &Bg[0][0], 2);
+        if (p->flags & FSO_PROP_COUPLED) { /* MITC3_composite.py:204-240, nodal-only form */
+            double tmp[324], Bk18[3][18];
+            memset(tmp, 0, sizeof tmp);
+            for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 18; c++) Bk18[a][c] = Bk[a][c];
+            btcb_n(tmp, 18, w, &Bm[0][0], 3, p->B, &Bk18[0][0], 3);
+            for (int i = 0; i < 18; i++)
+                for (int j = 0; j < 18; j++) kc[i * 18 + j] += tmp[i * 18 + j] + tmp[j * 18 + i];
+        }
+    }
+    /* condensation of the 2 bubble rotations */
+    double q00 = Kext[18 * 20 + 18], q01 = Kext[18 * 20 + 19], q10 = Kext[19 * 20 + 18], q11 = Kext[19 * 20 + 19];
+    double det = q00 * q11 - q01 * q10;
+    double i00 = q11 / det, i01 = -q01 / det, i10 = -q10 / det, i11 = q00 / det;
+    double kbs[324];
+    for (int i = 0; i < 18; i++) {
+        double a0 = Kext[i * 20 + 18], a1 = Kext[i * 20 + 19];
+        for (int j = 0; j < 18; j++) {
+            double b0 = Kext[18 * 20 + j], b1 = Kext[19 * 20 + j];
+            kbs[i * 18 + j] = Kext[i * 20 + j] - (a0 * (i00 * b0 + i01 * b1) + a1 * (i10 * b0 + i11 * b1));
+        }
+    }
+    for (int i = 0; i < 18; i++)
+        for (int j = 0; j < 18; j++) {
+            Kl[i * 18 + j] = km[i * 18 + j] + 0.5 * (kbs[i * 18 + j] + kbs[j * 18 + i]);
+            if (p->flags & FSO_PROP_COUPLED) Kl[i * 18 + j] += kc[i * 18 + j];
+        }
+    tri_rotate(&t, Kl, Kg);
+    for (int i = 0; i < 18; i++)
+        for (int j = 0; j < 18; j++) Ke[i * 18 + j] = 0.5 * (Kg[i * 18 + j] + Kg[j * 18 + i]);
+    return t.status;
+}
+
+int fso_mitc3_M(const double *xyz, const fso_shell_prop *p, double *Me) { /* MITC3.py:1105-1138 */
+    tri_t t;
+    tri_init(&t, xyz);
+    double Ml[324];
+    memset(Ml, 0, sizeof Ml);
+    for (int g = 0; g < 3; g++) {
+        double r = TRI_GP[g][0], s = TRI_GP[g][1], w = 1.0 / 3.0;
+        double h[3] = {1.0 - r - s, r, s};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double vt = h[i] * h[j] * p->m_t * w * t.area, vr = h[i] * h[j] * p->m_r * w * t.area;
+                for (int k = 0; k < 3; k++) Ml[(6 * i + k) * 18 + 6 * j + k] += vt;
+                for (int k = 3; k < 6; k++) Ml[(6 * i + k) * 18 + 6 * j + k] += vr;
+            }
+    }
+    tri_rotate(&t, Ml, Me);
+    return t.status;
+}
+
+int fso_mitc3_batch(const double *xyz, const int32_t *prop_id, const fso_shell_prop *props, int64_t E,
+                    double *Ke, double *Me, int32_t *status, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t e = 0; e < E; e++) {
+        int s = 0;
+        if (Ke) s |= fso_mitc3_K(xyz + 9 * e, props + prop_id[e], Ke + 324 * e);
+        if (Me) s |= fso_mitc3_M(xyz + 9 * e, props + prop_id[e], Me + 324 * e);
+        if (status) status[e] = s;
+    }
+    return 0;
+}

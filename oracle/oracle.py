@@ -83,6 +83,19 @@ def mitc4_M_batch(xyz, prop_id, props, nthreads=1):
     return Me, st
 
 
+def mitc3_batch(xyz, prop_id, props, want_K=True, want_M=False, nthreads=1):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3, 3)
+    E = xyz.shape[0]
+    prop_id = np.ascontiguousarray(prop_id, dtype=np.int32).reshape(E)
+    props = as_props(props)
+    Ke = np.empty((E, 18, 18)) if want_K else None
+    Me = np.empty((E, 18, 18)) if want_M else None
+    st = np.zeros(E, dtype=np.int32)
+    lib().fso_mitc3_batch(_p(xyz), _p(prop_id), _p(props), ctypes.c_int64(E), _p(Ke), _p(Me), _p(st),
+                          ctypes.c_int(nthreads))
+    return Ke, Me, st
+
+
 def mitc4_NL(xyz, prop, u):
     xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(4, 3)
     prop = as_props(prop).reshape(-1)[:1]

@@ -92,3 +92,19 @@ def test_assembly_scordelis(oracle):
     err = np.abs(u - g["u"]).max() / np.abs(g["u"]).max()
     print("displacement rel diff vs reference solve", err)
     assert err < 1e-9   # cond(K)*eps floor, see DESIGN.md "displacement parity"
+
+
+def test_mitc3_K_M_vs_reference(oracle):
+    """MITC3+ / MITC3Composite (elements/MITC3.py:1077-1138, MITC3_composite.py:165-240)."""
+    g = golden("elem_mitc3")
+    props = golden_props(g)
+    assert (g["prop_flags"] & 1).any() and (g["kind"] == 0).any()
+    pid = np.arange(g["xyz"].shape[0], dtype=np.int32)
+    K, M, st = oracle.mitc3_batch(g["xyz"], pid, props, want_K=True, want_M=True)
+    assert not st.any()
+    print("oracle MITC3 K vs reference", _rel(K, g["Ke"]), " M", _rel(M, g["Me"]))
+    assert _rel(K, g["Ke"]) < TOL
+    assert _rel(M, g["Me"]) < TOL
+    # property rows: the MITC3 classes evaluate the same constants as the MITC4 ones
+    import fem_shell_amd as fsa
+    assert np.allclose(g["Ke"], np.transpose(g["Ke"], (0, 2, 1)), rtol=0, atol=0)

@@ -126,6 +126,58 @@ def gen_elem_mitc4():
     print("elem_mitc4.npz", N)
 
 
+def tris(n, rng):
+    base = np.array([[0, 0, 0], [1, 0, .05], [.3, 1, .1]], float)
+    shapes = [
+        np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], float),                       # right triangle
+        np.array([[0, 0, 0], [1, 0, 0], [.5, np.sqrt(3) / 2, 0]], float),         # equilateral
+        base, base + 1e3, base * 1e-3 + 3.0, base * np.array([20.0, 1.0, 1.0]),
+        np.array([[0, 0, 0], [1, 0, 0], [2.5, .2, 0]], float),                    # obtuse sliver
+    ]
+    out = []
+    for i in range(n):
+        if i < len(shapes):
+            out.append(shapes[i])
+            continue
+        q = base + 0.1 * rng.standard_normal((3, 3))
+        out.append(q * rng.choice([1.0, 1e-3, 20.0]) + rng.choice([0.0, 0.0, 1e3, 3.0]) * rng.standard_normal(3))
+    return np.array(out)
+
+
+def gen_elem_mitc3():
+    """MITC3 / MITC3Composite K, M and local parts (elements/MITC3.py:1009-1138)."""
+    from fem_shell.elements import MITC3, MITC3Composite
+    rng = np.random.default_rng(3)
+    N = 72
+    xyz = tris(N, rng)
+    rows, Ke, Me, parts, kinds = [], [], [], [], []
+    for i in range(N):
+        size = np.linalg.norm(xyz[i, 1] - xyz[i, 0])
+        if i % 3 != 2:
+            E, nu, rho = ISO[i % len(ISO)]
+            h = float(rng.choice([1e-1, 1e-2, 1e-3, 1e-4]) * size)
+            kap = [None, 0.8][i % 2] if i % 5 == 0 else None
+            el = MITC3(xyz[i], (0, 1, 2), IsotropicMaterial("m", E, nu, rho), h,
+                       shear_correction_factor=kap)
+            lam = None
+            kinds.append(0)
+        else:
+            ang, t = LAYUPS[(i // 3) % len(LAYUPS)]
+            lam = create_laminate_from_angles(t300(), t * size, ang)
+            el = MITC3Composite(xyz[i], (0, 1, 2), lam)
+            kinds.append(1)
+        rows.append(ref_prop_row(el, lam))
+        Ke.append(el.K)
+        Me.append(el.M)
+        kc = el._coupling_stiffness() if el._has_membrane_bending_coupling else np.zeros((18, 18))
+        parts.append(np.stack([el.k_m(), el._k_bs_condensed(), kc]))
+    save = {k: np.array([r[k] for r in rows]) for k in rows[0]}
+    np.savez_compressed(os.path.join(OUT, "elem_mitc3.npz"), xyz=xyz, kind=np.array(kinds),
+                        Ke=np.array(Ke), Me=np.array(Me), parts=np.array(parts),
+                        **{"prop_" + k: v for k, v in save.items()})
+    print("elem_mitc3.npz", N)
+
+
 def gen_elem_nl():
     rng = np.random.default_rng(5)
     N = 24
@@ -233,5 +285,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_elem_mitc4()
     gen_elem_nl()
+    gen_elem_mitc3()
     gen_laminate()
     gen_scordelis(16)
