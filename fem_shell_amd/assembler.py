@@ -121,17 +121,14 @@ class MeshAssembler:
             return coords, conn, elem_ids, thickness, set_lookup
         # duck-typed reference mesh (core/assembler.py:72,107,121-187)
         n2i = mesh.node_id_to_index
-        nn = {e.node_count for e in mesh.elements}
-        if len(nn) != 1:
-            raise NotImplementedError("mixed node counts on the duck-typed path")
-        E, nnodes = len(mesh.elements), nn.pop()
-        conn = np.empty((E, nnodes), dtype=np.int64)
+        E, nnodes = len(mesh.elements), max(e.node_count for e in mesh.elements)
+        conn = np.full((E, nnodes), -1, dtype=np.int64)     # short rows padded with -1
         coords = np.full((mesh.node_count, 3), np.nan)
         elem_ids = np.empty(E, dtype=np.int64)
         thickness = np.full(E, np.nan)
         for i, el in enumerate(mesh.elements):
             idx = [n2i[n] for n in el.node_ids]
-            conn[i] = idx
+            conn[i, :len(idx)] = idx
             coords[idx] = np.asarray(el.node_coords, dtype=float)
             elem_ids[i] = el.id
             if getattr(el, "thickness", None) is not None:
@@ -202,46 +199,68 @@ class MeshAssembler:
                                       "in this round (SOLID is the next row of SURVEY.md 8)")
         self.dofs_per_node, self.spatial_dim = self._FAMILY_PROPERTIES[fam]
         coords, conn, elem_ids, thickness, set_lookup = self._extract()
-        if conn.shape[1] != 4:
-            raise NotImplementedError("only 4-node shells (MITC4+) are built in this round")
         E = conn.shape[0]
         self._coords, self._conn, self._elem_ids = coords, conn, elem_ids
         self._elem_pos = {int(e): i for i, e in enumerate(elem_ids)} if E < 2_000_000 else _RangePos(E)
         self.dofs_count = int(self.mesh.node_count) * self.dofs_per_node
         self._prop_table, self._prop_id = self._property_ids(E, elem_ids, thickness, set_lookup)
         dev = self.device
-        self._conn_d = torch.from_numpy(conn).to(dev)
-        self._xyz_d = torch.from_numpy(coords).to(dev)[self._conn_d]          # [E,4,3] gather (plumbing)
-        self._pid_d = torch.from_numpy(self._prop_id).to(dev)
         self._props_d = batch.to_device_props(self._prop_table)
         self._plan = self._given_plan or BlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node)
         p = self._plan
+        coords_d = torch.from_numpy(coords).to(dev)
+        # element groups (uniform node count each); their block buffers lie back to back
+        self._groups = []
+        for nn, pos, Eg, boff in p.groups:
+            if nn not in (3, 4):
+                raise NotImplementedError(f"shell elements with {nn} nodes are not supported "
+                                          "(reference factory: 3 -> MITC3, 4 -> MITC4)")
+            cg = conn if pos is None else conn[pos, :nn]
+            cg_d = torch.from_numpy(np.ascontiguousarray(cg[:, :nn])).to(dev)
+            pid = self._prop_id if pos is None else self._prop_id[pos]
+            self._groups.append(dict(nn=nn, pos=pos, E=Eg, boff=boff, npair=nn * (nn + 1) // 2,
+                                     conn_d=cg_d, xyz_d=coords_d[cg_d],        # [E_g,nn,3] gather (plumbing)
+                                     pid_d=torch.from_numpy(np.ascontiguousarray(pid)).to(dev)))
+        self._is_mixed_mesh = len(self._groups) > 1
+        g0 = self._groups[0]
+        self._conn_d, self._xyz_d, self._pid_d = g0["conn_d"], g0["xyz_d"], g0["pid_d"]
         self._plan_d = {k: torch.from_numpy(getattr(p, k)).to(dev)
                         for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
         self._desc_d = torch.from_numpy(p.descriptors().view(np.uint8).reshape(-1)).to(dev)
         self.refresh_element_matrices()
 
+    def _group_view(self, buf, g):
+        dd = self.dofs_per_node ** 2
+        return buf[g["boff"]:g["boff"] + g["E"] * g["npair"]].view(g["E"], g["npair"], dd)
+
     def refresh_element_matrices(self, want_K=True, want_M=True, check=True):
         """(Re)run the element kernels: K and M of every element, like the element loop of
         core/assembler.py:121-193 (which always evaluates both).  `check=False` skips the
         host-synchronising status test (call check_status() later)."""
-        out = batch.quad_batch(self._xyz_d, self._pid_d, self._props_d, len(self._prop_table),
-                               want_K=want_K, want_M=want_M, status=True, validate=False)
-        if want_K:
-            self._K_blk = out["K"]
-        if want_M:
-            self._M_blk = out["M"]
-        self._status = out["status"]
+        dd = self.dofs_per_node ** 2
+        nb = self._plan.n_src_blocks
+        if want_K and self._K_blk is None:
+            self._K_blk = torch.empty((nb, dd), dtype=torch.float64, device=self.device)
+        if want_M and self._M_blk is None:
+            self._M_blk = torch.empty((nb, dd), dtype=torch.float64, device=self.device)
+        self._status = []
+        for g in self._groups:
+            out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                    want_K=want_K, want_M=want_M, status=True, validate=False,
+                                    K_out=self._group_view(self._K_blk, g) if want_K else None,
+                                    M_out=self._group_view(self._M_blk, g) if want_M else None)
+            self._status.append(out["status"])
         if check:
             self.check_status()
 
     def check_status(self):
-        out = {"status": self._status}
-        bad = torch.nonzero(out["status"])
-        if bad.numel():
-            e = int(bad[0])
-            raise ValueError(f"element {int(self._elem_ids[e])}: degenerate geometry "
-                             f"(status bits {int(out['status'][e])})")
+        for g, st in zip(self._groups, self._status):
+            bad = torch.nonzero(st)
+            if bad.numel():
+                e = int(bad[0])
+                pos = e if g["pos"] is None else int(g["pos"][e])
+                raise ValueError(f"element {int(self._elem_ids[pos])}: degenerate geometry "
+                                 f"(status bits {int(st[e])})")
 
     def _compute_sparsity_pattern(self):
         self._row_nnz = self._plan.row_nnz()
@@ -253,20 +272,40 @@ class MeshAssembler:
                                           _lib.ptr(self._indices), _lib.stream_ptr()), "fs_csr_pattern_blk")
 
     # ------------------------------------------------------------------ lazy reference views
+    def _dofs_of(self, conn_rows):
+        d = self.dofs_per_node
+        return (conn_rows[:, :, None] * d + np.arange(d, dtype=np.int64)).reshape(conn_rows.shape[0], -1)
+
     @property
     def _dofs_array(self):
+        """[E, nn*d] int64 for uniform meshes, None for mixed ones (core/assembler.py:203-218)."""
+        return None if self._is_mixed_mesh else self._dofs_of(self._conn)
+
+    def _dense(self, buf, uniform):
+        if self._is_mixed_mesh == uniform:
+            return None
         d = self.dofs_per_node
-        return (self._conn[:, :, None] * d + np.arange(d, dtype=np.int64)).reshape(self._conn.shape[0], -1)
+        per_group = [batch.expand_blocks(self._group_view(buf, g), g["nn"], d).cpu().numpy()
+                     for g in self._groups]
+        if uniform:
+            return per_group[0]
+        out = [None] * self._conn.shape[0]
+        for g, arr in zip(self._groups, per_group):
+            for k, pos in enumerate(g["pos"]):
+                out[int(pos)] = arr[k]
+        return out
+
+    _ke_array = property(lambda self: self._dense(self._K_blk, True))
+    _me_array = property(lambda self: self._dense(self._M_blk, True))
+    _ke_list = property(lambda self: self._dense(self._K_blk, False))
+    _me_list = property(lambda self: self._dense(self._M_blk, False))
 
     @property
-    def _ke_array(self):
-        return batch.expand_blocks(self._K_blk, 4, 6).cpu().numpy()
-
-    @property
-    def _me_array(self):
-        return batch.expand_blocks(self._M_blk, 4, 6).cpu().numpy()
-
-    _dofs_list = _ke_list = _me_list = None
+    def _dofs_list(self):
+        if not self._is_mixed_mesh:
+            return None
+        d = self.dofs_per_node
+        return [(row[row >= 0][:, None] * d + np.arange(d, dtype=np.int64)).reshape(-1) for row in self._conn]
 
     @property
     def _element_map(self):
@@ -275,7 +314,7 @@ class MeshAssembler:
     @property
     def _node_dofs_map(self):
         d = self.dofs_per_node
-        used = np.unique(self._conn)
+        used = np.unique(self._conn[self._conn >= 0])
         return {int(n): tuple(range(int(n) * d, int(n) * d + d)) for n in used}
 
     def _make_element(self, pos):
@@ -313,6 +352,8 @@ class MeshAssembler:
 
     # --- new (SURVEY.md 8a "New"): Newton re-assembly of K_T(u) and f_int(u) -----------------
     def _element_displacements(self, u):
+        if self._is_mixed_mesh or self._groups[0]["nn"] != 4:
+            raise NotImplementedError("K_T / f_int re-assembly is available for MITC4 meshes only")
         lib = _lib.load()
         u = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
         if u.numel() != self.dofs_count:

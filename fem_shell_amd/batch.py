@@ -23,8 +23,18 @@ def to_device_props(props: np.ndarray) -> torch.Tensor:
     return raw.to(_dev())
 
 
+def _out_buf(given, E, npair, dev, dd=36):
+    """Caller-provided output view (element groups of one mesh share a block buffer) or a new one."""
+    if given is None:
+        return torch.empty((E, npair, dd), dtype=torch.float64, device=dev)
+    assert given.dtype == torch.float64 and given.is_cuda and given.is_contiguous()
+    assert given.numel() == E * npair * dd
+    return given.view(E, npair, dd)
+
+
 def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
-               status=True, validate=True, u_e=None, want_KT=False, want_F=False):
+               status=True, validate=True, u_e=None, want_KT=False, want_F=False, K_out=None,
+               M_out=None):
     """MITC4+ element matrices for E quads.
 
     xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
@@ -41,8 +51,8 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
         if pmin < 0 or pmax >= n_props:
             raise ValueError("prop_id out of range of the property table")
     out = {}
-    K = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev) if want_K else None
-    M = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev) if want_M else None
+    K = _out_buf(K_out, E, NPAIR4, dev) if want_K else None
+    M = _out_buf(M_out, E, NPAIR4, dev) if want_M else None
     st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
     want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
     KT = F = None
@@ -72,7 +82,7 @@ NPAIR3 = 6
 
 
 def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
-              status=True, validate=True):
+              status=True, validate=True, K_out=None, M_out=None):
     """MITC3+ element matrices for E triangles (fs_shell_tri_batch).
 
     xyz [E,3,3] f64 device.  Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,6,36] or dense
@@ -87,8 +97,8 @@ def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense
         pmin, pmax = int(prop_id.min()), int(prop_id.max())
         if pmin < 0 or pmax >= n_props:
             raise ValueError("prop_id out of range of the property table")
-    K = torch.empty((E, NPAIR3, 36), dtype=torch.float64, device=dev) if want_K else None
-    M = torch.empty((E, NPAIR3, 36), dtype=torch.float64, device=dev) if want_M else None
+    K = _out_buf(K_out, E, NPAIR3, dev) if want_K else None
+    M = _out_buf(M_out, E, NPAIR3, dev) if want_M else None
     st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
     want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
     _lib.check(lib.fs_shell_tri_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),

@@ -162,6 +162,85 @@ class MITC4Composite(MITC4):
         return laminate_row(self.laminate, self.nonlinear)
 
 
+class MITC3(ShellElement):
+    """MITC3+ triangular shell, 6 DOF/node (elements/MITC3.py:35-210)."""
+
+    vector_form = {"U": ("Ux", "Uy", "Uz"), "θ": ("θx", "θy", "θz")}
+
+    def __init__(self, node_coords, node_ids, material, thickness, shear_correction_factor=None,
+                 nonlinear=False):
+        super().__init__("MITC3", node_coords=node_coords, node_ids=node_ids, material=material,
+                         dofs_per_node=6, thickness=thickness, nonlinear=nonlinear)
+        self.element_type = "MITC3"
+        self._initial_coords = np.array(node_coords, dtype=float).copy()
+        if self._initial_coords.shape != (3, 3):
+            raise ValueError("MITC3 needs 3 nodes with 3 coordinates each")
+        self._kappa_arg = shear_correction_factor
+        # MITC3.py:375-418 raises at construction for a degenerate triangle
+        v12, v13 = self._initial_coords[1] - self._initial_coords[0], self._initial_coords[2] - self._initial_coords[0]
+        if np.linalg.norm(np.cross(v12, v13)) < 1e-12:
+            raise ValueError("Degenerate triangle: nodes are collinear")
+
+    def _prop_row(self):
+        if isinstance(self.material, OrthotropicMaterial):
+            raise NotImplementedError("Orthotropic material not yet supported in MITC3")
+        return iso_row(self.material, self.thickness, self._kappa_arg, self.nonlinear)
+
+    def _run(self, **want):
+        import torch
+        from . import batch
+        props = np.zeros(1, dtype=self._prop_row().dtype)
+        props[0] = self._prop_row()
+        dev = batch._dev()
+        xyz = torch.from_numpy(self._initial_coords[None]).to(dev)
+        pid = torch.zeros(1, dtype=torch.int32, device=dev)
+        out = batch.tri_batch(xyz, pid, batch.to_device_props(props), 1, dense=True, **want)
+        _check_status(int(out["status"][0]), self.name)
+        return out
+
+    @cached_property
+    def K(self) -> np.ndarray:
+        """Global-axes stiffness [18,18] (elements/MITC3.py:1077-1103)."""
+        return np.ascontiguousarray(self._run(want_K=True)["K"][0].cpu().numpy())
+
+    @cached_property
+    def M(self) -> np.ndarray:
+        """Consistent mass [18,18] (elements/MITC3.py:1105-1138)."""
+        return np.ascontiguousarray(self._run(want_K=False, want_M=True)["M"][0].cpu().numpy())
+
+    def area(self) -> float:
+        """elements/MITC3.py:427-447."""
+        x = self._initial_coords
+        return 0.5 * float(np.linalg.norm(np.cross(x[1] - x[0], x[2] - x[0])))
+
+
+class MITC3Composite(MITC3):
+    """Laminated MITC3+ (elements/MITC3_composite.py:34-135)."""
+
+    def __init__(self, node_coords, node_ids, laminate: Laminate, nonlinear=False):
+        self.laminate = laminate
+        eq = laminate.get_equivalent_properties()
+        ref = laminate.plies[0].material
+        Ex, Ey, Gxy, nuxy = eq["Ex_membrane"], eq["Ey_membrane"], eq["Gxy_membrane"], eq["nuxy_membrane"]
+        equivalent = OrthotropicMaterial(
+            name=f"Equivalent_{laminate}", E=(Ex, Ey, Ey), G=(Gxy, ref.G[1], ref.G[2]),
+            nu=(nuxy, nuxy * Ey / Ex, nuxy), rho=ref.rho,
+            shear_correction_factor=laminate.shear_correction_factor)
+        super().__init__(node_coords=node_coords, node_ids=node_ids, material=equivalent,
+                         thickness=laminate.total_thickness,
+                         shear_correction_factor=laminate.shear_correction_factor,
+                         nonlinear=nonlinear)
+        self.element_type = "MITC3Composite"
+
+    A = property(lambda self: self.laminate.A)
+    B_coup = property(lambda self: self.laminate.B)
+    D = property(lambda self: self.laminate.D)
+    has_coupling = property(lambda self: not self.laminate.is_symmetric)
+
+    def _prop_row(self):
+        return laminate_row(self.laminate, self.nonlinear)
+
+
 class ElementFactory:
     """elements/elements.py:107-259: dispatch by family x node count x composite."""
 
@@ -175,8 +254,8 @@ class ElementFactory:
         else:
             laminate = kwargs.pop("laminate", None)
             is_composite = laminate is not None
-        shell_map = {4: MITC4}
-        shell_composite_map = {4: MITC4Composite}
+        shell_map = {3: MITC3, 4: MITC4}
+        shell_composite_map = {3: MITC3Composite, 4: MITC4Composite}
         node_ids = mesh_element.node_ids
         node_coords = mesh_element.node_coords
         node_count = mesh_element.node_count

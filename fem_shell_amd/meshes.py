@@ -22,15 +22,16 @@ class _ElemView:
 
     @property
     def node_ids(self):
-        return tuple(int(i) for i in self._m.conn[self.id])
+        return tuple(int(i) for i in self._m.conn[self.id] if i >= 0)
 
     @property
     def node_count(self):
-        return self._m.conn.shape[1]
+        return int((self._m.conn[self.id] >= 0).sum())
 
     @property
     def node_coords(self):
-        return self._m.coords[self._m.conn[self.id]]
+        row = self._m.conn[self.id]
+        return self._m.coords[row[row >= 0]]
 
     thickness = None
 
@@ -55,7 +56,8 @@ class _ElemList:
 
 class ArrayMesh:
     """coords [N,3] float64, conn [E,nn] int (node indices == node ids), optional element sets
-    given as {name: int array of element indices} or a per-element set-id array + names."""
+    given as {name: int array of element indices} or a per-element set-id array + names.
+    Mixed node counts (e.g. triangles + quads): pad the short rows of `conn` with -1."""
 
     def __init__(self, coords, conn, set_id=None, set_names=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
@@ -121,6 +123,23 @@ def structured_conn(nx, ny, triangular=False):
         return np.stack([n00, n10, n11, n01], -1).reshape(-1, 4)
     t = np.stack([np.stack([n00, n10, n11], -1), np.stack([n00, n11, n01], -1)], 2)
     return t.reshape(-1, 3)
+
+
+def mixed_conn(nx, ny):
+    """Quads and triangle pairs alternating cell by cell (checkerboard), triangles padded with -1:
+    the smallest mesh that exercises a mixed MITC3+/MITC4+ assembly."""
+    q = structured_conn(nx, ny)
+    cell = np.arange(nx * ny)
+    tri_cell = ((cell // nx + cell % nx) % 2).astype(bool)
+    rows = []
+    for c in range(nx * ny):
+        n00, n10, n11, n01 = q[c]
+        if tri_cell[c]:
+            rows.append((n00, n10, n11, -1))
+            rows.append((n00, n11, n01, -1))
+        else:
+            rows.append((n00, n10, n11, n01))
+    return np.array(rows, dtype=np.int64)
 
 
 def cylindrical_patch(radius, length, angle_deg, nx, ny, triangular=False):

@@ -30,21 +30,60 @@ def pair_index(nn):
     return P, T
 
 
+def split_groups(conn):
+    """Padded connectivity [E, nnmax] (-1 = absent, trailing) -> list of (nn, pos, conn_g):
+    pos = positions of the group's elements in the mesh's element order (None: all, in order)."""
+    conn = np.ascontiguousarray(conn, dtype=np.int64)
+    E, nnmax = conn.shape
+    if E == 0 or conn.min() >= 0:
+        return [(nnmax, None, conn)]
+    cnt = (conn >= 0).sum(axis=1)
+    col = np.arange(nnmax)
+    if not np.array_equal(conn >= 0, col[None, :] < cnt[:, None]):
+        raise ValueError("padded connectivity: -1 entries must trail the node list")
+    out = []
+    for nn in np.unique(cnt):
+        pos = np.flatnonzero(cnt == nn).astype(np.int64)
+        out.append((int(nn), pos, np.ascontiguousarray(conn[pos, :nn])))
+    if len(out) == 1 and out[0][2].shape[0] == E:
+        return [(out[0][0], None, out[0][2])]
+    return out
+
+
 class BlockPlan:
-    """Node-pair block scatter plan for one element group (uniform nn nodes, d dofs/node)."""
+    """Node-pair block scatter plan (uniform d dofs/node; one or more element groups, each with a
+    uniform node count; the groups' FS_LAYOUT_SYMBLK buffers are laid out back to back)."""
 
     def __init__(self, conn: np.ndarray, n_nodes: int, d: int, extra_pairs=None):
-        """extra_pairs: optional int64 [n,2] node pairs (I,J) that must exist in the pattern even
-        without a local contribution (ghost columns of interface rows in a distributed run)."""
-        conn = np.ascontiguousarray(conn, dtype=np.int64)
-        E, nn = conn.shape
-        self.n_nodes, self.d, self.nn, self.E = int(n_nodes), int(d), nn, E
-        npair = nn * (nn + 1) // 2
-        if E and (conn.min() < 0 or conn.max() >= n_nodes):
-            raise ValueError("connectivity refers to nodes outside [0, n_nodes)")
-        # (I, J) key of every local node pair, e-major so a stable sort keeps element order
-        keys = (conn[:, :, None] * n_nodes + conn[:, None, :]).reshape(-1)
-        order = np.argsort(keys, kind="stable")
+        """conn: [E,nn] (or -1-padded for mixed node counts).  extra_pairs: optional int64 [n,2]
+        node pairs (I,J) that must exist in the pattern even without a local contribution (ghost
+        columns of interface rows in a distributed run)."""
+        groups = split_groups(conn)
+        self.n_nodes, self.d = int(n_nodes), int(d)
+        self.E = int(np.asarray(conn).shape[0])
+        self.groups = []          # (nn, pos, E_g, block offset)
+        keys_l, src_l, ord_l = [], [], []
+        off = 0
+        for nn, pos, cg in groups:
+            Eg = cg.shape[0]
+            npair = nn * (nn + 1) // 2
+            if Eg and (cg.min() < 0 or cg.max() >= n_nodes):
+                raise ValueError("connectivity refers to nodes outside [0, n_nodes)")
+            # (I, J) key of every local node pair, e-major so a stable sort keeps element order
+            keys_l.append((cg[:, :, None] * n_nodes + cg[:, None, :]).reshape(-1))
+            self.groups.append((nn, pos, Eg, off))
+            off += Eg * npair
+        self.n_src_blocks = off
+        self.nn = groups[0][0] if len(groups) == 1 else None
+        if len(groups) == 1:
+            keys = keys_l[0]
+            order = np.argsort(keys, kind="stable")
+        else:
+            keys = np.concatenate(keys_l)
+            eord = np.concatenate([np.repeat(pos if pos is not None else np.arange(Eg), nn * nn)
+                                   for (nn, pos, Eg, _) in self.groups])
+            order = np.lexsort((eord, keys))
+            del eord
         skeys = keys[order]
         first = np.ones(skeys.shape[0], dtype=bool)
         first[1:] = skeys[1:] != skeys[:-1]
@@ -58,11 +97,19 @@ class BlockPlan:
         self.nbr = (ukeys % n_nodes).astype(np.int32)
         self.nbr_ptr = np.searchsorted(self.blk_row, np.arange(n_nodes + 1), side="left").astype(np.int64)
         self.blk_ptr = np.append(np.searchsorted(skeys, ukeys, side="left"), skeys.shape[0]).astype(np.int64)
-        P, T = pair_index(nn)
-        e_of = order // (nn * nn)
-        ab = order % (nn * nn)
-        src_blk = e_of * npair + P.reshape(-1)[ab]
-        self.contrib = ((src_blk << 1) | T.reshape(-1)[ab]).astype(np.int64)
+        # source block (index << 1 | transposed) of every sorted entry
+        contrib = np.empty(order.shape[0], dtype=np.int64)
+        lo = 0
+        for nn, pos, Eg, boff in self.groups:
+            hi = lo + Eg * nn * nn
+            sel = (order >= lo) & (order < hi) if len(self.groups) > 1 else slice(None)
+            o = order[sel] - lo
+            P, T = pair_index(nn)
+            ab = o % (nn * nn)
+            src_blk = boff + (o // (nn * nn)) * (nn * (nn + 1) // 2) + P.reshape(-1)[ab]
+            contrib[sel] = (src_blk << 1) | T.reshape(-1)[ab]
+            lo = hi
+        self.contrib = contrib
 
     @property
     def nnz(self):

@@ -123,3 +123,22 @@ def csr_assemble(dofs, ndof, vals_e):
                                    _p(indptr), _p(indices), _p(data))
         assert rc == 0
     return indptr, indices, data
+
+
+def csr_assemble_mixed(dofs_list, ndof, ke_list):
+    """Mixed-mesh branch of the reference assembler (core/assembler.py:232-241 pattern by set
+    union, :287-292 values added element by element).  Pure NumPy/Python: small meshes only."""
+    rows = [set() for _ in range(ndof)]
+    for dofs in dofs_list:
+        for r in dofs:
+            rows[int(r)].update(int(c) for c in dofs)
+    indptr = np.zeros(ndof + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum([len(s) for s in rows])
+    indices = np.fromiter((c for s in rows for c in sorted(s)), dtype=np.int32, count=int(indptr[-1]))
+    data = np.zeros(indices.shape[0])
+    for dofs, ke in zip(dofs_list, ke_list):
+        for a, r in enumerate(dofs):
+            lo, hi = indptr[r], indptr[r + 1]
+            pos = lo + np.searchsorted(indices[lo:hi], dofs)
+            data[pos] += ke[a]
+    return indptr, indices, data

@@ -140,3 +140,41 @@ def test_mesh_protocol():
     a = meshes.jittered_plate(4, 3, x_offset_cells=0).coords.reshape(4, 5, 3)
     b = meshes.jittered_plate(4, 3, x_offset_cells=4).coords.reshape(4, 5, 3)
     assert np.array_equal(a[:, 4], b[:, 0])      # shards agree bit for bit on interface nodes
+
+
+def test_mixed_group_plan_matches_set_union(oracle):
+    """Triangles + quads in one shell mesh (padded connectivity): the grouped BlockPlan equals the
+    reference's mixed-mesh pattern, and replaying its contributions on the host equals the
+    element-by-element ADD_VALUES loop (core/assembler.py:232-241, 287-292)."""
+    from fem_shell_amd import meshes, symbolic
+    from tests import util
+    conn = meshes.mixed_conn(5, 4)
+    n_nodes = 6 * 5
+    plan = symbolic.BlockPlan(conn, n_nodes, 6)
+    assert len(plan.groups) == 2 and plan.groups[0][0] == 3 and plan.groups[1][0] == 4
+    rng = np.random.default_rng(0)
+    dofs_list, ke_list = [], []
+    bufs = {}
+    for nn, pos, Eg, boff in plan.groups:
+        blocks = rng.standard_normal((Eg, nn * (nn + 1) // 2, 36))
+        bufs[nn] = (pos, blocks)
+    packed = np.concatenate([bufs[nn][1].reshape(-1, 36) for nn, *_ in plan.groups])
+    dense_of = {}
+    for nn, (pos, blocks) in bufs.items():
+        P, T = symbolic.pair_index(nn)
+        for k, e in enumerate(pos):
+            ke = np.empty((nn * 6, nn * 6))
+            for i in range(nn):
+                for j in range(nn):
+                    b = blocks[k, P[i, j]].reshape(6, 6)
+                    ke[6 * i:6 * i + 6, 6 * j:6 * j + 6] = b.T if T[i, j] else b
+            dense_of[int(e)] = ke
+    for e in range(conn.shape[0]):
+        row = conn[e][conn[e] >= 0]
+        dofs_list.append((row[:, None] * 6 + np.arange(6)).reshape(-1))
+        ke_list.append(dense_of[e])
+    ip, ix, data = oracle.csr_assemble_mixed(dofs_list, n_nodes * 6, ke_list)
+    hp, hx = plan.host_pattern()
+    assert np.array_equal(hp, ip) and np.array_equal(hx, ix)
+    got = util.host_block_assemble(plan, packed)
+    assert np.array_equal(got, data)      # same summation order -> bitwise equal
