@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEMSHELL_HIP_LIB") or os.path.join(_HERE, "csrc", "libfemshell_hip.so")
 
 FS_WANT_K, FS_WANT_M, FS_WANT_KT, FS_WANT_FINT = 1, 2, 4, 8
+FS_WANT_FBODY, FS_WANT_KG = 16, 32
 FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK = 0, 1
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
@@ -19,6 +20,8 @@ SIGNATURES = {
                                            _vp, _vp, _vp, _vp]),
     "fs_shell_tri_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
                                           _vp, _vp, _vp, _vp]),
+    "fs_solid_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _i64, _u32, _u32, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp]),
     "fs_shell_quad_geom": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_blk_expand": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "fs_csr_numeric": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -21,7 +21,7 @@ import torch
 from . import _lib, batch
 from .elements import ElementFactory, ElementFamily
 from .properties import (CompositeShellProperty, ShellProperty, build_prop_table, iso_row,
-                         laminate_row, PROP_DTYPE)
+                         laminate_row, solid_row, PROP_DTYPE)
 from .symbolic import BlockPlan, vector_plan
 
 
@@ -194,27 +194,40 @@ class MeshAssembler:
     # ------------------------------------------------------------------ precompute
     def _precompute_elements(self):
         fam = self.model.get("element_family")
-        if fam != ElementFamily.SHELL:
-            raise NotImplementedError("fem_shell_amd.MeshAssembler: only ElementFamily.SHELL is built "
-                                      "in this round (SOLID is the next row of SURVEY.md 8)")
+        if fam not in (ElementFamily.SHELL, ElementFamily.SOLID):
+            raise NotImplementedError("fem_shell_amd.MeshAssembler: ElementFamily.SHELL and .SOLID are on "
+                                      "the GPU path (PLANE and family-less mixed models are not)")
+        self._family = fam
         self.dofs_per_node, self.spatial_dim = self._FAMILY_PROPERTIES[fam]
         coords, conn, elem_ids, thickness, set_lookup = self._extract()
         E = conn.shape[0]
         self._coords, self._conn, self._elem_ids = coords, conn, elem_ids
         self._elem_pos = {int(e): i for i, e in enumerate(elem_ids)} if E < 2_000_000 else _RangePos(E)
         self.dofs_count = int(self.mesh.node_count) * self.dofs_per_node
-        self._prop_table, self._prop_id = self._property_ids(E, elem_ids, thickness, set_lookup)
         dev = self.device
-        self._props_d = batch.to_device_props(self._prop_table)
+        if fam == ElementFamily.SHELL:
+            self._prop_table, self._prop_id = self._property_ids(E, elem_ids, thickness, set_lookup)
+            self._props_d = batch.to_device_props(self._prop_table)
+            allowed = (3, 4)
+        else:
+            # elements/SOLID.py:69-104: one material (+ optional 3x3 orientation) for the whole model
+            if "material" not in self.model:
+                raise TypeError("model['elements'] needs 'material' for ElementFamily.SOLID")
+            self._reduced = bool(self.model.get("reduced_integration", False))
+            self._prop_table = solid_row(self.model["material"], self.model.get("orientation"))[None]
+            self._prop_id = np.zeros(E, dtype=np.int32)
+            self._prop_objects = [self.model["material"]]
+            self._props_d = batch.to_device_solid_props(self._prop_table)
+            allowed = (4, 5, 6, 8)
         self._plan = self._given_plan or BlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node)
         p = self._plan
         coords_d = torch.from_numpy(coords).to(dev)
         # element groups (uniform node count each); their block buffers lie back to back
         self._groups = []
         for nn, pos, Eg, boff in p.groups:
-            if nn not in (3, 4):
-                raise NotImplementedError(f"shell elements with {nn} nodes are not supported "
-                                          "(reference factory: 3 -> MITC3, 4 -> MITC4)")
+            if nn not in allowed:
+                raise NotImplementedError(f"{fam.name} elements with {nn} nodes are not on the GPU path "
+                                          f"(supported node counts: {allowed})")
             cg = conn if pos is None else conn[pos, :nn]
             cg_d = torch.from_numpy(np.ascontiguousarray(cg[:, :nn])).to(dev)
             pid = self._prop_id if pos is None else self._prop_id[pos]
@@ -245,10 +258,14 @@ class MeshAssembler:
             self._M_blk = torch.empty((nb, dd), dtype=torch.float64, device=self.device)
         self._status = []
         for g in self._groups:
-            out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
-                                    want_K=want_K, want_M=want_M, status=True, validate=False,
-                                    K_out=self._group_view(self._K_blk, g) if want_K else None,
-                                    M_out=self._group_view(self._M_blk, g) if want_M else None)
+            kw = dict(want_K=want_K, want_M=want_M, status=True, validate=False,
+                      K_out=self._group_view(self._K_blk, g) if want_K else None,
+                      M_out=self._group_view(self._M_blk, g) if want_M else None)
+            if self._family == ElementFamily.SHELL:
+                out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table), **kw)
+            else:
+                out = batch.solid_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                        reduced=self._reduced, **kw)
             self._status.append(out["status"])
         if check:
             self.check_status()
@@ -322,6 +339,8 @@ class MeshAssembler:
         prop = self._prop_objects[int(self._prop_id[pos])]
         extra = {k: v for k, v in self.model.items()
                  if k not in ("properties", "material", "thickness", "laminate", "element_family")}
+        if self._family == ElementFamily.SOLID:
+            return ElementFactory.get_element(ElementFamily.SOLID, view, material=self.model["material"], **extra)
         return ElementFactory.get_element(ElementFamily.SHELL, view, shell_property=prop, **extra)
 
     # ------------------------------------------------------------------ assembly
@@ -352,7 +371,7 @@ class MeshAssembler:
 
     # --- new (SURVEY.md 8a "New"): Newton re-assembly of K_T(u) and f_int(u) -----------------
     def _element_displacements(self, u):
-        if self._is_mixed_mesh or self._groups[0]["nn"] != 4:
+        if self._family != ElementFamily.SHELL or self._is_mixed_mesh or self._groups[0]["nn"] != 4:
             raise NotImplementedError("K_T / f_int re-assembly is available for MITC4 meshes only")
         lib = _lib.load()
         u = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
@@ -373,6 +392,7 @@ class MeshAssembler:
                                 want_KT=want_KT, want_F=want_F)
 
     def _scatter_vector(self, fe):
+        """fe: flat device buffer of the groups' element vectors, group after group."""
         lib = _lib.load()
         if not hasattr(self, "_vplan_d"):
             seg, src = vector_plan(self._conn, int(self.mesh.node_count), self.dofs_per_node)
@@ -398,8 +418,51 @@ class MeshAssembler:
         return self._assemble(out["KT"]), self._scatter_vector(out["f_int"])
 
     def assemble_load_vector(self, load_condition):
-        """core/assembler.py:338-384: shells have no body_load in the reference (AttributeError)."""
-        raise AttributeError("'MITC4' object has no attribute 'body_load'")
+        """core/assembler.py:338-384: fe = element.body_load(load_condition.value), scatter-added in
+        element order.  Shells have no body_load in the reference (AttributeError)."""
+        if self._family != ElementFamily.SOLID:
+            name = "MITC3" if self._groups[0]["nn"] == 3 else "MITC4"
+            raise AttributeError(f"'{name}' object has no attribute 'body_load'")
+        value = getattr(load_condition, "value", load_condition)
+        parts = []
+        for g in self._groups:
+            out = batch.solid_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                    want_K=False, want_M=False, body=value, reduced=self._reduced,
+                                    status=False, validate=False)
+            parts.append(out["f"].reshape(-1))
+        return self._scatter_vector(parts[0] if len(parts) == 1 else torch.cat(parts))
+
+    def assemble_geometric_stiffness(self, stress_field=None, omega=None, rotation_axis=None,
+                                     rotation_center=None) -> CsrMatrix:
+        """core/assembler.py:386-516 for solids with an explicit `stress_field`
+        ({element id: Voigt [xx,yy,zz,xy,yz,zx]} or an [E,6] array in element order): per element
+        compute_geometric_stiffness(sigma) (elements/SOLID.py:322-374), scatter-added like K.
+        Elements without an entry (or with max|sigma| < 1e-20) contribute zeros; unlike the PETSc
+        matrix of the reference the returned CSR keeps K's full pattern (explicit zeros)."""
+        if stress_field is None and omega is None:
+            raise ValueError("Either 'stress_field' or 'omega' must be provided for geometric stiffness")
+        if self._family != ElementFamily.SOLID:
+            raise NotImplementedError("geometric stiffness is on the GPU path for solids only "
+                                      "(shell K_sigma is part of assemble_tangent_stiffness)")
+        if stress_field is None:
+            raise NotImplementedError("centrifugal prestress (omega) is not on the GPU path; pass stress_field")
+        E = self._conn.shape[0]
+        if isinstance(stress_field, dict):
+            sig = np.zeros((E, 6))
+            for eid, sv in stress_field.items():
+                if eid in self._elem_pos:
+                    sig[self._elem_pos[eid]] = np.asarray(sv, dtype=float)
+        else:
+            sig = np.ascontiguousarray(stress_field, dtype=np.float64).reshape(E, 6)
+        sig = np.where(np.abs(sig).max(axis=1, keepdims=True) < 1e-20, 0.0, sig)
+        buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
+        for g in self._groups:
+            sg = torch.from_numpy(np.ascontiguousarray(sig if g["pos"] is None else sig[g["pos"]])).to(self.device)
+            out = batch.solid_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                    want_K=False, want_M=False, sigma=sg, reduced=self._reduced,
+                                    status=False, validate=False)
+            self._group_view(buf, g).copy_(out["KG"])
+        return self._assemble(buf)
 
 
 class _RangePos:

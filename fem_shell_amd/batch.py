@@ -111,6 +111,59 @@ def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense
     return {"K": K, "M": M, "KT": None, "f_int": None, "status": st}
 
 
+def solid_batch(nn, xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, body=None,
+                sigma=None, reduced=False, dense=False, status=True, validate=True, K_out=None,
+                M_out=None):
+    """Linear solids (fs_solid_batch): nn = 4 TETRA4, 5 PYRAMID5, 6 WEDGE6, 8 HEXA8.
+
+    xyz [E,nn,3] f64 device; props_dev [P,37] f64 device (properties.solid_row).  body: 3 floats
+    (host) -> 'f' [E,3nn]; sigma [E,6] device -> 'KG'.  Matrices in FS_LAYOUT_SYMBLK
+    [E, nn(nn+1)/2, 9] or dense [E,3nn,3nn]."""
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    if nn not in (4, 5, 6, 8):
+        raise NotImplementedError(f"solid elements with {nn} nodes are not on the GPU path")
+    assert xyz.dtype == torch.float64 and xyz.shape[1:] == (nn, 3) and xyz.is_cuda
+    assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
+    assert props_dev.dtype == torch.float64 and props_dev.numel() == 37 * n_props
+    if E and validate:
+        pmin, pmax = int(prop_id.min()), int(prop_id.max())
+        if pmin < 0 or pmax >= n_props:
+            raise ValueError("prop_id out of range of the property table")
+    npair = nn * (nn + 1) // 2
+    K = _out_buf(K_out, E, npair, dev, 9) if want_K else None
+    M = _out_buf(M_out, E, npair, dev, 9) if want_M else None
+    st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
+    want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
+    F = KG = b3 = None
+    if body is not None:
+        b3 = np.ascontiguousarray(np.asarray(body, dtype=np.float64)[:3])
+        F = torch.empty((E, 3 * nn), dtype=torch.float64, device=dev)
+        want |= _lib.FS_WANT_FBODY
+    if sigma is not None:
+        sigma = sigma.contiguous()
+        assert sigma.dtype == torch.float64 and sigma.shape == (E, 6) and sigma.is_cuda
+        KG = torch.empty((E, npair, 9), dtype=torch.float64, device=dev)
+        want |= _lib.FS_WANT_KG
+    _lib.check(lib.fs_solid_batch(nn, int(bool(reduced)), _lib.ptr(xyz), _lib.ptr(prop_id),
+                                  _lib.ptr(props_dev), n_props, E, want, _lib.FS_LAYOUT_SYMBLK,
+                                  b3.ctypes.data if b3 is not None else None, _lib.ptr(sigma),
+                                  _lib.ptr(K), _lib.ptr(M), _lib.ptr(F), _lib.ptr(KG), _lib.ptr(st),
+                                  _lib.stream_ptr()), "fs_solid_batch")
+    if dense:
+        K = expand_blocks(K, nn, 3) if K is not None else None
+        M = expand_blocks(M, nn, 3) if M is not None else None
+        KG = expand_blocks(KG, nn, 3) if KG is not None else None
+    return {"K": K, "M": M, "f": F, "KG": KG, "status": st}
+
+
+def to_device_solid_props(rows) -> torch.Tensor:
+    rows = np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, 37))
+    return torch.from_numpy(rows).to(_dev())
+
+
 def shell_batch(nn, *args, **kw):
     """Dispatch on nodes per element (4 -> MITC4+, 3 -> MITC3+)."""
     if nn == 4:

@@ -1216,6 +1216,199 @@ __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__
     for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Linear solids (elements/SOLID.py): TETRA4 / PYRAMID5 / WEDGE6 / HEXA8, 3 dofs per node.
+// Workgroup = EPB elements.  Phase 1: thread (element, Gauss point) -> Jacobian, w*detJ and the
+// physical gradients of all NN shape functions into LDS.  Phase 2: thread (element, node pair
+// i<=j) -> 3x3 block of K (B_i^T C B_j), M, K_G; threads p < NN also the body-load vector.
+// Output FS_LAYOUT_SYMBLK with d = 3: [E][NN(NN+1)/2][9].
+// ------------------------------------------------------------------------------------------
+struct SolidRule { double pt[8][3]; double w[8]; int ng; };
+
+template <int NN>
+__device__ __forceinline__ void solid_shape(double xi, double eta, double zeta, double *N, double *dxi,
+                                            double *deta, double *dzeta) {
+    if constexpr (NN == 8) {  // SOLID.py:1768-1818
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const double sx = ((i & 3) == 1 || (i & 3) == 2) ? 1.0 : -1.0, sy = (i & 2) ? 1.0 : -1.0, sz = (i & 4) ? 1.0 : -1.0;
+            const double fx = 1.0 + sx * xi, fy = 1.0 + sy * eta, fz = 1.0 + sz * zeta;
+            N[i] = 0.125 * (fx * fy * fz);
+            dxi[i] = 0.125 * (sx * fy * fz); deta[i] = 0.125 * (sy * fx * fz); dzeta[i] = 0.125 * (sz * fx * fy);
+        }
+    } else if constexpr (NN == 4) {  // SOLID.py:1581-1597
+        N[0] = 1.0 - xi - eta - zeta; N[1] = xi; N[2] = eta; N[3] = zeta;
+        dxi[0] = -1.0; dxi[1] = 1.0; dxi[2] = 0.0; dxi[3] = 0.0;
+        deta[0] = -1.0; deta[1] = 0.0; deta[2] = 1.0; deta[3] = 0.0;
+        dzeta[0] = -1.0; dzeta[1] = 0.0; dzeta[2] = 0.0; dzeta[3] = 1.0;
+    } else if constexpr (NN == 6) {  // SOLID.py:756-829
+        const double L[3] = {1.0 - xi - eta, xi, eta}, Lm = 0.5 * (1.0 - zeta), Lp = 0.5 * (1.0 + zeta);
+        const double dLx[3] = {-1.0, 1.0, 0.0}, dLe[3] = {-1.0, 0.0, 1.0};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            N[i] = L[i] * Lm; N[3 + i] = L[i] * Lp;
+            dxi[i] = dLx[i] * Lm; dxi[3 + i] = dLx[i] * Lp;
+            deta[i] = dLe[i] * Lm; deta[3 + i] = dLe[i] * Lp;
+            dzeta[i] = L[i] * -0.5; dzeta[3 + i] = L[i] * 0.5;
+        }
+    } else {  // PYRAMID5, SOLID.py:1129-1218
+        static_assert(NN == 5, "unsupported solid");
+        double r = 1.0 - zeta;
+        r = (r < 1e-14) ? 1e-14 : r;
+        const double r2 = r * r, rmx = r - xi, rpx = r + xi, rme = r - eta, rpe = r + eta;
+        N[0] = 0.25 * rmx * rme / r; N[1] = 0.25 * rpx * rme / r; N[2] = 0.25 * rpx * rpe / r; N[3] = 0.25 * rmx * rpe / r; N[4] = zeta;
+        dxi[0] = -0.25 * rme / r; dxi[1] = 0.25 * rme / r; dxi[2] = 0.25 * rpe / r; dxi[3] = -0.25 * rpe / r; dxi[4] = 0.0;
+        deta[0] = -0.25 * rmx / r; deta[1] = -0.25 * rpx / r; deta[2] = 0.25 * rpx / r; deta[3] = 0.25 * rmx / r; deta[4] = 0.0;
+        dzeta[0] = -0.25 * (rme + rmx) / r + 0.25 * rmx * rme / r2;
+        dzeta[1] = -0.25 * (rme + rpx) / r + 0.25 * rpx * rme / r2;
+        dzeta[2] = -0.25 * (rpe + rpx) / r + 0.25 * rpx * rpe / r2;
+        dzeta[3] = -0.25 * (rpe + rmx) / r + 0.25 * rmx * rpe / r2;
+        dzeta[4] = 1.0;
+    }
+}
+
+template <int NN>
+__global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ xyz,
+                                                    const int32_t *__restrict__ prop_id,
+                                                    const double *__restrict__ props, int64_t E,
+                                                    SolidRule rule, double bx, double by, double bz,
+                                                    const double *__restrict__ sigma,
+                                                    double *__restrict__ Ke, double *__restrict__ Me,
+                                                    double *__restrict__ fe, double *__restrict__ KGe,
+                                                    int32_t *__restrict__ status) {
+    constexpr int NPAIR = NN * (NN + 1) / 2;
+    constexpr int EPB = 256 / NPAIR;
+    constexpr int GS = NN * 3;                     // doubles of one gradient set
+    __shared__ double s_g[EPB * 8 * GS];           // dN/dx      (SOLID.py:245-248)
+    __shared__ double s_gt[EPB * 8 * GS];          // inv_J.T form used by K_G (SOLID.py:352-354)
+    __shared__ double s_wd[EPB * 8];               // w * detJ
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int ng = rule.ng;
+    {
+#pragma clang fp contract(fast)
+        const int el = tid / ng, q = tid - el * ng;
+        const int64_t e = e0 + el;
+        if (el < EPB && e < E) {
+            double N[NN], dxi[NN], deta[NN], dzeta[NN];
+            solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, dxi, deta, dzeta);
+            double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            const double *x = xyz + e * GS;
+#pragma unroll
+            for (int i = 0; i < NN; i++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double xc = x[3 * i + c];
+                    J[0][c] += dxi[i] * xc; J[1][c] += deta[i] * xc; J[2][c] += dzeta[i] * xc;
+                }
+            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0],
+                         c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+            const double det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+            if (det <= 1e-14 && status) atomicOr(status + e, FS_ST_BAD_JAC);   // ValueError in SOLID.py:211-212
+            double inv[3][3];
+            inv[0][0] = c00 / det; inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+            inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det; inv[1][0] = -c01 / det;
+            inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det; inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+            inv[2][0] = c02 / det; inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+            inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+            double *g = s_g + (el * 8 + q) * GS, *gt = s_gt + (el * 8 + q) * GS;
+#pragma unroll
+            for (int i = 0; i < NN; i++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    g[3 * i + a] = inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i];
+                    gt[3 * i + a] = inv[0][a] * dxi[i] + inv[1][a] * deta[i] + inv[2][a] * dzeta[i];
+                }
+            s_wd[el * 8 + q] = det * rule.w[q];
+        }
+    }
+    __syncthreads();
+    {
+#pragma clang fp contract(fast)
+        const int el = tid / NPAIR, p = tid - el * NPAIR;
+        const int64_t e = e0 + el;
+        if (el >= EPB || e >= E) return;
+        int ti = 0, rem = p;
+        while (rem >= NN - ti) { rem -= NN - ti; ti++; }
+        const int tj = ti + rem;
+        const double *pr = props + 37 * (int64_t)prop_id[e];
+        const int64_t ob = (e * NPAIR + p) * 9;
+        if (Ke) {
+            double C[6][6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) C[a][b] = 0.5 * (pr[a * 6 + b] + pr[b * 6 + a]);   // 0.5 (K + K^T) of SOLID.py:565
+            double K[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int q = 0; q < ng; q++) {
+                const double *gi = s_g + (el * 8 + q) * GS + 3 * ti, *gj = s_g + (el * 8 + q) * GS + 3 * tj;
+                const double ax = gi[0], ay = gi[1], az = gi[2], bx_ = gj[0], by_ = gj[1], bz_ = gj[2];
+                const double wd = s_wd[el * 8 + q];
+                // columns of C B_j: u -> (xx: bx, xy: by, zx: bz), v -> (yy: by, xy: bx, yz: bz), w -> (zz: bz, yz: by, zx: bx)
+                double cb[6][3];
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    cb[a][0] = C[a][0] * bx_ + C[a][3] * by_ + C[a][5] * bz_;
+                    cb[a][1] = C[a][1] * by_ + C[a][3] * bx_ + C[a][4] * bz_;
+                    cb[a][2] = C[a][2] * bz_ + C[a][4] * by_ + C[a][5] * bx_;
+                }
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    K[0][b] += (ax * cb[0][b] + ay * cb[3][b] + az * cb[5][b]) * wd;
+                    K[1][b] += (ay * cb[1][b] + ax * cb[3][b] + az * cb[4][b]) * wd;
+                    K[2][b] += (az * cb[2][b] + ay * cb[4][b] + ax * cb[5][b]) * wd;
+                }
+            }
+            if (ti == tj) {
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (K[a][b] + K[b][a]); K[a][b] = m; K[b][a] = m; }
+            }
+#pragma unroll
+            for (int c = 0; c < 9; c++) Ke[ob + c] = (&K[0][0])[c];
+        }
+        if (Me || fe) {
+            const double rho = pr[36];
+            double m = 0.0, f0 = 0.0;
+            for (int q = 0; q < ng; q++) {
+                double N[NN], d0[NN], d1[NN], d2[NN];
+                solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, d0, d1, d2);
+                double Ni = 0.0, Nj = 0.0;
+#pragma unroll
+                for (int i = 0; i < NN; i++) { Ni = (i == ti) ? N[i] : Ni; Nj = (i == tj) ? N[i] : Nj; }
+                const double wd = s_wd[el * 8 + q];
+                m += rho * (Ni * Nj) * wd;
+                double Np = 0.0;
+#pragma unroll
+                for (int i = 0; i < NN; i++) Np = (i == p) ? N[i] : Np;
+                f0 += Np * wd;
+            }
+            if (Me) {
+#pragma unroll
+                for (int c = 0; c < 9; c++) Me[ob + c] = (c == 0 || c == 4 || c == 8) ? m : 0.0;
+            }
+            if (fe && p < NN) {   // body_load: f_i = sum_q N_i b detJ w   (SOLID.py:599-631)
+                fe[e * GS + 3 * p + 0] = f0 * bx; fe[e * GS + 3 * p + 1] = f0 * by; fe[e * GS + 3 * p + 2] = f0 * bz;
+            }
+        }
+        if (KGe) {   // SOLID.py:322-374
+            const double *sg = sigma + e * 6;
+            const double S[3][3] = {{sg[0], sg[3], sg[5]}, {sg[3], sg[1], sg[4]}, {sg[5], sg[4], sg[2]}};
+            double gsum = 0.0;
+            for (int q = 0; q < ng; q++) {
+                const double *gi = s_gt + (el * 8 + q) * GS + 3 * ti, *gj = s_gt + (el * 8 + q) * GS + 3 * tj;
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) v += (gi[0] * S[0][a] + gi[1] * S[1][a] + gi[2] * S[2][a]) * gj[a];
+                gsum += v * s_wd[el * 8 + q];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; c++) KGe[ob + c] = (c == 0 || c == 4 || c == 8) ? gsum : 0.0;
+        }
+    }
+}
+
 // geometry probe for bit-exactness tests
 __global__ void mitc4_geom_kernel(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
                                   double *acoef) {
@@ -1497,6 +1690,84 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
                            props, E, Me);
         FS_LAUNCH_CHECK("mitc3_m_kernel");
     }
+    return FS_OK;
+}
+
+}  // extern "C" (reopened below)
+
+namespace {
+template <int NN>
+int launch_solid(const double *xyz, const int32_t *prop_id, const double *props, int64_t E, const SolidRule &rule,
+                 const double *b, const double *sigma, double *Ke, double *Me, double *fe, double *KGe,
+                 int32_t *status, hipStream_t s) {
+    constexpr int EPB = 256 / (NN * (NN + 1) / 2);
+    static_assert(EPB * 8 <= 256, "phase 1 needs one thread per (element, Gauss point)");
+    hipLaunchKernelGGL(solid_kernel<NN>, dim3(grid_for((E + EPB - 1) / EPB, 1, INT32_MAX)), dim3(256), 0, s, xyz,
+                       prop_id, props, E, rule, b[0], b[1], b[2], sigma, Ke, Me, fe, KGe, status);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t *prop_id, const double *props,
+                   int32_t n_props, int64_t E, uint32_t want, uint32_t layout, const double *body_host,
+                   const double *sigma, double *Ke, double *Me, double *fe, double *KGe, int32_t *status,
+                   void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_solid_batch: bad sizes");
+    if (nn != 4 && nn != 5 && nn != 6 && nn != 8)
+        return fail(FS_ENOSYS, "fs_solid_batch: only TETRA4 / PYRAMID5 / WEDGE6 / HEXA8 (nn = 4, 5, 6, 8)");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_solid_batch: null input");
+    if (layout != FS_LAYOUT_SYMBLK)
+        return fail(FS_EINVAL, "fs_solid_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
+    if ((want & FS_WANT_K) && !Ke) return fail(FS_EINVAL, "fs_solid_batch: Ke is null");
+    if ((want & FS_WANT_M) && !Me) return fail(FS_EINVAL, "fs_solid_batch: Me is null");
+    if ((want & FS_WANT_FBODY) && (!fe || !body_host)) return fail(FS_EINVAL, "fs_solid_batch: fe / body is null");
+    if ((want & FS_WANT_KG) && (!KGe || !sigma)) return fail(FS_EINVAL, "fs_solid_batch: KGe / sigma is null");
+    SolidRule rule;
+    memset(&rule, 0, sizeof rule);
+    const double gp = 0.57735026918962584;   // 1/np.sqrt(3)
+    if (nn == 8) {                            // SOLID.py:1744-1766
+        if (reduced) { rule.ng = 1; rule.w[0] = 8.0; }
+        else {
+            rule.ng = 8;
+            for (int q = 0; q < 8; q++) {
+                rule.pt[q][0] = (q & 1) ? gp : -gp; rule.pt[q][1] = (q & 2) ? gp : -gp; rule.pt[q][2] = (q & 4) ? gp : -gp;
+                rule.w[q] = 1.0;
+            }
+        }
+    } else if (nn == 4) {                     // SOLID.py:1575-1579
+        rule.ng = 1; rule.pt[0][0] = rule.pt[0][1] = rule.pt[0][2] = 0.25; rule.w[0] = 1.0 / 6;
+    } else if (nn == 6) {                     // SOLID.py:731-754 (weights sum to 2: reference quirk, kept)
+        const double tp[3][2] = {{1.0 / 6, 1.0 / 6}, {2.0 / 3, 1.0 / 6}, {1.0 / 6, 2.0 / 3}};
+        rule.ng = 6;
+        for (int q = 0; q < 6; q++) {
+            rule.pt[q][0] = tp[q / 2][0]; rule.pt[q][1] = tp[q / 2][1]; rule.pt[q][2] = (q & 1) ? gp : -gp;
+            rule.w[q] = (1.0 / 6) * 1.0 * 2;
+        }
+    } else {                                  // SOLID.py:1099-1127
+        const double a = 0.26318405556971359557, za = 0.54415184401122528880, wa = 0.10078588207982543059;
+        const double b = 0.50661630334978742377, zb = 0.12251482265544137787, wb = 0.23254745125350790274;
+        const double sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+        rule.ng = 8;
+        for (int q = 0; q < 4; q++) {
+            rule.pt[q][0] = sx[q] * a; rule.pt[q][1] = sy[q] * a; rule.pt[q][2] = za; rule.w[q] = wa;
+            rule.pt[4 + q][0] = sx[q] * b; rule.pt[4 + q][1] = sy[q] * b; rule.pt[4 + q][2] = zb; rule.w[4 + q] = wb;
+        }
+    }
+    const double zero3[3] = {0, 0, 0};
+    const double *b3 = (want & FS_WANT_FBODY) ? body_host : zero3;
+    double *k = (want & FS_WANT_K) ? Ke : nullptr, *m = (want & FS_WANT_M) ? Me : nullptr;
+    double *f = (want & FS_WANT_FBODY) ? fe : nullptr, *kg = (want & FS_WANT_KG) ? KGe : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    switch (nn) {
+        case 8: launch_solid<8>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
+        case 6: launch_solid<6>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
+        case 5: launch_solid<5>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
+        default: launch_solid<4>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
+    }
+    FS_LAUNCH_CHECK("solid_kernel");
     return FS_OK;
 }
 

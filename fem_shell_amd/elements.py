@@ -241,6 +241,77 @@ class MITC3Composite(MITC3):
         return laminate_row(self.laminate, self.nonlinear)
 
 
+class SolidElement(FemElement):
+    """Linear 3-D solids, 3 DOF/node (elements/SOLID.py:47-692): K, M, body_load and
+    compute_geometric_stiffness run through fs_solid_batch (batch of 1)."""
+
+    vector_form = {"U": ("Ux", "Uy", "Uz")}
+    _NN = 0
+
+    def __init__(self, name, node_coords, node_ids, material, orientation=None, reduced_integration=False):
+        super().__init__(name=name, node_coords=np.asarray(node_coords), node_ids=list(node_ids),
+                         material=material, dofs_per_node=3)
+        if len(node_ids) != self._NN:
+            raise ValueError(f"{name} requires {self._NN} nodes, got {len(node_ids)}")
+        self.element_family = ElementFamily.SOLID
+        self.orientation = orientation
+        self.reduced_integration = reduced_integration
+        if self.node_coords.shape[1] != 3:
+            raise ValueError(f"Solid elements require 3D coordinates, got shape {self.node_coords.shape}")
+
+    @property
+    def C(self) -> np.ndarray:
+        from .properties import solid_C
+        return solid_C(self.material, self.orientation)
+
+    def _run(self, **kw):
+        import torch
+        from . import batch
+        from .properties import solid_row
+        dev = batch._dev()
+        xyz = torch.from_numpy(np.ascontiguousarray(self.node_coords, dtype=np.float64)[None]).to(dev)
+        pid = torch.zeros(1, dtype=torch.int32, device=dev)
+        props = batch.to_device_solid_props(solid_row(self.material, self.orientation)[None])
+        if kw.get("sigma") is not None:
+            kw["sigma"] = torch.as_tensor(np.asarray(kw["sigma"], dtype=np.float64).reshape(1, 6), device=dev)
+        out = batch.solid_batch(self._NN, xyz, pid, props, 1, dense=True,
+                                reduced=bool(self.reduced_integration) and self._NN == 8, **kw)
+        if int(out["status"][0]):
+            raise ValueError(f"Non-positive Jacobian determinant in {self.name} element")
+        return out
+
+    @cached_property
+    def K(self) -> np.ndarray:
+        """elements/SOLID.py:543-567."""
+        return np.ascontiguousarray(self._run(want_K=True)["K"][0].cpu().numpy())
+
+    @cached_property
+    def M(self) -> np.ndarray:
+        """elements/SOLID.py:569-597."""
+        return np.ascontiguousarray(self._run(want_K=False, want_M=True)["M"][0].cpu().numpy())
+
+    def body_load(self, body_force) -> np.ndarray:
+        """elements/SOLID.py:599-631."""
+        return np.ascontiguousarray(self._run(want_K=False, body=np.asarray(body_force)[:3])["f"][0].cpu().numpy())
+
+    def compute_geometric_stiffness(self, sigma_membrane, transform_to_global=True) -> np.ndarray:
+        """elements/SOLID.py:322-374 (Voigt stress xx,yy,zz,xy,yz,zx in global axes)."""
+        return np.ascontiguousarray(self._run(want_K=False, sigma=sigma_membrane)["KG"][0].cpu().numpy())
+
+
+def _solid_class(name, nn, doc):
+    def __init__(self, node_coords, node_ids, material, orientation=None, reduced_integration=False):
+        SolidElement.__init__(self, name, node_coords, node_ids, material, orientation,
+                              reduced_integration if nn == 8 else False)
+    return type(name, (SolidElement,), {"__init__": __init__, "_NN": nn, "__doc__": doc})
+
+
+TETRA4 = _solid_class("TETRA4", 4, "4-node tetrahedron, 1-point rule (elements/SOLID.py:1545-1597).")
+PYRAMID5 = _solid_class("PYRAMID5", 5, "5-node pyramid, Felippa 8-point rule (elements/SOLID.py:1067-1218).")
+WEDGE6 = _solid_class("WEDGE6", 6, "6-node wedge, 3x2 rule with the reference's x2 weights (elements/SOLID.py:700-829).")
+HEXA8 = _solid_class("HEXA8", 8, "8-node brick, 2x2x2 (or 1-point reduced) rule (elements/SOLID.py:1716-1818).")
+
+
 class ElementFactory:
     """elements/elements.py:107-259: dispatch by family x node count x composite."""
 
@@ -265,6 +336,12 @@ class ElementFactory:
                     return shell_composite_map[node_count](node_coords=node_coords, node_ids=node_ids,
                                                            laminate=laminate, **kwargs)
                 return shell_map[node_count](node_coords=node_coords, node_ids=node_ids, **kwargs)
+            if element_family == ElementFamily.SOLID:
+                if node_count in (10, 13, 15, 20):
+                    raise NotImplementedError(f"quadratic solid with {node_count} nodes is not on the GPU path")
+                solid_map = {4: TETRA4, 5: PYRAMID5, 6: WEDGE6, 8: HEXA8}
+                kwargs.pop("thickness", None)
+                return solid_map[node_count](node_coords=node_coords, node_ids=node_ids, **kwargs)
             raise NotImplementedError(f"Element family {element_family} not implemented")
         except KeyError:
             return False

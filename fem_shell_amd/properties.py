@@ -116,3 +116,51 @@ def build_prop_table(props: Sequence, nonlinear: bool = False,
     for i, p in enumerate(props):
         out[i] = prop_row(p, nonlinear, shear_correction_factor)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# solids: rows of [C (36, global axes), rho]  (fs_solid_batch)
+# ---------------------------------------------------------------------------------------------
+_VOIGT = ((0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (2, 0))     # xx, yy, zz, xy, yz, zx
+
+
+def solid_C(material, orientation=None) -> np.ndarray:
+    """6x6 constitutive matrix of a solid element in global axes (elements/SOLID.py:377-541):
+    isotropic Lame form, or orthotropic inv(S) rotated as T C T^T with the Voigt stress
+    transformation T of the 3x3 `orientation`."""
+    if isinstance(material, IsotropicMaterial):
+        E, nu = material.E, material.nu
+        lambd = E * nu / ((1 + nu) * (1 - 2 * nu))
+        mu = E / (2 * (1 + nu))
+        C = np.zeros((6, 6))
+        C[:3, :3] = lambd
+        C[np.arange(3), np.arange(3)] = lambd + 2 * mu
+        C[np.arange(3, 6), np.arange(3, 6)] = mu
+        return C
+    if not isinstance(material, OrthotropicMaterial):
+        raise TypeError(f"Unsupported material type: {type(material)}")
+    E1, E2, E3 = material.E
+    G12, G23, G31 = material.G
+    nu12, nu23, nu31 = material.nu
+    nu21, nu32, nu13 = nu12 * E2 / E1, nu23 * E3 / E2, nu31 * E1 / E3
+    S = np.zeros((6, 6))
+    S[0, :3] = (1 / E1, -nu21 / E2, -nu31 / E3)
+    S[1, :3] = (-nu12 / E1, 1 / E2, -nu32 / E3)
+    S[2, :3] = (-nu13 / E1, -nu23 / E2, 1 / E3)
+    S[3, 3], S[4, 4], S[5, 5] = 1 / G12, 1 / G23, 1 / G31
+    C = np.linalg.inv(S)
+    if orientation is None:
+        return C
+    r = np.asarray(orientation, dtype=float)
+    T = np.empty((6, 6))
+    for I, (i, j) in enumerate(_VOIGT):
+        for J, (k, l) in enumerate(_VOIGT):
+            if J < 3:
+                T[I, J] = r[i, k] ** 2 if I < 3 else r[i, k] * r[j, k]
+            else:
+                T[I, J] = 2 * r[i, k] * r[i, l] if I < 3 else r[i, k] * r[j, l] + r[i, l] * r[j, k]
+    return T @ C @ T.T
+
+
+def solid_row(material, orientation=None) -> np.ndarray:
+    return np.concatenate([solid_C(material, orientation).ravel(), [float(material.rho)]])

@@ -192,11 +192,25 @@ def dofs_list_iter(dofs_list, sizes):
 
 def vector_plan(conn, n_nodes, d):
     """Segmented gather plan for vectors (f_int, load vectors): for DOF r the entries
-    src[seg_ptr[r]:seg_ptr[r+1]] index the flattened [E, nn*d] element vectors, element order
-    (== the reference's setValuesLocal insertion order, core/assembler.py:369-381)."""
-    conn = np.ascontiguousarray(conn, dtype=np.int64)
-    E, nn = conn.shape
-    dofs = (conn[:, :, None] * d + np.arange(d, dtype=np.int64)).reshape(-1)
-    order = np.argsort(dofs, kind="stable").astype(np.int64)
+    src[seg_ptr[r]:seg_ptr[r+1]] index the element vectors ([E_g, nn*d] per group, the groups'
+    buffers back to back), in element order (== the reference's setValuesLocal insertion order,
+    core/assembler.py:369-381)."""
+    groups = split_groups(conn)
+    dofs_l, src_l, ord_l = [], [], []
+    off = 0
+    for nn, pos, cg in groups:
+        Eg = cg.shape[0]
+        dofs_l.append((cg[:, :, None] * d + np.arange(d, dtype=np.int64)).reshape(-1))
+        src_l.append(off + np.arange(Eg * nn * d, dtype=np.int64))
+        ord_l.append(np.repeat(pos if pos is not None else np.arange(Eg, dtype=np.int64), nn * d))
+        off += Eg * nn * d
+    if len(groups) == 1:
+        dofs = dofs_l[0]
+        order = np.argsort(dofs, kind="stable").astype(np.int64)
+        src = order
+    else:
+        dofs = np.concatenate(dofs_l)
+        order = np.lexsort((np.concatenate(ord_l), dofs))
+        src = np.concatenate(src_l)[order]
     seg_ptr = np.searchsorted(dofs[order], np.arange(n_nodes * d + 1), side="left").astype(np.int64)
-    return seg_ptr, order
+    return seg_ptr, src

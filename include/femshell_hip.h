@@ -33,6 +33,8 @@ extern "C" {
 #define FS_WANT_M 2u
 #define FS_WANT_KT 4u
 #define FS_WANT_FINT 8u
+#define FS_WANT_FBODY 16u /* solids: body-load vectors */
+#define FS_WANT_KG 32u    /* solids: geometric stiffness from a per-element stress */
 
 /* element-matrix layouts */
 #define FS_LAYOUT_DENSE 0u  /* [E][nd][nd] C-order == reference `_ke_array` (core/assembler.py:213-215) */
@@ -100,6 +102,26 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
                        int32_t n_props, const double *u_e, int64_t E, uint32_t want,
                        uint32_t layout, double *Ke, double *Me, double *KTe, double *fe,
                        int32_t *status, void *stream);
+
+/*
+ * Linear solids, 3 dofs/node: nn = 4 TETRA4, 5 PYRAMID5, 6 WEDGE6, 8 HEXA8 (elements/SOLID.py).
+ * Replaces, per element, SolidElement._compute_jacobian / compute_B_matrix (:164-266), K (:543-567),
+ * M (:569-597), body_load (:599-631), compute_geometric_stiffness (:322-374) with the quadrature
+ * rules and shape functions of the concrete classes (:731-829, :1099-1218, :1575-1597, :1744-1818;
+ * `reduced` != 0 selects HEXA8's 1-point rule).  Reference quirks kept: WEDGE6 weights sum to 2;
+ * K_G uses inv_J.T where B uses inv_J.
+ *   xyz     [E][nn][3]
+ *   props   [n_props][37]  C (6x6, global axes, Voigt xx,yy,zz,xy,yz,zx; SOLID.py:377-541 evaluated
+ *                          on the host by fem_shell_amd.properties.solid_row) followed by rho
+ *   body_host  3 doubles in HOST memory (FS_WANT_FBODY);  sigma [E][6] device (FS_WANT_KG)
+ *   Ke/Me/KGe  FS_LAYOUT_SYMBLK with d = 3: [E][nn(nn+1)/2][9];  fe [E][3 nn]
+ *   status  FS_ST_BAD_JAC where the reference raises ValueError (det J <= 1e-14); must be zeroed
+ *           by the caller (bits are OR-ed in).
+ */
+int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t *prop_id,
+                   const double *props, int32_t n_props, int64_t E, uint32_t want, uint32_t layout,
+                   const double *body_host, const double *sigma, double *Ke, double *Me, double *fe,
+                   double *KGe, int32_t *status, void *stream);
 
 /* Geometry stage only, for bit-exactness tests against the oracle:
  * frame[E][9] (e1,e2,e3), xl[E][8], detJ[E][4], acoef[E][5] (a_A..a_E). */

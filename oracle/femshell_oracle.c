@@ -978,3 +978,189 @@ int fso_mitc3_batch(const double *xyz, const int32_t *prop_id, const fso_shell_p
     }
     return 0;
 }
+
+/* ====================================================================================
+ * Linear solids (elements/SOLID.py): TETRA4, PYRAMID5, WEDGE6, HEXA8.  type == node count.
+ * ==================================================================================== */
+static int solid_rule(int nn, int reduced, double pts[][3], double *w) {
+    const double gp = 1.0 / sqrt(3.0);
+    if (nn == 8) { /* SOLID.py:1744-1766: order k-j-i, weights 1; reduced: 1 point, w = 8 */
+        if (reduced) { pts[0][0] = pts[0][1] = pts[0][2] = 0.0; w[0] = 8.0; return 1; }
+        int n = 0;
+        for (int k = 0; k < 2; k++)
+            for (int j = 0; j < 2; j++)
+                for (int i = 0; i < 2; i++) {
+                    pts[n][0] = i ? gp : -gp; pts[n][1] = j ? gp : -gp; pts[n][2] = k ? gp : -gp;
+                    w[n++] = 1.0;
+                }
+        return 8;
+    }
+    if (nn == 4) { pts[0][0] = pts[0][1] = pts[0][2] = 0.25; w[0] = 1.0 / 6.0; return 1; } /* :1575-1579 */
+    if (nn == 6) { /* SOLID.py:731-754: tri_w * lin_w * 2 (the documented x2 quirk) */
+        const double tp[3][2] = {{1.0 / 6, 1.0 / 6}, {2.0 / 3, 1.0 / 6}, {1.0 / 6, 2.0 / 3}};
+        int n = 0;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 2; j++) {
+                pts[n][0] = tp[i][0]; pts[n][1] = tp[i][1]; pts[n][2] = j ? gp : -gp;
+                w[n++] = (1.0 / 6) * 1.0 * 2;
+            }
+        return 6;
+    }
+    if (nn == 5) { /* SOLID.py:1099-1127 Felippa 8-point */
+        const double a = 0.26318405556971359557, za = 0.54415184401122528880, wa = 0.10078588207982543059;
+        const double b = 0.50661630334978742377, zb = 0.12251482265544137787, wb = 0.23254745125350790274;
+        const double sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+        for (int q = 0; q < 4; q++) {
+            pts[q][0] = sx[q] * a; pts[q][1] = sy[q] * a; pts[q][2] = za; w[q] = wa;
+            pts[4 + q][0] = sx[q] * b; pts[4 + q][1] = sy[q] * b; pts[4 + q][2] = zb; w[4 + q] = wb;
+        }
+        return 8;
+    }
+    return -1;
+}
+
+static void solid_shape(int nn, double xi, double eta, double zeta, double *N, double *dxi, double *deta,
+                        double *dzeta) {
+    if (nn == 8) { /* SOLID.py:1768-1818 */
+        const double sx[8] = {-1, 1, 1, -1, -1, 1, 1, -1}, sy[8] = {-1, -1, 1, 1, -1, -1, 1, 1},
+                     sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+        for (int i = 0; i < 8; i++) {
+            double fx = 1 + sx[i] * xi, fy = 1 + sy[i] * eta, fz = 1 + sz[i] * zeta;
+            N[i] = 0.125 * (fx * fy * fz);
+            dxi[i] = 0.125 * (sx[i] * fy * fz); deta[i] = 0.125 * (sy[i] * fx * fz); dzeta[i] = 0.125 * (sz[i] * fx * fy);
+        }
+    } else if (nn == 4) { /* :1581-1597 */
+        N[0] = 1 - xi - eta - zeta; N[1] = xi; N[2] = eta; N[3] = zeta;
+        const double a[4] = {-1, 1, 0, 0}, b[4] = {-1, 0, 1, 0}, c[4] = {-1, 0, 0, 1};
+        for (int i = 0; i < 4; i++) { dxi[i] = a[i]; deta[i] = b[i]; dzeta[i] = c[i]; }
+    } else if (nn == 6) { /* :756-829 */
+        double L[3] = {1 - xi - eta, xi, eta}, Lm = 0.5 * (1 - zeta), Lp = 0.5 * (1 + zeta);
+        const double dLx[3] = {-1, 1, 0}, dLe[3] = {-1, 0, 1};
+        for (int i = 0; i < 3; i++) {
+            N[i] = L[i] * Lm; N[3 + i] = L[i] * Lp;
+            dxi[i] = dLx[i] * Lm; dxi[3 + i] = dLx[i] * Lp;
+            deta[i] = dLe[i] * Lm; deta[3 + i] = dLe[i] * Lp;
+            dzeta[i] = L[i] * -0.5; dzeta[3 + i] = L[i] * 0.5;
+        }
+    } else { /* PYRAMID5 :1129-1218 */
+        double r = 1 - zeta; if (r < 1e-14) r = 1e-14;
+        double r2 = r * r, rmx = r - xi, rpx = r + xi, rme = r - eta, rpe = r + eta;
+        N[0] = 0.25 * rmx * rme / r; N[1] = 0.25 * rpx * rme / r; N[2] = 0.25 * rpx * rpe / r; N[3] = 0.25 * rmx * rpe / r; N[4] = zeta;
+        dxi[0] = -0.25 * rme / r; dxi[1] = 0.25 * rme / r; dxi[2] = 0.25 * rpe / r; dxi[3] = -0.25 * rpe / r; dxi[4] = 0;
+        deta[0] = -0.25 * rmx / r; deta[1] = -0.25 * rpx / r; deta[2] = 0.25 * rpx / r; deta[3] = 0.25 * rmx / r; deta[4] = 0;
+        dzeta[0] = -0.25 * (rme + rmx) / r + 0.25 * rmx * rme / r2;
+        dzeta[1] = -0.25 * (rme + rpx) / r + 0.25 * rpx * rme / r2;
+        dzeta[2] = -0.25 * (rpe + rpx) / r + 0.25 * rpx * rpe / r2;
+        dzeta[3] = -0.25 * (rpe + rmx) / r + 0.25 * rmx * rpe / r2;
+        dzeta[4] = 1.0;
+    }
+}
+
+/* J, det, gradients (SOLID.py:164-216, 242-248). returns 0, or 4 (FS_ST_BAD_JAC) if det <= 1e-14 */
+static int solid_grad(int nn, const double *xyz, const double *dxi, const double *deta, const double *dzeta,
+                      double *detJ, double g[][3], double gT[][3]) {
+    double J[3][3] = {{0}};
+    for (int c = 0; c < 3; c++)
+        for (int i = 0; i < nn; i++) {
+            J[0][c] += dxi[i] * xyz[3 * i + c]; J[1][c] += deta[i] * xyz[3 * i + c]; J[2][c] += dzeta[i] * xyz[3 * i + c];
+        }
+    double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                 J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+    *detJ = det;
+    double inv[3][3];
+    inv[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det; inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+    inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det; inv[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+    inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det; inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+    inv[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det; inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+    inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    for (int i = 0; i < nn; i++)
+        for (int a = 0; a < 3; a++) {
+            g[i][a] = inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i];
+            /* quirk: compute_geometric_stiffness uses inv_J.T @ dN_local (SOLID.py:352-354) */
+            gT[i][a] = inv[0][a] * dxi[i] + inv[1][a] * deta[i] + inv[2][a] * dzeta[i];
+        }
+    return (det <= 1e-14) ? 4 : 0;
+}
+
+/* K, M, body load, geometric stiffness of one solid element; any output may be NULL.
+ * C[36] constitutive (global axes), rho, b[3] body force, sigma[6] Voigt stress (xx,yy,zz,xy,yz,zx).
+ * SOLID.py:543-567 (K), :569-597 (M), :599-631 (body_load), :322-374 (K_G). */
+int fso_solid(int nn, int reduced, const double *xyz, const double *C, double rho, const double *b,
+              const double *sigma, double *Ke, double *Me, double *fe, double *KGe) {
+    double pts[8][3], w[8];
+    int ng = solid_rule(nn, reduced, pts, w), nd = 3 * nn, status = 0;
+    if (ng < 0) return -1;
+    if (Ke) memset(Ke, 0, sizeof(double) * nd * nd);
+    if (Me) memset(Me, 0, sizeof(double) * nd * nd);
+    if (fe) memset(fe, 0, sizeof(double) * nd);
+    if (KGe) memset(KGe, 0, sizeof(double) * nd * nd);
+    for (int q = 0; q < ng; q++) {
+        double N[8], dxi[8], deta[8], dzeta[8], g[8][3], gT[8][3], det;
+        solid_shape(nn, pts[q][0], pts[q][1], pts[q][2], N, dxi, deta, dzeta);
+        status |= solid_grad(nn, xyz, dxi, deta, dzeta, &det, g, gT);
+        if (Ke) {
+            double B[6][24];
+            memset(B, 0, sizeof B);
+            for (int i = 0; i < nn; i++) {
+                B[0][3 * i] = g[i][0]; B[1][3 * i + 1] = g[i][1]; B[2][3 * i + 2] = g[i][2];
+                B[3][3 * i] = g[i][1]; B[3][3 * i + 1] = g[i][0];
+                B[4][3 * i + 1] = g[i][2]; B[4][3 * i + 2] = g[i][1];
+                B[5][3 * i] = g[i][2]; B[5][3 * i + 2] = g[i][0];
+            }
+            for (int r = 0; r < nd; r++) {
+                double t6[6];
+                for (int c = 0; c < 6; c++) {
+                    double s = 0;
+                    for (int a = 0; a < 6; a++) s += B[a][r] * C[a * 6 + c];
+                    t6[c] = s;
+                }
+                for (int c = 0; c < nd; c++) {
+                    double s = 0;
+                    for (int a = 0; a < 6; a++) s += t6[a] * B[a][c];
+                    Ke[r * nd + c] += s * det * w[q];
+                }
+            }
+        }
+        for (int i = 0; i < nn; i++) {
+            if (fe) for (int k = 0; k < 3; k++) fe[3 * i + k] += (N[i] * b[k]) * det * w[q];
+            for (int j = 0; j < nn; j++) {
+                if (Me) for (int k = 0; k < 3; k++) Me[(3 * i + k) * nd + 3 * j + k] += rho * (N[i] * N[j]) * det * w[q];
+                if (KGe) {
+                    const double S[3][3] = {{sigma[0], sigma[3], sigma[5]}, {sigma[3], sigma[1], sigma[4]}, {sigma[5], sigma[4], sigma[2]}};
+                    double gv = 0;
+                    for (int a = 0; a < 3; a++) {
+                        double t = 0;
+                        for (int c = 0; c < 3; c++) t += gT[i][c] * S[c][a];
+                        gv += t * gT[j][a];
+                    }
+                    for (int k = 0; k < 3; k++) KGe[(3 * i + k) * nd + 3 * j + k] += gv * (w[q] * det);
+                }
+            }
+        }
+    }
+    if (Ke)
+        for (int r = 0; r < nd; r++)
+            for (int c = r + 1; c < nd; c++) { double m = 0.5 * (Ke[r * nd + c] + Ke[c * nd + r]); Ke[r * nd + c] = Ke[c * nd + r] = m; }
+    if (Me)
+        for (int r = 0; r < nd; r++)
+            for (int c = r + 1; c < nd; c++) { double m = 0.5 * (Me[r * nd + c] + Me[c * nd + r]); Me[r * nd + c] = Me[c * nd + r] = m; }
+    return status;
+}
+
+int fso_solid_batch(int nn, int reduced, const double *xyz, const int32_t *prop_id, const double *props /* [P][37]: C, rho */,
+                    const double *b, const double *sigma /* [E][6] or NULL */, int64_t E, double *Ke, double *Me,
+                    double *fe, double *KGe, int32_t *status, int nthreads) {
+    const int nd = 3 * nn;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t e = 0; e < E; e++) {
+        const double *p = props + 37 * prop_id[e];
+        int s = fso_solid(nn, reduced, xyz + 3 * nn * e, p, p[36], b, sigma ? sigma + 6 * e : NULL,
+                          Ke ? Ke + (int64_t)nd * nd * e : NULL, Me ? Me + (int64_t)nd * nd * e : NULL,
+                          fe ? fe + (int64_t)nd * e : NULL, (KGe && sigma) ? KGe + (int64_t)nd * nd * e : NULL);
+        if (status) status[e] = s;
+    }
+    return 0;
+}

@@ -96,6 +96,26 @@ def mitc3_batch(xyz, prop_id, props, want_K=True, want_M=False, nthreads=1):
     return Ke, Me, st
 
 
+def solid_batch(nn, xyz, prop_id, props, want_K=True, want_M=False, body=None, sigma=None,
+                reduced=False, nthreads=1):
+    """Linear solids (nn = 4 TETRA4, 5 PYRAMID5, 6 WEDGE6, 8 HEXA8). props: [P,37] = C.ravel(), rho.
+    Returns dict K, M, f (body load), KG (geometric stiffness from sigma [E,6]), status."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, nn, 3)
+    E, nd = xyz.shape[0], 3 * nn
+    prop_id = np.ascontiguousarray(prop_id, dtype=np.int32).reshape(E)
+    props = np.ascontiguousarray(props, dtype=np.float64).reshape(-1, 37)
+    K = np.empty((E, nd, nd)) if want_K else None
+    M = np.empty((E, nd, nd)) if want_M else None
+    f = np.empty((E, nd)) if body is not None else None
+    b = np.ascontiguousarray(body if body is not None else np.zeros(3), dtype=np.float64)
+    sg = np.ascontiguousarray(sigma, dtype=np.float64).reshape(E, 6) if sigma is not None else None
+    KG = np.empty((E, nd, nd)) if sigma is not None else None
+    st = np.zeros(E, dtype=np.int32)
+    lib().fso_solid_batch(ctypes.c_int(nn), ctypes.c_int(int(reduced)), _p(xyz), _p(prop_id), _p(props), _p(b),
+                          _p(sg), ctypes.c_int64(E), _p(K), _p(M), _p(f), _p(KG), _p(st), ctypes.c_int(nthreads))
+    return dict(K=K, M=M, f=f, KG=KG, status=st)
+
+
 def mitc4_NL(xyz, prop, u):
     xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(4, 3)
     prop = as_props(prop).reshape(-1)[:1]

@@ -197,3 +197,78 @@ def test_mitc3_element_classes(oracle):
     view = meshes.ArrayMesh(xyz, np.array([[0, 1, 2]])).elements[0]
     made = ElementFactory.get_element(ElementFamily.SHELL, view, shell_property=fsa.CompositeShellProperty(lam))
     assert type(made).__name__ == "MITC3Composite"
+
+
+def _hex_block(nx, ny, nz, jitter=0.08, seed=4):
+    ids = np.arange((nx + 1) * (ny + 1) * (nz + 1)).reshape(nz + 1, ny + 1, nx + 1)
+    Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
+    coords = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    coords += jitter * np.random.default_rng(seed).uniform(-1, 1, coords.shape)
+    n = lambda dz, dy, dx: ids[dz:nz + dz, dy:ny + dy, dx:nx + dx]
+    hexa = np.stack([n(0, 0, 0), n(0, 0, 1), n(0, 1, 1), n(0, 1, 0), n(1, 0, 0), n(1, 0, 1), n(1, 1, 1), n(1, 1, 0)], -1)
+    return coords, hexa.reshape(-1, 8)
+
+
+@pytest.mark.parametrize("case", ["hexa", "mixed_solid"])
+def test_assembled_solids(case, oracle):
+    """SOLID family: K, M, body-load vector and geometric stiffness; 'mixed_solid' splits some
+    bricks into 2 wedges or 6 tets... (here: wedges + pyramids/tets around them) so that all four
+    linear solids meet in one mesh (tests/test_mixed_solid_elements.py of the reference)."""
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.properties import solid_row
+    coords, hexa = _hex_block(4, 3, 3)
+    if case == "hexa":
+        conn = hexa
+        mat = fsa.IsotropicMaterial("steel", 2.1e11, 0.3, 7800.0)
+        model = {"elements": {"element_family": ElementFamily.SOLID, "material": mat}}
+    else:
+        rows = []
+        for k, h in enumerate(hexa):
+            if k % 3 == 0:
+                rows.append(list(h))
+            elif k % 3 == 1:      # two wedges: triangles (0,1,2)/(4,5,6) and (0,2,3)/(4,6,7)
+                rows.append([h[0], h[1], h[2], h[4], h[5], h[6], -1, -1])
+                rows.append([h[0], h[2], h[3], h[4], h[6], h[7], -1, -1])
+            else:                 # pyramid on the bottom face with apex 6 + two tets filling the rest... keep it
+                rows.append([h[0], h[1], h[2], h[3], h[6], -1, -1, -1])      # simple: base 0123, apex 6
+                rows.append([h[0], h[1], h[6], h[5], -1, -1, -1, -1])        # tets (orientation checked below)
+                rows.append([h[0], h[5], h[6], h[4], -1, -1, -1, -1])
+        conn = np.array(rows, dtype=np.int64)
+        R = np.linalg.qr(np.random.default_rng(1).standard_normal((3, 3)))[0]
+        mat = util.t300()
+        model = {"elements": {"element_family": ElementFamily.SOLID, "material": mat, "orientation": R}}
+    mesh = meshes.ArrayMesh(coords, conn)
+    asm = MeshAssembler(mesh, model)
+    assert asm.dofs_per_node == 3 and asm.dofs_count == 3 * mesh.node_count
+    props = solid_row(mat, model["elements"].get("orientation"))[None]
+    body = np.array([0.3, -1.0, -9.81])
+    sig = np.random.default_rng(3).standard_normal((conn.shape[0], 6)) * 1e5
+    sig[2] = 0.0
+    dofs_list, mats = [], {"K": [], "M": [], "KG": []}
+    f_ref = np.zeros(asm.dofs_count)
+    for e in range(conn.shape[0]):
+        row = conn[e][conn[e] >= 0]
+        o = oracle.solid_batch(len(row), coords[row][None], [0], props, want_K=True, want_M=True, body=body,
+                               sigma=sig[e:e + 1])
+        assert o["status"][0] == 0, (e, len(row))
+        d = (row[:, None] * 3 + np.arange(3)).reshape(-1)
+        dofs_list.append(d)
+        for k in mats:
+            mats[k].append(o[k][0])
+        f_ref[d] += o["f"][0]
+    got = {"K": asm.assemble_stiffness_matrix(), "M": asm.assemble_mass_matrix(),
+           "KG": asm.assemble_geometric_stiffness(stress_field={int(e): sig[e] for e in range(conn.shape[0])})}
+    for k, A in got.items():
+        ip, ix, data = oracle.csr_assemble_mixed(dofs_list, asm.dofs_count, mats[k])
+        assert np.array_equal(A.indptr.cpu().numpy(), ip) and np.array_equal(A.indices.cpu().numpy(), ix)
+        err = np.abs(A.data.cpu().numpy() - data).max() / np.abs(data).max()
+        print(case, k, "nnz", A.nnz, "rel err", err)
+        assert err < 1e-12
+    f = asm.assemble_load_vector(type("LC", (), {"value": body})()).cpu().numpy()
+    assert np.abs(f - f_ref).max() < 1e-12 * np.abs(f_ref).max()
+    el = asm._element_map[1]
+    assert np.abs(el.K - mats["K"][1]).max() < 1e-12 * np.abs(mats["K"][1]).max()
+    assert np.abs(el.body_load(body) - oracle.solid_batch(el.node_count, coords[conn[1][conn[1] >= 0]][None], [0], props,
+                                                          want_K=False, body=body)["f"][0]).max() < 1e-9
+    with pytest.raises(ValueError):
+        asm.assemble_geometric_stiffness()

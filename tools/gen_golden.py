@@ -178,6 +178,47 @@ def gen_elem_mitc3():
     print("elem_mitc3.npz", N)
 
 
+SOLID_REF = {
+    8: np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float),
+    4: np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float),
+    6: np.array([[0, 0, -1], [1, 0, -1], [0, 1, -1], [0, 0, 1], [1, 0, 1], [0, 1, 1]], float),
+    5: np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [0, 0, 1]], float),
+}
+
+
+def gen_elem_solid():
+    """HEXA8 / TETRA4 / WEDGE6 / PYRAMID5: K, M, body_load, geometric stiffness
+    (elements/SOLID.py:322-374, 543-631) for isotropic, orthotropic and rotated-orthotropic C."""
+    from fem_shell.elements.SOLID import HEXA8, PYRAMID5, TETRA4, WEDGE6
+    cls = {8: HEXA8, 4: TETRA4, 6: WEDGE6, 5: PYRAMID5}
+    rng = np.random.default_rng(8)
+    out = {}
+    body = np.array([1.0, -2.0, 9.81])
+    for nn in (8, 4, 6, 5):
+        n = 24
+        xyz, props, K, M, F, KG, sig, red = [], [], [], [], [], [], [], []
+        for t in range(n):
+            x = SOLID_REF[nn].copy() if t == 0 else SOLID_REF[nn] + 0.15 * rng.standard_normal((nn, 3))
+            x = x * rng.choice([1.0, 1e-2, 30.0]) + (rng.choice([0.0, 5.0]) * rng.standard_normal(3) if t else 0.0)
+            if t % 3 == 2:
+                mat = t300()
+                ori = np.linalg.qr(rng.standard_normal((3, 3)))[0] if t % 2 else None
+            else:
+                E, nu, rho = ISO[t % len(ISO)]
+                mat, ori = IsotropicMaterial("m", E, nu, rho), None
+            kw = {"reduced_integration": True} if (nn == 8 and t % 4 == 1) else {}
+            el = cls[nn](x, tuple(range(nn)), mat, orientation=ori, **kw)
+            sg = rng.standard_normal(6) * 1e6
+            xyz.append(x); props.append(np.concatenate([el.C.ravel(), [mat.rho]]))
+            K.append(el.K); M.append(el.M); F.append(el.body_load(body))
+            KG.append(el.compute_geometric_stiffness(sg)); sig.append(sg); red.append(bool(kw))
+        out.update({f"xyz{nn}": np.array(xyz), f"props{nn}": np.array(props), f"K{nn}": np.array(K),
+                    f"M{nn}": np.array(M), f"F{nn}": np.array(F), f"KG{nn}": np.array(KG),
+                    f"sigma{nn}": np.array(sig), f"reduced{nn}": np.array(red)})
+    np.savez_compressed(os.path.join(OUT, "elem_solid.npz"), body=body, **out)
+    print("elem_solid.npz")
+
+
 def gen_elem_nl():
     rng = np.random.default_rng(5)
     N = 24
@@ -286,5 +327,6 @@ if __name__ == "__main__":
     gen_elem_mitc4()
     gen_elem_nl()
     gen_elem_mitc3()
+    gen_elem_solid()
     gen_laminate()
     gen_scordelis(16)
