@@ -187,9 +187,9 @@ def main():
                  "flop_per_element": flop,
                  "note": "fp64 VALU kernel priced against the fp64 peak (vector == matrix peak on "
                          f"MI355X); HBM view of the same launch: {k_gbs:.0f} GB/s of {PEAK_HBM_GBS:.0f}"}
-        a_obj = {"kernel": "csr_numeric_desc2_kernel<6>", "kernel_ms": a_ms, "bound": "hbm",
+        a_obj = {"kernel": "csr_numeric_desc6_lds_kernel", "kernel_ms": a_ms, "bound": "hbm",
                  "achieved": a_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBS,
-                 "traffic": pmc.get("csr_numeric_desc2_kernel", {}).get("hbm_bytes_per_launch"),
+                 "traffic": pmc.get("csr_numeric_desc6_lds_kernel", {}).get("hbm_bytes_per_launch"),
                  "bytes_per_element": a_bytes}
         dominant, other = (k_obj, a_obj) if k_ms >= a_ms else (a_obj, k_obj)
         line = {

@@ -28,6 +28,7 @@ SIGNATURES = {
     "fs_vec_gather_sum": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fs_csr_numeric_blk": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_numeric_desc": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "fs_csr_numeric_sym": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_pattern_blk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "fs_halo_pack": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),

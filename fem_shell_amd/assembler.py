@@ -90,6 +90,7 @@ class _LazyElementMap:
 
 class MeshAssembler:
     use_descriptors = True   # fs_csr_numeric_desc (False: fs_csr_numeric_blk, same result)
+    use_symmetric = False    # fs_csr_numeric_sym: each source block read once (same result)
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
@@ -240,6 +241,9 @@ class MeshAssembler:
         self._plan_d = {k: torch.from_numpy(getattr(p, k)).to(dev)
                         for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
         self._desc_d = torch.from_numpy(p.descriptors().view(np.uint8).reshape(-1)).to(dev)
+        sd = p.sym_descriptors()
+        self._n_sym = sd.shape[0]
+        self._sdesc_d = torch.from_numpy(sd.view(np.uint8).reshape(-1)).to(dev)
         self.refresh_element_matrices()
 
     def _group_view(self, buf, g):
@@ -347,7 +351,11 @@ class MeshAssembler:
     def _assemble(self, blk):
         lib, p, d = _lib.load(), self._plan, self._plan_d
         data = torch.empty(p.nnz, dtype=torch.float64, device=self.device)
-        if self.use_descriptors:
+        if self.use_symmetric and self.use_descriptors:
+            _lib.check(lib.fs_csr_numeric_sym(_lib.ptr(blk), _lib.ptr(self._sdesc_d), _lib.ptr(d["contrib"]),
+                                              self._n_sym, p.d, _lib.ptr(data), _lib.stream_ptr()),
+                       "fs_csr_numeric_sym")
+        elif self.use_descriptors:
             _lib.check(lib.fs_csr_numeric_desc(_lib.ptr(blk), _lib.ptr(self._desc_d), _lib.ptr(d["contrib"]),
                                                p.nblk, p.d, _lib.ptr(data), _lib.stream_ptr()),
                        "fs_csr_numeric_desc")

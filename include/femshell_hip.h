@@ -172,6 +172,23 @@ typedef struct fs_blk_desc {
 int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64_t *contrib,
                         int64_t nblk, int32_t d, double *data, void *stream);
 
+/* Symmetric form of fs_csr_numeric_desc (same result bit for bit): one descriptor per node-pair
+ * block with I <= J; the summed block goes to (I,J) at dst/stride and, transposed, to (J,I) at
+ * dst_t/stride_t (dst_t = -1: no transposed copy -- diagonal blocks, and pattern-only blocks whose
+ * partner is absent).  K, M, K_T, K_G element matrices are symmetric by construction
+ * (FS_LAYOUT_SYMBLK stores i <= j only), so each source block is read once. */
+typedef struct fs_blk_desc_sym {
+    int64_t dst;
+    int64_t dst_t;
+    int32_t stride;
+    int32_t stride_t;
+    int32_t cnt;
+    int32_t pad_;
+    int64_t c[4];
+} fs_blk_desc_sym; /* 64 bytes */
+int fs_csr_numeric_sym(const double *vals, const fs_blk_desc_sym *desc, const int64_t *contrib,
+                       int64_t ndesc, int32_t d, double *data, void *stream);
+
 /* Symbolic companion of fs_csr_numeric_blk (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph.
  * nbr[nblk] = neighbour node J of each block. */

@@ -178,3 +178,20 @@ def test_mixed_group_plan_matches_set_union(oracle):
     assert np.array_equal(hp, ip) and np.array_equal(hx, ix)
     got = util.host_block_assemble(plan, packed)
     assert np.array_equal(got, data)      # same summation order -> bitwise equal
+
+
+def test_sym_descriptors_cover_every_block_once():
+    """fs_blk_desc_sym rows: every block is written exactly once, either directly or as the
+    transposed partner; pattern-only ghost blocks without a partner stay own descriptors."""
+    from fem_shell_amd import meshes, symbolic
+    conn = meshes.mixed_conn(6, 5)
+    n_nodes = 7 * 6
+    extra = np.array([[0, 40], [3, 41]])                       # ghost columns, no partner rows
+    plan = symbolic.BlockPlan(conn, n_nodes, 6, extra_pairs=extra)
+    full, sym = plan.descriptors(), plan.sym_descriptors()
+    written = np.concatenate([sym["dst"], sym["dst_t"][sym["dst_t"] >= 0]])
+    assert np.array_equal(np.sort(written), np.sort(full["dst"]))
+    assert sym.shape[0] < full.shape[0]
+    t = sym["dst_t"] >= 0
+    lookup = {int(d): int(s) for d, s in zip(full["dst"], full["stride"])}
+    assert all(lookup[int(d)] == int(st) for d, st in zip(sym["dst_t"][t], sym["stride_t"][t]))

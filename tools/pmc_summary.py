@@ -2,14 +2,14 @@
 """Summarise gpurun_out/pmc/*/ counter_collection.csv -> per-kernel averages per launch; writes
 profiles/pmc_summary.json (hbm bytes per launch with the gfx950 FETCH_SIZE x2 correction of
 MI355X_MICROARCH.md 'HBM')."""
-import csv, glob, json, collections, sys, os
+import csv, glob, json, collections, sys, os, re
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        short = "mitc4_k_kernel" if "mitc4_k_kernel" in k else "csr_numeric_desc2_kernel" if "csr_numeric_desc2" in k else \
-                "mitc4_m_kernel" if "mitc4_m_kernel" in k else None
+        m = re.search(r"(\w+_kernel)", k)
+        short = m.group(1) if m else None
         if short:
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
