@@ -3,7 +3,8 @@
 profiles/pmc_summary.json (hbm bytes per launch with the gfx950 FETCH_SIZE x2 correction of
 MI355X_MICROARCH.md 'HBM')."""
 import csv, glob, json, collections, sys, os, re
-root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+root = args[0] if args else "gpurun_out/pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
