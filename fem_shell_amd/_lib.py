@@ -22,6 +22,9 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp]),
     "fs_solid_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _i64, _u32, _u32, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp]),
+    "fs_shell_kg_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _u32, _vp, _vp]),
+    "fs_centrifugal_prestress": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, ctypes.c_double, _vp, _vp,
+                                                _i64, _vp, _vp]),
     "fs_shell_quad_geom": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_blk_expand": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "fs_csr_numeric": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -379,25 +379,41 @@ class MeshAssembler:
 
     # --- new (SURVEY.md 8a "New"): Newton re-assembly of K_T(u) and f_int(u) -----------------
     def _element_displacements(self, u):
-        if self._family != ElementFamily.SHELL or self._is_mixed_mesh or self._groups[0]["nn"] != 4:
-            raise NotImplementedError("K_T / f_int re-assembly is available for MITC4 meshes only")
+        """u_e[e] = u[dofs_e] for every element group (fs_gather_dofs)."""
+        if self._family != ElementFamily.SHELL:
+            raise NotImplementedError("K_T / f_int re-assembly is available for shell meshes (MITC4 / MITC3)")
         lib = _lib.load()
         u = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
         if u.numel() != self.dofs_count:
             raise ValueError(f"Expected {self.dofs_count} DOFs, got {u.numel()}")
-        if not hasattr(self, "_dofs_d"):
-            self._dofs_d = torch.from_numpy(self._dofs_array).to(self.device)
-        E = self._conn.shape[0]
-        ue = torch.empty((E, 24), dtype=torch.float64, device=self.device)
-        _lib.check(lib.fs_gather_dofs(_lib.ptr(u), _lib.ptr(self._dofs_d), E * 24, _lib.ptr(ue),
-                                      _lib.stream_ptr()), "fs_gather_dofs")
-        return ue
+        d = self.dofs_per_node
+        out = []
+        for g in self._groups:
+            if "dofs_d" not in g:
+                ar = torch.arange(d, dtype=torch.int64, device=self.device)
+                g["dofs_d"] = (g["conn_d"].to(torch.int64)[:, :, None] * d + ar).reshape(g["E"], -1).contiguous()
+            nd = g["nn"] * d
+            ue = torch.empty((g["E"], nd), dtype=torch.float64, device=self.device)
+            _lib.check(lib.fs_gather_dofs(_lib.ptr(u), _lib.ptr(g["dofs_d"]), g["E"] * nd, _lib.ptr(ue),
+                                          _lib.stream_ptr()), "fs_gather_dofs")
+            out.append(ue)
+        return out
 
     def _nl_pass(self, u, want_KT, want_F):
-        ue = self._element_displacements(u)
-        return batch.quad_batch(self._xyz_d, self._pid_d, self._props_d, len(self._prop_table),
-                                want_K=False, status=False, validate=False, u_e=ue,
-                                want_KT=want_KT, want_F=want_F)
+        """Per group: update_configuration(u_e) + compute_tangent_stiffness / compute_internal_forces."""
+        ues = self._element_displacements(u)
+        buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
+        fparts = []
+        for g, ue in zip(self._groups, ues):
+            out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                    want_K=False, status=False, validate=False, u_e=ue, want_KT=want_KT,
+                                    want_F=want_F, KT_out=self._group_view(buf, g))
+            if want_F:
+                fparts.append(out["f_int"].reshape(-1))
+        f = None
+        if want_F:
+            f = fparts[0] if len(fparts) == 1 else torch.cat(fparts)
+        return {"KT": buf if want_KT else None, "f_int": f}
 
     def _scatter_vector(self, fe):
         """fe: flat device buffer of the groups' element vectors, group after group."""
@@ -442,34 +458,56 @@ class MeshAssembler:
 
     def assemble_geometric_stiffness(self, stress_field=None, omega=None, rotation_axis=None,
                                      rotation_center=None) -> CsrMatrix:
-        """core/assembler.py:386-516 for solids with an explicit `stress_field`
-        ({element id: Voigt [xx,yy,zz,xy,yz,zx]} or an [E,6] array in element order): per element
-        compute_geometric_stiffness(sigma) (elements/SOLID.py:322-374), scatter-added like K.
-        Elements without an entry (or with max|sigma| < 1e-20) contribute zeros; unlike the PETSc
-        matrix of the reference the returned CSR keeps K's full pattern (explicit zeros)."""
+        """core/assembler.py:386-516.  Per element: sigma = stress_field[element id] if present, else
+        compute_centrifugal_prestress(omega, axis, center) (MITC3.py:1633-1715, SOLID.py:268-320), else
+        skipped; elements with max|sigma| < 1e-20 are skipped; K_G^e = compute_geometric_stiffness(sigma)
+        (MITC4.py:1191-1225, MITC3.py:1501-1580, SOLID.py:322-374), scatter-added like K.
+        `stress_field`: {element id: stress} or an array in element order -- shells [sxx,syy,sxy] in
+        element-local axes (or 2x2), solids Voigt [xx,yy,zz,xy,yz,zx].  Like the reference, the omega
+        mode raises AttributeError for MITC4 (it has no compute_centrifugal_prestress).  Unlike the
+        PETSc matrix of the reference the returned CSR keeps K's full pattern (explicit zeros)."""
         if stress_field is None and omega is None:
             raise ValueError("Either 'stress_field' or 'omega' must be provided for geometric stiffness")
-        if self._family != ElementFamily.SOLID:
-            raise NotImplementedError("geometric stiffness is on the GPU path for solids only "
-                                      "(shell K_sigma is part of assemble_tangent_stiffness)")
-        if stress_field is None:
-            raise NotImplementedError("centrifugal prestress (omega) is not on the GPU path; pass stress_field")
+        axis = np.array([0.0, 0.0, 1.0]) if rotation_axis is None else np.asarray(rotation_axis, dtype=float)
+        axis = axis / np.linalg.norm(axis)
+        center = np.zeros(3) if rotation_center is None else np.asarray(rotation_center, dtype=float)
+        solid = self._family == ElementFamily.SOLID
+        ns = 6 if solid else 3
         E = self._conn.shape[0]
+        given = np.zeros(E, dtype=bool)
+        sig = np.zeros((E, ns))
         if isinstance(stress_field, dict):
-            sig = np.zeros((E, 6))
             for eid, sv in stress_field.items():
                 if eid in self._elem_pos:
-                    sig[self._elem_pos[eid]] = np.asarray(sv, dtype=float)
-        else:
-            sig = np.ascontiguousarray(stress_field, dtype=np.float64).reshape(E, 6)
-        sig = np.where(np.abs(sig).max(axis=1, keepdims=True) < 1e-20, 0.0, sig)
+                    sv = np.asarray(sv, dtype=float)
+                    if not solid and sv.shape == (2, 2):
+                        sv = np.array([sv[0, 0], sv[1, 1], sv[0, 1]])
+                    sig[self._elem_pos[eid]] = sv
+                    given[self._elem_pos[eid]] = True
+        elif stress_field is not None:
+            sig = np.ascontiguousarray(stress_field, dtype=np.float64).reshape(E, ns).copy()
+            given[:] = True
+        if solid:   # the shell kernel applies the 1e-20 skip rule itself
+            sig = np.where(np.abs(sig).max(axis=1, keepdims=True) < 1e-20, 0.0, sig)
         buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
         for g in self._groups:
-            sg = torch.from_numpy(np.ascontiguousarray(sig if g["pos"] is None else sig[g["pos"]])).to(self.device)
-            out = batch.solid_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
-                                    want_K=False, want_M=False, sigma=sg, reduced=self._reduced,
-                                    status=False, validate=False)
-            self._group_view(buf, g).copy_(out["KG"])
+            sel = slice(None) if g["pos"] is None else g["pos"]
+            sg = torch.from_numpy(np.ascontiguousarray(sig[sel])).to(self.device)
+            gv = given[sel]
+            if omega is not None and not gv.all():
+                cf = batch.centrifugal_prestress(solid, g["nn"], g["xyz_d"], g["pid_d"], self._props_d,
+                                                 len(self._prop_table), omega, axis, center)
+                if solid:
+                    cf = torch.where(cf.abs().amax(dim=1, keepdim=True) < 1e-20, torch.zeros_like(cf), cf)
+                sg = torch.where(torch.from_numpy(gv).to(self.device)[:, None], sg, cf)
+            if solid:
+                out = batch.solid_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                        want_K=False, want_M=False, sigma=sg, reduced=self._reduced,
+                                        status=False, validate=False)
+                self._group_view(buf, g).copy_(out["KG"])
+            else:
+                batch.shell_kg_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table), sg,
+                                     KG_out=self._group_view(buf, g))
         return self._assemble(buf)
 
 

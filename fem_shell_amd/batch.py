@@ -34,7 +34,7 @@ def _out_buf(given, E, npair, dev, dd=36):
 
 def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
                status=True, validate=True, u_e=None, want_KT=False, want_F=False, K_out=None,
-               M_out=None):
+               M_out=None, KT_out=None):
     """MITC4+ element matrices for E quads.
 
     xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
@@ -61,7 +61,7 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
             raise ValueError("KT / f_int need the element displacement vectors u_e [E,24]")
         u_e = u_e.contiguous()
         assert u_e.dtype == torch.float64 and u_e.shape == (E, 24) and u_e.is_cuda
-        KT = torch.empty((E, NPAIR4, 36), dtype=torch.float64, device=dev)   # also the FINT workspace
+        KT = _out_buf(KT_out, E, NPAIR4, dev)   # also the FINT workspace
         F = torch.empty((E, 24), dtype=torch.float64, device=dev) if want_F else None
         want |= (_lib.FS_WANT_KT if want_KT else 0) | (_lib.FS_WANT_FINT if want_F else 0)
     _lib.check(lib.fs_shell_quad_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
@@ -82,11 +82,12 @@ NPAIR3 = 6
 
 
 def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
-              status=True, validate=True, K_out=None, M_out=None):
+              status=True, validate=True, K_out=None, M_out=None, u_e=None, want_KT=False,
+              want_F=False, KT_out=None):
     """MITC3+ element matrices for E triangles (fs_shell_tri_batch).
 
-    xyz [E,3,3] f64 device.  Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,6,36] or dense
-    [E,18,18]) and 'status'."""
+    xyz [E,3,3] f64 device.  Returns dict with 'K'/'M'/'KT' (FS_LAYOUT_SYMBLK [E,6,36] or dense
+    [E,18,18]), 'f_int' [E,18] and 'status'."""
     lib = _lib.load()
     dev = _dev()
     xyz = xyz.contiguous()
@@ -101,14 +102,65 @@ def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense
     M = _out_buf(M_out, E, NPAIR3, dev) if want_M else None
     st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
     want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
+    KT = F = None
+    if want_KT or want_F:
+        if u_e is None:
+            raise ValueError("KT / f_int need the element displacement vectors u_e [E,18]")
+        u_e = u_e.contiguous()
+        assert u_e.dtype == torch.float64 and u_e.shape == (E, 18) and u_e.is_cuda
+        KT = _out_buf(KT_out, E, NPAIR3, dev)   # also the FINT workspace
+        F = torch.empty((E, 18), dtype=torch.float64, device=dev) if want_F else None
+        want |= (_lib.FS_WANT_KT if want_KT else 0) | (_lib.FS_WANT_FINT if want_F else 0)
     _lib.check(lib.fs_shell_tri_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
-                                      n_props, None, E, want, _lib.FS_LAYOUT_SYMBLK,
-                                      _lib.ptr(K), _lib.ptr(M), None, None, _lib.ptr(st),
+                                      n_props, _lib.ptr(u_e), E, want, _lib.FS_LAYOUT_SYMBLK,
+                                      _lib.ptr(K), _lib.ptr(M), _lib.ptr(KT), _lib.ptr(F), _lib.ptr(st),
                                       _lib.stream_ptr()), "fs_shell_tri_batch")
+    if not want_KT:
+        KT = None
     if dense:
         K = expand_blocks(K, 3, 6) if K is not None else None
         M = expand_blocks(M, 3, 6) if M is not None else None
-    return {"K": K, "M": M, "KT": None, "f_int": None, "status": st}
+        KT = expand_blocks(KT, 3, 6) if KT is not None else None
+    return {"K": K, "M": M, "KT": KT, "f_int": F, "status": st}
+
+
+def shell_kg_batch(nn, xyz, prop_id, props_dev, n_props, sigma, dense=False, KG_out=None):
+    """Shell geometric stiffness from local membrane stresses sigma [E,3] (fs_shell_kg_batch):
+    FS_LAYOUT_SYMBLK [E, nn(nn+1)/2, 36] or dense [E,6nn,6nn]."""
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    if nn not in (3, 4):
+        raise ValueError(f"unsupported shell element with {nn} nodes")
+    assert xyz.dtype == torch.float64 and xyz.shape[1:] == (nn, 3) and xyz.is_cuda
+    assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
+    sigma = sigma.contiguous()
+    assert sigma.dtype == torch.float64 and sigma.shape == (E, 3) and sigma.is_cuda
+    KG = _out_buf(KG_out, E, nn * (nn + 1) // 2, dev)
+    _lib.check(lib.fs_shell_kg_batch(nn, _lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev), n_props,
+                                     _lib.ptr(sigma), E, _lib.FS_LAYOUT_SYMBLK, _lib.ptr(KG),
+                                     _lib.stream_ptr()), "fs_shell_kg_batch")
+    return expand_blocks(KG, nn, 6) if dense else KG
+
+
+def centrifugal_prestress(solid, nn, xyz, prop_id, props_dev, n_props, omega, rotation_axis, rotation_center):
+    """compute_centrifugal_prestress of every element (fs_centrifugal_prestress): [E,3] local
+    membrane stresses for MITC3, [E,6] global Voigt stresses for the linear solids."""
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    if not solid and nn == 4:
+        raise AttributeError("'MITC4' object has no attribute 'compute_centrifugal_prestress'")
+    ax = np.ascontiguousarray(np.asarray(rotation_axis, dtype=np.float64).reshape(3))
+    ce = np.ascontiguousarray(np.asarray(rotation_center, dtype=np.float64).reshape(3))
+    sig = torch.empty((E, 6 if solid else 3), dtype=torch.float64, device=dev)
+    _lib.check(lib.fs_centrifugal_prestress(int(bool(solid)), nn, _lib.ptr(xyz), _lib.ptr(prop_id),
+                                            _lib.ptr(props_dev), n_props, float(omega), ax.ctypes.data,
+                                            ce.ctypes.data, E, _lib.ptr(sig), _lib.stream_ptr()),
+               "fs_centrifugal_prestress")
+    return sig
 
 
 def solid_batch(nn, xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, body=None,
@@ -169,9 +221,6 @@ def shell_batch(nn, *args, **kw):
     if nn == 4:
         return quad_batch(*args, **kw)
     if nn == 3:
-        kw.pop("u_e", None)
-        if kw.pop("want_KT", False) or kw.pop("want_F", False):
-            raise NotImplementedError("K_T / f_int are not available for MITC3 yet")
         return tri_batch(*args, **kw)
     raise ValueError(f"unsupported shell element with {nn} nodes")
 

@@ -18,6 +18,7 @@
 // Citations: file:line relative to /root/reference/src/fem_shell/.
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -188,9 +189,12 @@ __device__ __forceinline__ double jacobian(const QuadGeom &g, const double *dxi,
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS layout of one wave (16 elements): component-major, g-major, then a (node, quad) swizzle that
-// makes every stage-2 read (uniform component and Gauss point, per-lane node) conflict-free:
-// within a 32-lane group the 8 quads x 4 nodes map to 32 distinct double-banks.
+// LDS layout of one wave (16 elements): component-major, g-major, then a (node, quad) swizzle:
+// in-slab index = (Q>>2)*16 + ((node+g)&3)*4 + (Q&3).  ds_write_b64 is serviced in 16-lane groups
+// over 16 double-banks (MI355X_MICROARCH.md "LDS"): the stage-1 store of one node by the 4 Gauss-point
+// lanes of 4 quads hits 16 distinct banks thanks to the +g rotation; stage-2 reads (uniform
+// component and Gauss point, per-lane node) hit 16 / 32 distinct double-banks per 16 / 32-lane group,
+// so they stay conflict-free whether the compiler emits ds_read_b64 or ds_read2_b64.
 // ------------------------------------------------------------------------------------------
 constexpr int NC = 8;  // per (node, gp): dNdx dNdy | Bs[2][3]
 constexpr int C_DN = 0, C_BS = 2;
@@ -200,7 +204,7 @@ constexpr int LDS_U = LDS_KNB + 6 * 64;    // coupling U[c<10][node][Q] (only wr
 constexpr int LDS_WAVE = LDS_U + 10 * 64;  // 3136 doubles = 25088 B
 
 __device__ __forceinline__ int lds_slot(int c, int g, int node, int Q) {
-    return ((c * 4 + g) << 6) + ((Q >> 3) << 5) + (node << 3) + (Q & 7);
+    return ((c * 4 + g) << 6) + ((Q >> 2) << 4) + (((node + g) & 3) << 2) + (Q & 3);
 }
 
 __device__ __forceinline__ double quad_sum(double v) {
@@ -229,7 +233,10 @@ __device__ __forceinline__ void tying_weights(int i, double *w) {
 // which is the same sum of products as MITC4.py:934-944 re-associated (eps-level difference) and
 // removes B_m from LDS and from the Gauss-point loop of every node-pair task.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
+#ifndef FS_K_WAVES
+#define FS_K_WAVES 1
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_K_WAVES, FS_K_WAVES))) void mitc4_k_kernel(const double *__restrict__ xyz,
                                                      const int32_t *__restrict__ prop_id,
                                                      const fs_shell_prop *__restrict__ props,
                                                      int64_t E, double *__restrict__ out,
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
     }
 
-    const int qoff = ((Q >> 3) << 5) + (Q & 7);
+    const int qoff = ((Q >> 2) << 4) + (Q & 3);
     double S[15];         // upper triangle of the 5x5 membrane core, row-major (t <= u)
     double kbb00, kbb01, kbb11;
     {
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
                 for (int t = 0; t < 5; t++)
                     for (int c = 0; c < 2; c++) {
                         const double u = quad_sum(W[0][t] * LK[0][c] + W[1][t] * LK[1][c] + W[2][t] * LK[2][c]);
-                        if (j == g) lds[LDS_U + ((2 * t + c) << 6) + (j << 3) + qoff] = u;
+                        if (j == g) lds[LDS_U + ((2 * t + c) << 6) + (j << 2) + qoff] = u;
                     }
             }
         }
@@ -427,12 +434,12 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
                 n0 = quad_sum(detJ * n0);
                 n1 = quad_sum(detJ * n1);
                 if (i == g) {
-                    lds[LDS_KNB + ((2 * k) << 6) + (i << 3) + qoff] = n0;
-                    lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 3) + qoff] = n1;
+                    lds[LDS_KNB + ((2 * k) << 6) + (i << 2) + qoff] = n0;
+                    lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 2) + qoff] = n1;
                 }
             }
         }
-        lds[LDS_DET + g * 16 + Q] = detJ;
+        lds[LDS_DET + Q * 4 + g] = detJ;
         // Kbb = Bkb^T Cb Bkb + Bsb^T Cs Bsb
         kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
         kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         if (round == 0) { ti = g; tj = g; }
         else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
         else { ti = g & 1; tj = (g & 1) + 2; active = active && (g < 2); }
-        const int oi = (ti << 3) + qoff, oj = (tj << 3) + qoff;
+        const int oi = (ti << 2) + qoff, oj = (tj << 2) + qoff;
         // shape-function signs of nodes ti, tj (for N_i at the Gauss points)
         const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
         const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
@@ -522,13 +529,14 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         }
 
         for (int gg = 0; gg < 4; gg++) {
-            const double w = lds[LDS_DET + gg * 16 + Q];
+            const double w = lds[LDS_DET + Q * 4 + gg];
+            const int gi = (((ti + gg) & 3) << 2) + qoff, gj = (((tj + gg) & 3) << 2) + qoff;
             double bsi[2][3], bsj[2][3];
-            const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + oi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + oi];
-            const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + oj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + oj];
+            const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + gi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + gi];
+            const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + gj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + gj];
             for (int c = 0; c < 6; c++) {
-                (&bsi[0][0])[c] = w * lds[(((C_BS + c) * 4 + gg) << 6) + oi];
-                (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + oj];
+                (&bsi[0][0])[c] = w * lds[(((C_BS + c) * 4 + gg) << 6) + gi];
+                (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + gj];
             }
             const double wdxi = w * dxi_, wdyi = w * dyi_;
             // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
@@ -1217,6 +1225,346 @@ __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// MITC3 total-Lagrangian tangent and internal force (MITC3.py:1144-1832, composite overrides
+// MITC3_composite.py:246-265, 496-621).  One lane per element; runs AFTER mitc3_k_kernel has
+// written the linear blocks K (global axes, INITIAL frame R0) into `kt` (FS_LAYOUT_SYMBLK, 6 pairs).
+// Reference quirk kept: T() is rebuilt from the CURRENT coordinates x + u (MITC3.py:471-494) while
+// K0, the derivatives and the area come from the initial geometry.  With Rc the current frame and
+// P = R0^T Rc (3x3):  K0 in current-frame global axes = P^T K P block-wise, so
+//   K_T   = P^T K P + Rc^T sym(K_L + K_sigma) Rc          (translational sub-blocks only)
+//   f_int = P^T (K (P u)) + Rc^T ( f_membrane(GL) - K_m,CST u_loc )        [nonlinear rows]
+//         = P^T (K (P u))                                                  [linear rows]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__ xyz,
+                                                      const int32_t *__restrict__ prop_id,
+                                                      const fs_shell_prop *__restrict__ props,
+                                                      const double *__restrict__ ue, int64_t E,
+                                                      double *__restrict__ kt, int want_kt,
+                                                      double *__restrict__ fe) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double x[3][3], u[3][6];
+    for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+    for (int c = 0; c < 18; c++) (&u[0][0])[c] = ue[e * 18 + c];
+    const fs_shell_prop *pr = props + prop_id[e];
+    TriGeom geo;
+    tri_geometry(x, geo);
+    const double R0[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    double Rc[3][3];
+    {   // MITC3.py:480-488 on x + u
+        double v12[3], v13[3], n[3];
+        for (int k = 0; k < 3; k++) {
+            const double a0 = x[0][k] + u[0][k], a1 = x[1][k] + u[1][k], a2 = x[2][k] + u[2][k];
+            v12[k] = a1 - a0; v13[k] = a2 - a0;
+        }
+        double l = norm3(v12);
+        for (int k = 0; k < 3; k++) Rc[0][k] = v12[k] / l;
+        cross3(v12, v13, n);
+        l = norm3(n);
+        for (int k = 0; k < 3; k++) Rc[2][k] = n[k] / l;
+        cross3(Rc[2], Rc[0], Rc[1]);
+    }
+    double *blk = kt + e * 216;
+    const int pidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    {
+#pragma clang fp contract(fast)
+    double P[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) P[a][b] = R0[0][a] * Rc[0][b] + R0[1][a] * Rc[1][b] + R0[2][a] * Rc[2][b];
+    const double dr[3] = {-1.0, 1.0, 0.0}, ds[3] = {-1.0, 0.0, 1.0};
+    double nx[3], ny[3];
+    for (int i = 0; i < 3; i++) { nx[i] = geo.J00 * dr[i]; ny[i] = geo.J10 * dr[i] + geo.J11 * ds[i]; }
+    const double h = pr->h, ar = geo.area;
+    double C[3][3];
+    for (int a = 0; a < 9; a++) (&C[0][0])[a] = pr->C_raw[a];
+    // local displacements in the CURRENT frame
+    double ul[3][3], rl[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int a = 0; a < 3; a++) {
+            ul[i][a] = Rc[a][0] * u[i][0] + Rc[a][1] * u[i][1] + Rc[a][2] * u[i][2];
+            rl[i][a] = Rc[a][0] * u[i][3] + Rc[a][1] * u[i][4] + Rc[a][2] * u[i][5];
+        }
+    double f[3][6];
+    for (int c = 0; c < 18; c++) (&f[0][0])[c] = 0.0;
+    if (fe) {   // P^T (K (P u))
+        double q[3][6], w[3][6];
+        for (int i = 0; i < 3; i++)
+            for (int a = 0; a < 3; a++) {
+                q[i][a] = P[a][0] * u[i][0] + P[a][1] * u[i][1] + P[a][2] * u[i][2];
+                q[i][3 + a] = P[a][0] * u[i][3] + P[a][1] * u[i][4] + P[a][2] * u[i][5];
+            }
+        for (int c = 0; c < 18; c++) (&w[0][0])[c] = 0.0;
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++) {
+                const double *B = blk + pidx[i][j] * 36;
+                for (int a = 0; a < 6; a++)
+                    for (int b = 0; b < 6; b++) {
+                        const double v = B[a * 6 + b];
+                        w[i][a] += v * q[j][b];
+                        if (i != j) w[j][b] += v * q[i][a];
+                    }
+            }
+        for (int i = 0; i < 3; i++)
+            for (int a = 0; a < 3; a++) {
+                f[i][a] = P[0][a] * w[i][0] + P[1][a] * w[i][1] + P[2][a] * w[i][2];
+                f[i][3 + a] = P[0][a] * w[i][3] + P[1][a] * w[i][4] + P[2][a] * w[i][5];
+            }
+    }
+    if (want_kt) {  // K <- P^T K P, every 3x3 sub-block
+        for (int p = 0; p < 6; p++)
+            for (int ba = 0; ba < 2; ba++)
+                for (int bb = 0; bb < 2; bb++) {
+                    double X[3][3], Y[3][3];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) X[a][b] = blk[p * 36 + (3 * ba + a) * 6 + 3 * bb + b];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) Y[a][b] = P[0][a] * X[0][b] + P[1][a] * X[1][b] + P[2][a] * X[2][b];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++)
+                            blk[p * 36 + (3 * ba + a) * 6 + 3 * bb + b] = Y[a][0] * P[0][b] + Y[a][1] * P[1][b] + Y[a][2] * P[2][b];
+                }
+    }
+    if (pr->nonlinear) {
+        // membrane stress at the centroid (MITC3.py:1582-1631; laminate MITC3_composite.py:496-505)
+        double Sm00, Sm01, Sm11;
+        {
+            double eps[3] = {0, 0, 0}, kap[3] = {0, 0, 0};
+            for (int i = 0; i < 3; i++) {
+                eps[0] += nx[i] * ul[i][0]; eps[1] += ny[i] * ul[i][1]; eps[2] += ny[i] * ul[i][0] + nx[i] * ul[i][1];
+                kap[0] += nx[i] * rl[i][1]; kap[1] += -ny[i] * rl[i][0]; kap[2] += ny[i] * rl[i][1] - nx[i] * rl[i][0];
+            }
+            double sig[3];
+            if (pr->flags & FS_PROP_LAMINATE) {
+                for (int a = 0; a < 3; a++)
+                    sig[a] = ((pr->A[a * 3] * eps[0] + pr->A[a * 3 + 1] * eps[1] + pr->A[a * 3 + 2] * eps[2]) +
+                              (pr->B[a * 3] * kap[0] + pr->B[a * 3 + 1] * kap[1] + pr->B[a * 3 + 2] * kap[2])) / h;
+            } else {
+                for (int a = 0; a < 3; a++) sig[a] = C[a][0] * eps[0] + C[a][1] * eps[1] + C[a][2] * eps[2];
+            }
+            Sm00 = sig[0] * h; Sm11 = sig[1] * h; Sm01 = sig[2] * h;
+            // K_m,CST u_loc (MITC3.py:1018-1024), subtracted from f: A eps * area
+            if (fe) {
+                double N[3];
+                for (int a = 0; a < 3; a++) N[a] = ar * (pr->A[a * 3] * eps[0] + pr->A[a * 3 + 1] * eps[1] + pr->A[a * 3 + 2] * eps[2]);
+                for (int i = 0; i < 3; i++) {
+                    const double fl[3] = {-(nx[i] * N[0] + ny[i] * N[2]), -(ny[i] * N[1] + nx[i] * N[2]), 0.0};
+                    for (int a = 0; a < 3; a++) f[i][a] += Rc[0][a] * fl[0] + Rc[1][a] * fl[1] + Rc[2][a] * fl[2];
+                }
+            }
+        }
+        // displacement gradient: GLOBAL components, local derivatives (MITC3.py:1198-1225), constant
+        double H[3][2];
+        for (int c = 0; c < 3; c++) {
+            H[c][0] = u[0][c] * nx[0] + u[1][c] * nx[1] + u[2][c] * nx[2];
+            H[c][1] = u[0][c] * ny[0] + u[1][c] * ny[1] + u[2][c] * ny[2];
+        }
+        const double E00 = 0.5 * (2.0 * H[0][0] + (H[0][0] * H[0][0] + H[1][0] * H[1][0] + H[2][0] * H[2][0]));
+        const double E11 = 0.5 * (2.0 * H[1][1] + (H[0][1] * H[0][1] + H[1][1] * H[1][1] + H[2][1] * H[2][1]));
+        const double E01 = 0.5 * ((H[0][1] + H[1][0]) + (H[0][0] * H[0][1] + H[1][0] * H[1][1] + H[2][0] * H[2][1]));
+        const double eg[3] = {E00, E11, 2.0 * E01};
+        double sg[3];
+        for (int a = 0; a < 3; a++) sg[a] = C[a][0] * eg[0] + C[a][1] * eg[1] + C[a][2] * eg[2];
+        const double wh = ar * h;
+        double Bt[3][3][3], BL[3][3][3], CBt[3][3][3], CBL[3][3][3];
+        for (int i = 0; i < 3; i++) {
+            for (int k = 0; k < 3; k++) {
+                BL[i][0][k] = (k == 0) ? nx[i] : 0.0;
+                BL[i][1][k] = (k == 1) ? ny[i] : 0.0;
+                BL[i][2][k] = (k == 0) ? ny[i] : ((k == 1) ? nx[i] : 0.0);
+                Bt[i][0][k] = BL[i][0][k] + H[k][0] * nx[i];
+                Bt[i][1][k] = BL[i][1][k] + H[k][1] * ny[i];
+                Bt[i][2][k] = BL[i][2][k] + (H[k][0] * ny[i] + H[k][1] * nx[i]);
+            }
+            for (int a = 0; a < 3; a++)
+                for (int k = 0; k < 3; k++) {
+                    CBt[i][a][k] = wh * (C[a][0] * Bt[i][0][k] + C[a][1] * Bt[i][1][k] + C[a][2] * Bt[i][2][k]);
+                    CBL[i][a][k] = wh * (C[a][0] * BL[i][0][k] + C[a][1] * BL[i][1][k] + C[a][2] * BL[i][2][k]);
+                }
+            if (fe) {
+                double fl[3];
+                for (int k = 0; k < 3; k++) fl[k] = wh * (Bt[i][0][k] * sg[0] + Bt[i][1][k] * sg[1] + Bt[i][2][k] * sg[2]);
+                for (int a = 0; a < 3; a++) f[i][a] += Rc[0][a] * fl[0] + Rc[1][a] * fl[1] + Rc[2][a] * fl[2];
+            }
+        }
+        if (want_kt) {
+            for (int i = 0; i < 3; i++)
+                for (int j = i; j < 3; j++) {
+                    const int p = pidx[i][j];
+                    const double ks = ar * (nx[i] * (Sm00 * nx[j] + Sm01 * ny[j]) + ny[i] * (Sm01 * nx[j] + Sm11 * ny[j]));
+                    double Xs[3][3];
+                    for (int k = 0; k < 3; k++)
+                        for (int l = 0; l < 3; l++) {
+                            double v = Bt[i][0][k] * CBt[j][0][l] + Bt[i][1][k] * CBt[j][1][l] + Bt[i][2][k] * CBt[j][2][l];
+                            v -= BL[i][0][k] * CBL[j][0][l] + BL[i][1][k] * CBL[j][1][l] + BL[i][2][k] * CBL[j][2][l];
+                            if (k == l) v += ks;
+                            Xs[k][l] = v;
+                        }
+                    if (i == j)
+                        for (int k = 0; k < 3; k++)
+                            for (int l = k + 1; l < 3; l++) { const double m = 0.5 * (Xs[k][l] + Xs[l][k]); Xs[k][l] = m; Xs[l][k] = m; }
+                    double Yt[3][3];
+                    for (int a = 0; a < 3; a++)
+                        for (int l = 0; l < 3; l++) Yt[a][l] = Rc[0][a] * Xs[0][l] + Rc[1][a] * Xs[1][l] + Rc[2][a] * Xs[2][l];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++)
+                            blk[p * 36 + a * 6 + b] += Yt[a][0] * Rc[0][b] + Yt[a][1] * Rc[1][b] + Yt[a][2] * Rc[2][b];
+                }
+        }
+    }
+    if (want_kt)   // keep the diagonal blocks exactly symmetric (MITC3.py:1771 symmetrises K_T)
+        for (int i = 0; i < 3; i++) {
+            const int p = pidx[i][i];
+            for (int a = 0; a < 6; a++)
+                for (int b = a + 1; b < 6; b++) {
+                    const double m = 0.5 * (blk[p * 36 + a * 6 + b] + blk[p * 36 + b * 6 + a]);
+                    blk[p * 36 + a * 6 + b] = m; blk[p * 36 + b * 6 + a] = m;
+                }
+        }
+    if (fe)
+        for (int c = 0; c < 18; c++) fe[e * 18 + c] = (&f[0][0])[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Shell geometric stiffness from a given LOCAL membrane stress [sxx, syy, sxy]
+// (MITC4.py:1191-1225, MITC3.py:1501-1580): K_sigma couples only the translations,
+// block (i,j) = g_ij R^T R with g_ij = h sum_gp w detJ grad(N_i)^T S grad(N_j).
+// One thread per (element, node pair i<=j); elements with max|sigma| < 1e-20 give zero blocks
+// (the assembler skips them, core/assembler.py:498-500).
+// ------------------------------------------------------------------------------------------
+template <int NN>
+__global__ __launch_bounds__(256) void shell_kg_kernel(const double *__restrict__ xyz,
+                                                       const int32_t *__restrict__ prop_id,
+                                                       const fs_shell_prop *__restrict__ props,
+                                                       const double *__restrict__ sigma, int64_t E,
+                                                       double *__restrict__ out) {
+    constexpr int NP = NN * (NN + 1) / 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * NP) return;
+    const int64_t e = t / NP;
+    const int p = (int)(t - e * NP);
+    int ti = 0, rem = p;
+    while (rem >= NN - ti) { rem -= NN - ti; ti++; }
+    const int tj = ti + rem;
+    const double s0 = sigma[e * 3], s1 = sigma[e * 3 + 1], s2 = sigma[e * 3 + 2];
+    const double h = props[prop_id[e]].h;
+    const bool skip = __builtin_fmax(__builtin_fabs(s0), __builtin_fmax(__builtin_fabs(s1), __builtin_fabs(s2))) < 1e-20;
+    double g = 0.0, R[3][3];
+    if constexpr (NN == 3) {
+        double x[3][3];
+        for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+        TriGeom geo;
+        tri_geometry(x, geo);
+        for (int k = 0; k < 3; k++) { R[0][k] = geo.e1[k]; R[1][k] = geo.e2[k]; R[2][k] = geo.e3[k]; }
+        const double dri = (ti == 0) ? -1.0 : ((ti == 1) ? 1.0 : 0.0), dsi = (ti == 0) ? -1.0 : ((ti == 2) ? 1.0 : 0.0);
+        const double drj = (tj == 0) ? -1.0 : ((tj == 1) ? 1.0 : 0.0), dsj = (tj == 0) ? -1.0 : ((tj == 2) ? 1.0 : 0.0);
+        const double xi_ = geo.J00 * dri, yi_ = geo.J10 * dri + geo.J11 * dsi;
+        const double xj_ = geo.J00 * drj, yj_ = geo.J10 * drj + geo.J11 * dsj;
+        const double v = xi_ * ((s0 * h) * xj_ + (s2 * h) * yj_) + yi_ * ((s2 * h) * xj_ + (s1 * h) * yj_);
+        for (int q = 0; q < 3; q++) g += (1.0 / 3.0) * geo.area * v;
+    } else {
+        double x[4][3];
+        for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
+        QuadGeom geo;
+        quad_geometry(x, geo);
+        for (int k = 0; k < 3; k++) { R[0][k] = geo.e1[k]; R[1][k] = geo.e2[k]; R[2][k] = geo.e3[k]; }
+        for (int q = 0; q < 4; q++) {
+            const double xi = (q == 1 || q == 2) ? kGP : -kGP, eta = (q >= 2) ? kGP : -kGP;
+            double dxi[4], deta[4], ia, ib, ic, id;
+            dshape(xi, eta, dxi, deta);
+            const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
+            double xi_ = 0, yi_ = 0, xj_ = 0, yj_ = 0;
+            for (int n = 0; n < 4; n++) {   // select nodes ti, tj without dynamic register indexing
+                const double nxn = ia * dxi[n] + ib * deta[n], nyn = ic * dxi[n] + id * deta[n];
+                if (n == ti) { xi_ = nxn; yi_ = nyn; }
+                if (n == tj) { xj_ = nxn; yj_ = nyn; }
+            }
+            g += detJ * (xi_ * ((s0 * h) * xj_ + (s2 * h) * yj_) + yi_ * ((s2 * h) * xj_ + (s1 * h) * yj_));
+        }
+    }
+    if (skip) g = 0.0;
+    double G[6][6];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) G[a][b] = 0.0;
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) G[a][b] = skip ? 0.0 : (R[0][a] * g) * R[0][b] + (R[1][a] * g) * R[1][b] + (R[2][a] * g) * R[2][b];
+    if (ti == tj)   // diagonal block exactly symmetric (K_sigma is symmetrised, MITC4.py:1219)
+        for (int a = 0; a < 3; a++)
+            for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (G[a][b] + G[b][a]); G[a][b] = m; G[b][a] = m; }
+    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
+    for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Centrifugal prestress (MITC3.py:1633-1715 -> local [sxx,syy,sxy]; SOLID.py:268-320 -> global Voigt
+// [xx,yy,zz,xy,yz,zx]).  One thread per element; `ax` is the unit rotation axis, `ce` a point on it.
+// ------------------------------------------------------------------------------------------
+struct Vec3 { double v[3]; };
+
+template <int NN>
+__device__ __forceinline__ bool radial_dir(const double *x, const Vec3 &ax, const Vec3 &ce, double *rd, double &rr) {
+    double rv[3], rq[3];
+    for (int k = 0; k < 3; k++) {
+        double s = x[k];
+        for (int i = 1; i < NN; i++) s = s + x[3 * i + k];
+        rv[k] = s / (double)NN - ce.v[k];
+    }
+    const double d = dot3(rv, ax.v);
+    for (int k = 0; k < 3; k++) { const double par = d * ax.v[k]; rq[k] = rv[k] - par; }
+    rr = norm3(rq);
+    if (rr < 1e-10) return false;
+    for (int k = 0; k < 3; k++) rd[k] = rq[k] / rr;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void centrifugal_tri_kernel(const double *__restrict__ xyz,
+                                                              const int32_t *__restrict__ prop_id,
+                                                              const fs_shell_prop *__restrict__ props,
+                                                              double omega, Vec3 ax, Vec3 ce, int64_t E,
+                                                              double *__restrict__ sigma) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double x[3][3];
+    for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+    TriGeom geo;
+    tri_geometry(x, geo);
+    double rd[3], rr, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (radial_dir<3>(&x[0][0], ax, ce, rd, rr)) {
+        const double rho = props[prop_id[e]].rho;
+        const double sm = rho * (omega * omega) * rr * __builtin_sqrt(geo.area);
+        const double c = dot3(geo.e1, rd), sn = dot3(geo.e2, rd);
+        s0 = sm * (c * c); s1 = sm * (sn * sn); s2 = sm * c * sn;
+    }
+    sigma[e * 3] = s0; sigma[e * 3 + 1] = s1; sigma[e * 3 + 2] = s2;
+}
+
+template <int NN>
+__global__ __launch_bounds__(256) void centrifugal_solid_kernel(const double *__restrict__ xyz,
+                                                                const int32_t *__restrict__ prop_id,
+                                                                const double *__restrict__ props,
+                                                                double omega, Vec3 ax, Vec3 ce, int64_t E,
+                                                                double *__restrict__ sigma) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double x[NN * 3];
+    for (int c = 0; c < NN * 3; c++) x[c] = xyz[e * NN * 3 + c];
+    double rd[3], rr, sg[6] = {0, 0, 0, 0, 0, 0};
+    if (radial_dir<NN>(x, ax, ce, rd, rr)) {
+        double d[3];
+        for (int k = 0; k < 3; k++) {
+            double mn = x[k], mx = x[k];
+            for (int i = 1; i < NN; i++) { mn = __builtin_fmin(mn, x[3 * i + k]); mx = __builtin_fmax(mx, x[3 * i + k]); }
+            d[k] = mx - mn;
+        }
+        const double rho = props[(int64_t)prop_id[e] * 37 + 36];
+        const double sm = rho * (omega * omega) * rr * (norm3(d) / 1.732);
+        sg[0] = sm * rd[0] * rd[0]; sg[1] = sm * rd[1] * rd[1]; sg[2] = sm * rd[2] * rd[2];
+        sg[3] = sm * rd[0] * rd[1]; sg[4] = sm * rd[1] * rd[2]; sg[5] = sm * rd[0] * rd[2];
+    }
+    for (int c = 0; c < 6; c++) sigma[e * 6 + c] = sg[c];
+}
+
+// ------------------------------------------------------------------------------------------
 // Linear solids (elements/SOLID.py): TETRA4 / PYRAMID5 / WEDGE6 / HEXA8, 3 dofs per node.
 // Workgroup = EPB elements.  Phase 1: thread (element, Gauss point) -> Jacobian, w*detJ and the
 // physical gradients of all NN shape functions into LDS.  Phase 2: thread (element, node pair
@@ -1828,15 +2176,22 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
 int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
                        int32_t n_props, const double *u_e, int64_t E, uint32_t want, uint32_t layout,
                        double *Ke, double *Me, double *KTe, double *fe, int32_t *status, void *stream) {
-    (void)u_e; (void)KTe; (void)fe;
     if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_tri_batch: bad sizes");
     if (E == 0) return FS_OK;
     if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_shell_tri_batch: null input");
     if (layout != FS_LAYOUT_SYMBLK)
         return fail(FS_EINVAL, "fs_shell_tri_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
-    if (want & (FS_WANT_KT | FS_WANT_FINT))
-        return fail(FS_ENOSYS, "fs_shell_tri_batch: KT / FINT not implemented for MITC3 yet");
     hipStream_t s = (hipStream_t)stream;
+    if (want & (FS_WANT_KT | FS_WANT_FINT)) {
+        if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_tri_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
+        if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_tri_batch: fe is null");
+        hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
+                           props, E, KTe, status);
+        FS_LAUNCH_CHECK("mitc3_k_kernel");
+        hipLaunchKernelGGL(mitc3_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
+                           E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+        FS_LAUNCH_CHECK("mitc3_nl_kernel");
+    }
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_tri_batch: Ke is null");
         hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
@@ -1927,6 +2282,58 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
         default: launch_solid<4>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
     }
     FS_LAUNCH_CHECK("solid_kernel");
+    return FS_OK;
+}
+
+int fs_shell_kg_batch(int32_t nn, const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                      int32_t n_props, const double *sigma, int64_t E, uint32_t layout, double *KGe, void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_kg_batch: bad sizes");
+    if (nn != 3 && nn != 4) return fail(FS_EINVAL, "fs_shell_kg_batch: nn must be 3 (MITC3) or 4 (MITC4)");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !sigma || !KGe) return fail(FS_EINVAL, "fs_shell_kg_batch: null argument");
+    if (layout != FS_LAYOUT_SYMBLK)
+        return fail(FS_EINVAL, "fs_shell_kg_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
+    hipStream_t s = (hipStream_t)stream;
+    if (nn == 3)
+        hipLaunchKernelGGL(shell_kg_kernel<3>, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
+                           props, sigma, E, KGe);
+    else
+        hipLaunchKernelGGL(shell_kg_kernel<4>, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
+                           props, sigma, E, KGe);
+    FS_LAUNCH_CHECK("shell_kg_kernel");
+    return FS_OK;
+}
+
+int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const int32_t *prop_id,
+                             const void *props, int32_t n_props, double omega, const double *axis_host,
+                             const double *center_host, int64_t E, double *sigma, void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_centrifugal_prestress: bad sizes");
+    if (!axis_host || !center_host) return fail(FS_EINVAL, "fs_centrifugal_prestress: axis / center is null");
+    if (!solid && nn == 4)   // 'MITC4' object has no attribute 'compute_centrifugal_prestress'
+        return fail(FS_ENOSYS, "fs_centrifugal_prestress: the reference MITC4 has no compute_centrifugal_prestress");
+    if ((!solid && nn != 3) || (solid && nn != 4 && nn != 5 && nn != 6 && nn != 8))
+        return fail(FS_EINVAL, "fs_centrifugal_prestress: unsupported element");
+    const double la = sqrt(axis_host[0] * axis_host[0] + axis_host[1] * axis_host[1] + axis_host[2] * axis_host[2]);
+    if (!(la > 0.0)) return fail(FS_EINVAL, "fs_centrifugal_prestress: zero rotation axis");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !sigma) return fail(FS_EINVAL, "fs_centrifugal_prestress: null argument");
+    Vec3 ax, ce;
+    for (int k = 0; k < 3; k++) { ax.v[k] = axis_host[k] / la; ce.v[k] = center_host[k]; }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for(E, 256, INT32_MAX)), block(256);
+    if (!solid) {
+        hipLaunchKernelGGL(centrifugal_tri_kernel, grid, block, 0, s, xyz, prop_id, (const fs_shell_prop *)props, omega,
+                           ax, ce, E, sigma);
+    } else {
+        const double *pp = (const double *)props;
+        switch (nn) {
+            case 8: hipLaunchKernelGGL(centrifugal_solid_kernel<8>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+            case 6: hipLaunchKernelGGL(centrifugal_solid_kernel<6>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+            case 5: hipLaunchKernelGGL(centrifugal_solid_kernel<5>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+            default: hipLaunchKernelGGL(centrifugal_solid_kernel<4>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+        }
+    }
+    FS_LAUNCH_CHECK("centrifugal kernel");
     return FS_OK;
 }
 

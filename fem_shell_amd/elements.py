@@ -46,23 +46,93 @@ class FemElement:
         return f"<Element id={self.id} name={self.name}>"
 
 
+def _check_status(st, what):
+    if st:
+        raise ValueError(f"{what}: degenerate element geometry (status bits {int(st)})")
+
+
 class ShellElement(FemElement):
+    """Shared plumbing of the 6-DOF/node shells: one-element batches through fs_shell_quad_batch /
+    fs_shell_tri_batch / fs_shell_kg_batch."""
+    _NN = 0
+
     def __init__(self, name, node_coords, node_ids, material, dofs_per_node, thickness, nonlinear):
         super().__init__(name, node_coords, node_ids, material, dofs_per_node)
         self.thickness = thickness
         self.nonlinear = nonlinear
         self.element_family = ElementFamily.SHELL
 
+    def _device_inputs(self):
+        import torch
+        from . import batch
+        row = self._prop_row()
+        props = np.zeros(1, dtype=row.dtype)
+        props[0] = row
+        dev = batch._dev()
+        xyz = torch.from_numpy(self._initial_coords[None]).to(dev)
+        pid = torch.zeros(1, dtype=torch.int32, device=dev)
+        return xyz, pid, batch.to_device_props(props), dev
 
-def _check_status(st, what):
-    if st:
-        raise ValueError(f"{what}: degenerate element geometry (status bits {int(st)})")
+    def _run(self, **want):
+        from . import batch
+        xyz, pid, props, _ = self._device_inputs()
+        out = batch.shell_batch(self._NN, xyz, pid, props, 1, dense=True, **want)
+        _check_status(int(out["status"][0]), self.name)
+        return out
+
+    def update_configuration(self, displacements):
+        """elements/MITC4.py:1067-1084, MITC3.py:1144-1187 (the directors they also update are
+        unused by K_T / f_int)."""
+        n = 6 * self._NN
+        if len(displacements) != n:
+            raise ValueError(f"Expected {n} DOFs, got {len(displacements)}")
+        self._current_displacements = np.array(displacements, dtype=float)
+
+    def reset_configuration(self):
+        self._current_displacements = np.zeros(6 * self._NN)
+
+    def _run_nl(self, want_KT, want_F):
+        import torch
+        from . import batch
+        u = torch.from_numpy(self._current_displacements[None].copy()).to(batch._dev())
+        return self._run(want_K=False, u_e=u, want_KT=want_KT, want_F=want_F)
+
+    def compute_tangent_stiffness(self, sigma=None, transform_to_global=True):
+        """K_T = T^T sym(K0 + K_L + K_sigma) T (elements/MITC4.py:1246-1298, MITC3.py:1717-1777,
+        composite overrides); global axes only."""
+        if sigma is not None or not transform_to_global:
+            raise NotImplementedError("only sigma=None, transform_to_global=True are on the GPU path")
+        return np.ascontiguousarray(self._run_nl(True, False)["KT"][0].cpu().numpy())
+
+    def compute_internal_forces(self, transform_to_global=True):
+        """elements/MITC4.py:1300-1341, MITC3.py:1779-1832; global axes only."""
+        if not transform_to_global:
+            raise NotImplementedError("only transform_to_global=True is on the GPU path")
+        return np.ascontiguousarray(self._run_nl(False, True)["f_int"][0].cpu().numpy())
+
+    def compute_residual(self, f_ext, transform_to_global=True):
+        return f_ext - self.compute_internal_forces(transform_to_global=transform_to_global)
+
+    def compute_geometric_stiffness(self, sigma_membrane, transform_to_global=True):
+        """K_sigma from a LOCAL membrane stress [sxx, syy, sxy] (elements/MITC4.py:1191-1225,
+        MITC3.py:1501-1580); global axes only."""
+        import torch
+        from . import batch
+        if not transform_to_global:
+            raise NotImplementedError("only transform_to_global=True is on the GPU path")
+        xyz, pid, props, dev = self._device_inputs()
+        sg = np.asarray(sigma_membrane, dtype=np.float64)
+        if sg.shape == (2, 2):
+            sg = np.array([sg[0, 0], sg[1, 1], sg[0, 1]])
+        sg = torch.from_numpy(np.ascontiguousarray(sg.reshape(1, 3))).to(dev)
+        return np.ascontiguousarray(batch.shell_kg_batch(self._NN, xyz, pid, props, 1, sg, dense=True)[0].cpu().numpy())
 
 
 class MITC4(ShellElement):
     """MITC4+ quadrilateral shell, 6 DOF/node (elements/MITC4.py:26-99)."""
 
     vector_form = {"U": ("Ux", "Uy", "Uz"), "θ": ("θx", "θy", "θz")}
+    _NN = 4
 
     def __init__(self, node_coords, node_ids, material, thickness, shear_correction_factor=None,
                  nonlinear=False):
@@ -75,21 +145,8 @@ class MITC4(ShellElement):
         self._current_displacements = np.zeros(24)
         self._kappa_arg = shear_correction_factor
 
-    # -- property-table row (host) --------------------------------------------------------
     def _prop_row(self):
         return iso_row(self.material, self.thickness, self._kappa_arg, self.nonlinear)
-
-    def _run(self, **want):
-        import torch
-        from . import batch
-        props = np.zeros(1, dtype=self._prop_row().dtype)
-        props[0] = self._prop_row()
-        dev = batch._dev()
-        xyz = torch.from_numpy(self._initial_coords[None]).to(dev)
-        pid = torch.zeros(1, dtype=torch.int32, device=dev)
-        out = batch.quad_batch(xyz, pid, batch.to_device_props(props), 1, dense=True, **want)
-        _check_status(int(out["status"][0]), self.name)
-        return out
 
     @cached_property
     def K(self) -> np.ndarray:
@@ -100,37 +157,6 @@ class MITC4(ShellElement):
     def M(self) -> np.ndarray:
         """Consistent mass [24,24] (elements/MITC4.py:1038-1061)."""
         return np.ascontiguousarray(self._run(want_K=False, want_M=True)["M"][0].cpu().numpy())
-
-    def update_configuration(self, displacements):
-        """elements/MITC4.py:1067-1084 (the directors it also updates are unused by K_T / f_int)."""
-        if len(displacements) != 24:
-            raise ValueError(f"Expected 24 DOFs, got {len(displacements)}")
-        self._current_displacements = np.array(displacements, dtype=float)
-
-    def reset_configuration(self):
-        self._current_displacements = np.zeros(24)
-
-    def _run_nl(self, want_KT, want_F):
-        import torch
-        from . import batch
-        dev = batch._dev()
-        u = torch.from_numpy(self._current_displacements[None].copy()).to(dev)
-        return self._run(want_K=False, u_e=u, want_KT=want_KT, want_F=want_F)
-
-    def compute_tangent_stiffness(self, sigma=None, transform_to_global=True):
-        """K_T = T^T sym(K0 + K_L + K_sigma) T (elements/MITC4.py:1246-1298); global axes only."""
-        if sigma is not None or not transform_to_global:
-            raise NotImplementedError("only sigma=None, transform_to_global=True are on the GPU path")
-        return np.ascontiguousarray(self._run_nl(True, False)["KT"][0].cpu().numpy())
-
-    def compute_internal_forces(self, transform_to_global=True):
-        """elements/MITC4.py:1300-1341; global axes only."""
-        if not transform_to_global:
-            raise NotImplementedError("only transform_to_global=True is on the GPU path")
-        return np.ascontiguousarray(self._run_nl(False, True)["f_int"][0].cpu().numpy())
-
-    def compute_residual(self, f_ext, transform_to_global=True):
-        return f_ext - self.compute_internal_forces(transform_to_global=transform_to_global)
 
 
 class MITC4Composite(MITC4):
@@ -166,6 +192,7 @@ class MITC3(ShellElement):
     """MITC3+ triangular shell, 6 DOF/node (elements/MITC3.py:35-210)."""
 
     vector_form = {"U": ("Ux", "Uy", "Uz"), "θ": ("θx", "θy", "θz")}
+    _NN = 3
 
     def __init__(self, node_coords, node_ids, material, thickness, shear_correction_factor=None,
                  nonlinear=False):
@@ -176,6 +203,7 @@ class MITC3(ShellElement):
         if self._initial_coords.shape != (3, 3):
             raise ValueError("MITC3 needs 3 nodes with 3 coordinates each")
         self._kappa_arg = shear_correction_factor
+        self._current_displacements = np.zeros(18)
         # MITC3.py:375-418 raises at construction for a degenerate triangle
         v12, v13 = self._initial_coords[1] - self._initial_coords[0], self._initial_coords[2] - self._initial_coords[0]
         if np.linalg.norm(np.cross(v12, v13)) < 1e-12:
@@ -185,18 +213,6 @@ class MITC3(ShellElement):
         if isinstance(self.material, OrthotropicMaterial):
             raise NotImplementedError("Orthotropic material not yet supported in MITC3")
         return iso_row(self.material, self.thickness, self._kappa_arg, self.nonlinear)
-
-    def _run(self, **want):
-        import torch
-        from . import batch
-        props = np.zeros(1, dtype=self._prop_row().dtype)
-        props[0] = self._prop_row()
-        dev = batch._dev()
-        xyz = torch.from_numpy(self._initial_coords[None]).to(dev)
-        pid = torch.zeros(1, dtype=torch.int32, device=dev)
-        out = batch.tri_batch(xyz, pid, batch.to_device_props(props), 1, dense=True, **want)
-        _check_status(int(out["status"][0]), self.name)
-        return out
 
     @cached_property
     def K(self) -> np.ndarray:
@@ -212,6 +228,13 @@ class MITC3(ShellElement):
         """elements/MITC3.py:427-447."""
         x = self._initial_coords
         return 0.5 * float(np.linalg.norm(np.cross(x[1] - x[0], x[2] - x[0])))
+
+    def compute_centrifugal_prestress(self, omega, rotation_axis, rotation_center) -> np.ndarray:
+        """elements/MITC3.py:1633-1715: local membrane stress [sxx, syy, sxy] of a rotating structure."""
+        from . import batch
+        xyz, pid, props, _ = self._device_inputs()
+        return np.ascontiguousarray(batch.centrifugal_prestress(False, 3, xyz, pid, props, 1, omega,
+                                                                rotation_axis, rotation_center)[0].cpu().numpy())
 
 
 class MITC3Composite(MITC3):
@@ -297,6 +320,18 @@ class SolidElement(FemElement):
     def compute_geometric_stiffness(self, sigma_membrane, transform_to_global=True) -> np.ndarray:
         """elements/SOLID.py:322-374 (Voigt stress xx,yy,zz,xy,yz,zx in global axes)."""
         return np.ascontiguousarray(self._run(want_K=False, sigma=sigma_membrane)["KG"][0].cpu().numpy())
+
+    def compute_centrifugal_prestress(self, omega, rotation_axis, rotation_center) -> np.ndarray:
+        """elements/SOLID.py:268-320: global Voigt stress [xx,yy,zz,xy,yz,zx]."""
+        import torch
+        from . import batch
+        from .properties import solid_row
+        dev = batch._dev()
+        xyz = torch.from_numpy(np.ascontiguousarray(self.node_coords, dtype=np.float64)[None]).to(dev)
+        pid = torch.zeros(1, dtype=torch.int32, device=dev)
+        props = batch.to_device_solid_props(solid_row(self.material, self.orientation)[None])
+        return np.ascontiguousarray(batch.centrifugal_prestress(True, self._NN, xyz, pid, props, 1, omega,
+                                                                rotation_axis, rotation_center)[0].cpu().numpy())
 
 
 def _solid_class(name, nn, doc):

@@ -19,9 +19,9 @@ FS_PROP_LAMINATE = 2
 PROP_DTYPE = np.dtype([
     ("A", "f8", (9,)), ("B", "f8", (9,)), ("D", "f8", (9,)), ("Cs", "f8", (4,)),
     ("h", "f8"), ("m_t", "f8"), ("m_r", "f8"), ("k_drill", "f8"), ("C_raw", "f8", (9,)),
-    ("flags", "i4"), ("nonlinear", "i4"),
+    ("rho", "f8"), ("flags", "i4"), ("nonlinear", "i4"),
 ])
-assert PROP_DTYPE.itemsize == 360
+assert PROP_DTYPE.itemsize == 368
 
 
 @dataclass
@@ -76,6 +76,7 @@ def iso_row(material, thickness, shear_correction_factor: Optional[float] = None
     row["m_r"] = material.rho * h**3 / 12.0
     row["k_drill"] = E * (h**2) * 0.15
     row["C_raw"] = (E / (1 - nu**2) * shape).ravel()
+    row["rho"] = material.rho
     row["flags"] = 0
     row["nonlinear"] = int(bool(nonlinear))
     return row
@@ -94,6 +95,7 @@ def laminate_row(lam: Laminate, nonlinear: bool = False) -> np.ndarray:
     row["m_r"] = sum(p.material.rho * (p.z_top**3 - p.z_bottom**3) / 3 for p in lam.plies)
     row["k_drill"] = np.trace(lam.A) / 3.0 * h * 0.15
     row["C_raw"] = (lam.A / h).ravel()
+    row["rho"] = lam.plies[0].material.rho   # equivalent material of the composite classes (MITC3_composite.py:121,133)
     row["flags"] = FS_PROP_LAMINATE | (0 if lam.is_symmetric else FS_PROP_COUPLED)
     row["nonlinear"] = int(bool(nonlinear))
     return row

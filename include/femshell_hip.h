@@ -63,9 +63,10 @@ typedef struct fs_shell_prop {
     double m_r;       /* rotational inertia / area    */
     double k_drill;   /* drilling stabilisation factor */
     double C_raw[9];  /* membrane stress-strain (Cm/h) */
+    double rho;       /* density used by the centrifugal prestress (laminates: first ply) */
     int32_t flags;    /* FS_PROP_*                    */
     int32_t nonlinear;
-} fs_shell_prop;      /* 360 bytes */
+} fs_shell_prop;      /* 368 bytes */
 
 const char *fs_last_error(void);
 /* library / device probe: returns FS_OK when a gfx950 device is usable; fills name (<=len). */
@@ -95,7 +96,10 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
  * (elements/MITC3.py:103-210,375-418), K (:1077-1103 with k_m :1009-1037, _k_bs_condensed :935-1007,
  * tying :796-933, MITC3Composite._coupling_stiffness MITC3_composite.py:204-240) and M (:1105-1138).
  * Same arguments as fs_shell_quad_batch with xyz [E][3][3]; FS_LAYOUT_SYMBLK has 6 pair blocks per
- * element.  FS_WANT_KT / FS_WANT_FINT return FS_ENOSYS (u_e, KTe, fe reserved).
+ * element.  With u_e [E][18]: FS_WANT_KT / FS_WANT_FINT = update_configuration(u_e) +
+ * compute_tangent_stiffness() / compute_internal_forces() (MITC3.py:1144-1832, MITC3_composite.py:496-621;
+ * the reference rebuilds T() from the CURRENT coordinates x + u, :471-494 -- kept); KTe is also the
+ * FINT workspace, fe [E][18].
  * status: FS_ST_NAN_FRAME where the reference raises ValueError("Degenerate triangle").
  */
 int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
@@ -122,6 +126,33 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
                    const double *props, int32_t n_props, int64_t E, uint32_t want, uint32_t layout,
                    const double *body_host, const double *sigma, double *Ke, double *Me, double *fe,
                    double *KGe, int32_t *status, void *stream);
+
+/*
+ * Shell geometric stiffness from a given membrane stress: per element
+ * compute_geometric_stiffness(sigma, transform_to_global=True) (MITC4.py:1191-1225, MITC3.py:1501-1580),
+ * the element call of MeshAssembler.assemble_geometric_stiffness (core/assembler.py:483-513).
+ *   nn      3 (MITC3) or 4 (MITC4);  xyz [E][nn][3]
+ *   sigma   [E][3] device: [sxx, syy, sxy] in the element's LOCAL axes; elements with
+ *           max|sigma| < 1e-20 yield zero blocks (skipped by the reference, :498-500)
+ *   KGe     FS_LAYOUT_SYMBLK [E][nn(nn+1)/2][36]
+ */
+int fs_shell_kg_batch(int32_t nn, const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                      int32_t n_props, const double *sigma, int64_t E, uint32_t layout, double *KGe,
+                      void *stream);
+
+/*
+ * Centrifugal prestress of every element (the `omega` mode of assemble_geometric_stiffness,
+ * core/assembler.py:487-493): compute_centrifugal_prestress of MITC3 (MITC3.py:1633-1715 ->
+ * sigma [E][3] local [sxx,syy,sxy]) or of the linear solids (SOLID.py:268-320 -> sigma [E][6]
+ * global Voigt [xx,yy,zz,xy,yz,zx]).
+ *   solid   0: shells (nn = 3; nn = 4 returns FS_ENOSYS -- the reference MITC4 has no such method),
+ *           1: solids (nn = 4, 5, 6, 8)
+ *   props   fs_shell_prop rows (rho field) for shells, [n_props][37] rows for solids (rho = column 36)
+ *   axis_host, center_host   3 doubles each in HOST memory; the axis is normalised here
+ */
+int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const int32_t *prop_id,
+                             const void *props, int32_t n_props, double omega, const double *axis_host,
+                             const double *center_host, int64_t E, double *sigma, void *stream);
 
 /* Geometry stage only, for bit-exactness tests against the oracle:
  * frame[E][9] (e1,e2,e3), xl[E][8], detJ[E][4], acoef[E][5] (a_A..a_E). */

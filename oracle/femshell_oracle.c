@@ -885,13 +885,14 @@ static void tri_rotate(const tri_t *t, const double *Kl, double *Kg) { /* T^T K 
         }
 }
 
-int fso_mitc3_K(const double *xyz, const fso_shell_prop *p, double *Ke) { /* MITC3.py:1077-1103 */
-    tri_t t;
-    tri_init(&t, xyz);
-    double km[324], Kext[400], Kl[324], Kg[324];
-    memset(km, 0, sizeof km); memset(Kext, 0, sizeof Kext);
-    double Bm[3][18], kc[324];
-    memset(Bm, 0, sizeof Bm); memset(kc, 0, sizeof kc);
+/* local parts of MITC3.K: km = membrane CST + drilling (MITC3.py:1009-1037), kbs = condensed and
+ * symmetrised bending+shear (:935-1007), kc = membrane-bending coupling (MITC3_composite.py:204-240) */
+static void tri_k_local(const tri_t *tp, const fso_shell_prop *p, double *km, double *kbs_sym, double *kc) {
+    const tri_t t = *tp;
+    double Kext[400];
+    memset(km, 0, 324 * sizeof(double)); memset(Kext, 0, sizeof Kext);
+    double Bm[3][18];
+    memset(Bm, 0, sizeof Bm); memset(kc, 0, 324 * sizeof(double));
     for (int i = 0; i < 3; i++) {
         Bm[0][6 * i] = t.dhx[i]; Bm[1][6 * i + 1] = t.dhy[i];
         Bm[2][6 * i] = t.dhy[i]; Bm[2][6 * i + 1] = t.dhx[i];
@@ -935,14 +936,291 @@ int fso_mitc3_K(const double *xyz, const fso_shell_prop *p, double *Ke) { /* MIT
         }
     }
     for (int i = 0; i < 18; i++)
+        for (int j = 0; j < 18; j++) kbs_sym[i * 18 + j] = 0.5 * (kbs[i * 18 + j] + kbs[j * 18 + i]);
+}
+
+int fso_mitc3_K(const double *xyz, const fso_shell_prop *p, double *Ke) { /* MITC3.py:1077-1103 */
+    tri_t t;
+    tri_init(&t, xyz);
+    double km[324], kbs[324], kc[324], Kl[324], Kg[324];
+    tri_k_local(&t, p, km, kbs, kc);
+    for (int i = 0; i < 18; i++)
         for (int j = 0; j < 18; j++) {
-            Kl[i * 18 + j] = km[i * 18 + j] + 0.5 * (kbs[i * 18 + j] + kbs[j * 18 + i]);
+            Kl[i * 18 + j] = km[i * 18 + j] + kbs[i * 18 + j];
             if (p->flags & FSO_PROP_COUPLED) Kl[i * 18 + j] += kc[i * 18 + j];
         }
     tri_rotate(&t, Kl, Kg);
     for (int i = 0; i < 18; i++)
         for (int j = 0; j < 18; j++) Ke[i * 18 + j] = 0.5 * (Kg[i * 18 + j] + Kg[j * 18 + i]);
     return t.status;
+}
+
+/* rotation with an explicit frame R (rows e1,e2,e3): Kg = T^T Kl T ; vectors: to_local ? T u : T^T u */
+static void tri_rotate_R(const double R[3][3], const double *Kl, double *Kg) {
+    tri_t t;
+    memcpy(t.e1, R[0], 24); memcpy(t.e2, R[1], 24); memcpy(t.e3, R[2], 24);
+    tri_rotate(&t, Kl, Kg);
+}
+static void tri_rotate_vec(const double R[3][3], const double *u, double *out, int to_local) {
+    for (int b = 0; b < 6; b++)
+        for (int a = 0; a < 3; a++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (to_local ? R[a][k] : R[k][a]) * u[3 * b + k];
+            out[3 * b + a] = s;
+        }
+}
+
+/* MITC3 total-Lagrangian tangent / internal force after update_configuration(u)
+ * (MITC3.py:1144-1187, 1198-1258, 1334-1447, 1449-1580, 1582-1631, 1717-1832; composite overrides
+ * MITC3_composite.py:246-265, 496-621).  Quirks kept: every derivative, the area and K0 come from the
+ * INITIAL geometry (cached _local_coordinates / _dH_cache), while T() is rebuilt from the CURRENT
+ * coordinates x + u (MITC3.py:471-494); H mixes global displacement components with local
+ * derivatives (:1198-1225). */
+int fso_mitc3_NL(const double *xyz, const fso_shell_prop *p, const double *u, double *KT, double *f) {
+    tri_t t;
+    tri_init(&t, xyz);
+    double km[324], kbs[324], kc[324], K0[324];
+    tri_k_local(&t, p, km, kbs, kc);
+    const int coupled = (p->flags & FSO_PROP_COUPLED) != 0;
+    for (int i = 0; i < 324; i++) K0[i] = km[i] + kbs[i] + (coupled ? kc[i] : 0.0);
+    /* T() from the current coordinates */
+    double R[3][3];
+    {
+        double xc[3][3], v12[3], v13[3], n[3];
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < 3; k++) xc[i][k] = t.x[i][k] + u[6 * i + k];
+        for (int k = 0; k < 3; k++) { v12[k] = xc[1][k] - xc[0][k]; v13[k] = xc[2][k] - xc[0][k]; }
+        double l = norm3(v12);
+        for (int k = 0; k < 3; k++) R[0][k] = v12[k] / l;
+        cross3(v12, v13, n);
+        l = norm3(n);
+        for (int k = 0; k < 3; k++) R[2][k] = n[k] / l;
+        cross3(R[2], R[0], R[1]);
+    }
+    double ul[18];
+    tri_rotate_vec(R, u, ul, 1);
+    if (!p->nonlinear) {
+        if (KT) tri_rotate_R(R, K0, KT); /* MITC3.py:1728-1732, not symmetrised */
+        if (f) { /* MITC3.py:1786-1832 with the linear membrane branch */
+            double fl[18];
+            for (int i = 0; i < 18; i++) {
+                double s = 0;
+                for (int j = 0; j < 18; j++) s += (kbs[i * 18 + j] + (coupled ? kc[i * 18 + j] : 0.0)) * ul[j];
+                fl[i] = s;
+            }
+            for (int g = 0; g < 3; g++) {
+                double r = TRI_GP[g][0], s = TRI_GP[g][1], w = 1.0 / 3.0;
+                double h[3] = {1.0 - r - s, r, s}, Bd[18], bu = 0;
+                memset(Bd, 0, sizeof Bd);
+                for (int i = 0; i < 3; i++) { Bd[6 * i] = -0.5 * t.dhy[i]; Bd[6 * i + 1] = 0.5 * t.dhx[i]; Bd[6 * i + 5] = -h[i]; }
+                for (int i = 0; i < 18; i++) bu += Bd[i] * ul[i];
+                for (int i = 0; i < 18; i++) fl[i] += p->k_drill * (Bd[i] * bu) * w * t.area;
+            }
+            for (int g = 0; g < 3; g++) {
+                double eps[3] = {0, 0, 0}, sm[3], w = 1.0 / 3.0;
+                for (int i = 0; i < 3; i++) {
+                    eps[0] += t.dhx[i] * ul[6 * i]; eps[1] += t.dhy[i] * ul[6 * i + 1];
+                    eps[2] += t.dhy[i] * ul[6 * i] + t.dhx[i] * ul[6 * i + 1];
+                }
+                for (int a = 0; a < 3; a++) sm[a] = p->C_raw[a * 3] * eps[0] + p->C_raw[a * 3 + 1] * eps[1] + p->C_raw[a * 3 + 2] * eps[2];
+                for (int i = 0; i < 3; i++) {
+                    fl[6 * i] += (t.dhx[i] * sm[0] + t.dhy[i] * sm[2]) * w * t.area * p->h;
+                    fl[6 * i + 1] += (t.dhy[i] * sm[1] + t.dhx[i] * sm[2]) * w * t.area * p->h;
+                }
+            }
+            tri_rotate_vec(R, fl, f, 0);
+        }
+        return t.status;
+    }
+    /* sigma at the centroid (MITC3.py:1582-1631; laminate MITC3_composite.py:496-505) */
+    double sig[3];
+    {
+        double eps[3] = {0, 0, 0}, kap[3] = {0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            eps[0] += t.dhx[i] * ul[6 * i]; eps[1] += t.dhy[i] * ul[6 * i + 1];
+            eps[2] += t.dhy[i] * ul[6 * i] + t.dhx[i] * ul[6 * i + 1];
+            kap[0] += t.dhx[i] * ul[6 * i + 4]; kap[1] += -t.dhy[i] * ul[6 * i + 3];
+            kap[2] += t.dhy[i] * ul[6 * i + 4] - t.dhx[i] * ul[6 * i + 3];
+        }
+        for (int a = 0; a < 3; a++) {
+            if (p->flags & FSO_PROP_LAMINATE) {
+                double s1 = 0, s2 = 0;
+                for (int c = 0; c < 3; c++) { s1 += p->A[a * 3 + c] * eps[c]; s2 += p->B[a * 3 + c] * kap[c]; }
+                sig[a] = (s1 + s2) / p->h;
+            } else {
+                double s1 = 0;
+                for (int c = 0; c < 3; c++) s1 += p->C_raw[a * 3 + c] * eps[c];
+                sig[a] = s1;
+            }
+        }
+    }
+    /* H (constant over the CST): global components, local derivatives */
+    double H[3][3];
+    memset(H, 0, sizeof H);
+    for (int c = 0; c < 3; c++)
+        for (int i = 0; i < 3; i++) { H[c][0] += u[6 * i + c] * t.dhx[i]; H[c][1] += u[6 * i + c] * t.dhy[i]; }
+    double BL[3][18], BNL[3][18], BG[6][18];
+    memset(BL, 0, sizeof BL); memset(BNL, 0, sizeof BNL); memset(BG, 0, sizeof BG);
+    for (int i = 0; i < 3; i++) {
+        int c = 6 * i;
+        BL[0][c] = t.dhx[i]; BL[1][c + 1] = t.dhy[i]; BL[2][c] = t.dhy[i]; BL[2][c + 1] = t.dhx[i];
+        for (int k = 0; k < 3; k++) {
+            BNL[0][c + k] = H[k][0] * t.dhx[i];
+            BNL[1][c + k] = H[k][1] * t.dhy[i];
+            BNL[2][c + k] = H[k][0] * t.dhy[i] + H[k][1] * t.dhx[i];
+            BG[2 * k][c + k] = t.dhx[i]; BG[2 * k + 1][c + k] = t.dhy[i];
+        }
+    }
+    if (KT) {
+        double KL[324], Ks[324], S[36], Kt[324], Kt2[324];
+        memset(KL, 0, sizeof KL); memset(Ks, 0, sizeof Ks); memset(S, 0, sizeof S);
+        for (int k = 0; k < 3; k++) {
+            S[(2 * k) * 6 + 2 * k] = sig[0] * p->h; S[(2 * k) * 6 + 2 * k + 1] = sig[2] * p->h;
+            S[(2 * k + 1) * 6 + 2 * k] = sig[2] * p->h; S[(2 * k + 1) * 6 + 2 * k + 1] = sig[1] * p->h;
+        }
+        for (int g = 0; g < 3; g++) {
+            double w = (1.0 / 3.0) * t.area;
+            btcb_n(KL, 18, w * p->h, &BL[0][0], 3, p->C_raw, &BNL[0][0], 3);
+            btcb_n(KL, 18, w * p->h, &BNL[0][0], 3, p->C_raw, &BL[0][0], 3);
+            btcb_n(KL, 18, w * p->h, &BNL[0][0], 3, p->C_raw, &BNL[0][0], 3);
+            btcb_n(Ks, 18, w, &BG[0][0], 6, S, &BG[0][0], 6);
+        }
+        for (int i = 0; i < 18; i++)
+            for (int j = 0; j < 18; j++)
+                Kt[i * 18 + j] = K0[i * 18 + j] + KL[i * 18 + j] + 0.5 * (Ks[i * 18 + j] + Ks[j * 18 + i]);
+        for (int i = 0; i < 18; i++)
+            for (int j = 0; j < 18; j++) Kt2[i * 18 + j] = 0.5 * (Kt[i * 18 + j] + Kt[j * 18 + i]);
+        tri_rotate_R(R, Kt2, KT);
+    }
+    if (f) {
+        double fl[18];
+        for (int i = 0; i < 18; i++) {
+            double s = 0;
+            for (int j = 0; j < 18; j++) s += (kbs[i * 18 + j] + (coupled ? kc[i * 18 + j] : 0.0)) * ul[j];
+            fl[i] = s;
+        }
+        for (int g = 0; g < 3; g++) {
+            double r = TRI_GP[g][0], s = TRI_GP[g][1], w = 1.0 / 3.0;
+            double h[3] = {1.0 - r - s, r, s}, Bd[18], bu = 0;
+            memset(Bd, 0, sizeof Bd);
+            for (int i = 0; i < 3; i++) { Bd[6 * i] = -0.5 * t.dhy[i]; Bd[6 * i + 1] = 0.5 * t.dhx[i]; Bd[6 * i + 5] = -h[i]; }
+            for (int i = 0; i < 18; i++) bu += Bd[i] * ul[i];
+            for (int i = 0; i < 18; i++) fl[i] += p->k_drill * (Bd[i] * bu) * w * t.area;
+        }
+        double E[3][3];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                double hh = 0;
+                for (int k = 0; k < 3; k++) hh += H[k][a] * H[k][b];
+                E[a][b] = 0.5 * (H[a][b] + H[b][a] + hh);
+            }
+        double eps[3] = {E[0][0], E[1][1], 2 * E[0][1]}, sm[3];
+        for (int a = 0; a < 3; a++) sm[a] = p->C_raw[a * 3] * eps[0] + p->C_raw[a * 3 + 1] * eps[1] + p->C_raw[a * 3 + 2] * eps[2];
+        for (int g = 0; g < 3; g++) {
+            double w = 1.0 / 3.0;
+            for (int i = 0; i < 18; i++) {
+                double s = 0;
+                for (int r = 0; r < 3; r++) s += (BL[r][i] + BNL[r][i]) * sm[r];
+                fl[i] += s * w * t.area * p->h;
+            }
+        }
+        tri_rotate_vec(R, fl, f, 0);
+    }
+    return t.status;
+}
+
+/* shell geometric stiffness from a given local membrane stress [sxx, syy, sxy]
+ * (MITC4.py:1191-1225, MITC3.py:1501-1580), nn = 3 or 4; KG [6nn][6nn] global axes.  Returns 1 and a
+ * zero matrix when max|sigma| < 1e-20 (the assembler skips the element, core/assembler.py:498-500). */
+int fso_shell_KG(int nn, const double *xyz, const fso_shell_prop *p, const double *sigma, double *KG) {
+    const int nd = 6 * nn;
+    memset(KG, 0, (size_t)nd * nd * sizeof(double));
+    double mx = fmax(fabs(sigma[0]), fmax(fabs(sigma[1]), fabs(sigma[2])));
+    if (mx < 1e-20) return 1;
+    double S[36];
+    memset(S, 0, sizeof S);
+    for (int k = 0; k < 3; k++) {
+        S[(2 * k) * 6 + 2 * k] = sigma[0] * p->h; S[(2 * k) * 6 + 2 * k + 1] = sigma[2] * p->h;
+        S[(2 * k + 1) * 6 + 2 * k] = sigma[2] * p->h; S[(2 * k + 1) * 6 + 2 * k + 1] = sigma[1] * p->h;
+    }
+    if (nn == 4) {
+        geom_t g;
+        geom_init(&g, xyz);
+        double Ks[576], Ksym[576];
+        memset(Ks, 0, sizeof Ks);
+        for (int gp = 0; gp < 4; gp++) {
+            double xi, eta, dNdx[4], dNdy[4], BG[6][24];
+            gauss_point(gp, &xi, &eta);
+            double det = dH(&g, xi, eta, dNdx, dNdy);
+            memset(BG, 0, sizeof BG);
+            for (int i = 0; i < 4; i++)
+                for (int k = 0; k < 3; k++) { BG[2 * k][6 * i + k] = dNdx[i]; BG[2 * k + 1][6 * i + k] = dNdy[i]; }
+            btcb(Ks, det, &BG[0][0], 6, S, &BG[0][0], 6, 24);
+        }
+        for (int i = 0; i < 24; i++)
+            for (int j = 0; j < 24; j++) Ksym[i * 24 + j] = 0.5 * (Ks[i * 24 + j] + Ks[j * 24 + i]);
+        rotate_to_global(&g, Ksym, KG);
+        return 0;
+    }
+    tri_t t;
+    tri_init(&t, xyz);
+    double Ks[324], Ksym[324], BG[6][18];
+    memset(Ks, 0, sizeof Ks); memset(BG, 0, sizeof BG);
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) { BG[2 * k][6 * i + k] = t.dhx[i]; BG[2 * k + 1][6 * i + k] = t.dhy[i]; }
+    for (int g = 0; g < 3; g++) btcb_n(Ks, 18, (1.0 / 3.0) * t.area, &BG[0][0], 6, S, &BG[0][0], 6);
+    for (int i = 0; i < 18; i++)
+        for (int j = 0; j < 18; j++) Ksym[i * 18 + j] = 0.5 * (Ks[i * 18 + j] + Ks[j * 18 + i]);
+    tri_rotate(&t, Ksym, KG);
+    return 0;
+}
+
+/* centrifugal prestress: MITC3 (MITC3.py:1633-1715) -> local [sxx, syy, sxy];
+ * solids (SOLID.py:268-320) -> global Voigt [xx,yy,zz,xy,yz,zx].  `axis` is normalised here. */
+static int centrifugal_radial(int nn, const double *xyz, const double *axis_in, const double *center,
+                              double *axis, double *rdir, double *r_radial) {
+    double la = norm3(axis_in), c[3] = {0, 0, 0}, rv[3], rp[3], rr[3];
+    for (int k = 0; k < 3; k++) axis[k] = axis_in[k] / la;
+    for (int k = 0; k < 3; k++) { /* np.mean(axis=0): pairwise == sequential for n <= 8 */
+        double s = 0;
+        for (int i = 0; i < nn; i++) s += xyz[3 * i + k];
+        c[k] = s / nn;
+    }
+    for (int k = 0; k < 3; k++) rv[k] = c[k] - center[k];
+    double d = dot3(rv, axis);
+    for (int k = 0; k < 3; k++) { rp[k] = d * axis[k]; rr[k] = rv[k] - rp[k]; }
+    *r_radial = norm3(rr);
+    if (*r_radial < 1e-10) return 0;
+    for (int k = 0; k < 3; k++) rdir[k] = rr[k] / *r_radial;
+    return 1;
+}
+int fso_mitc3_centrifugal(const double *xyz, double rho, double omega, const double *axis_in,
+                          const double *center, double *sigma) {
+    tri_t t;
+    tri_init(&t, xyz);
+    double axis[3], rd[3], rr;
+    sigma[0] = sigma[1] = sigma[2] = 0.0;
+    if (!centrifugal_radial(3, xyz, axis_in, center, axis, rd, &rr)) return t.status;
+    double L = sqrt(t.area), s = rho * (omega * omega) * rr * L;
+    double c = dot3(t.e1, rd), sn = dot3(t.e2, rd);
+    sigma[0] = s * (c * c); sigma[1] = s * (sn * sn); sigma[2] = s * c * sn;
+    return t.status;
+}
+int fso_solid_centrifugal(int nn, const double *xyz, double rho, double omega, const double *axis_in,
+                          const double *center, double *sigma) {
+    double axis[3], rd[3], rr;
+    for (int k = 0; k < 6; k++) sigma[k] = 0.0;
+    if (!centrifugal_radial(nn, xyz, axis_in, center, axis, rd, &rr)) return 0;
+    double d[3];
+    for (int k = 0; k < 3; k++) {
+        double mn = xyz[k], mx = xyz[k];
+        for (int i = 1; i < nn; i++) { mn = fmin(mn, xyz[3 * i + k]); mx = fmax(mx, xyz[3 * i + k]); }
+        d[k] = mx - mn;
+    }
+    double L = norm3(d) / 1.732, s = rho * (omega * omega) * rr * L;
+    sigma[0] = s * rd[0] * rd[0]; sigma[1] = s * rd[1] * rd[1]; sigma[2] = s * rd[2] * rd[2];
+    sigma[3] = s * rd[0] * rd[1]; sigma[4] = s * rd[1] * rd[2]; sigma[5] = s * rd[0] * rd[2];
+    return 0;
 }
 
 int fso_mitc3_M(const double *xyz, const fso_shell_prop *p, double *Me) { /* MITC3.py:1105-1138 */

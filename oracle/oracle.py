@@ -15,9 +15,9 @@ _LIB = None
 PROP_DTYPE = np.dtype([
     ("A", "f8", (9,)), ("B", "f8", (9,)), ("D", "f8", (9,)), ("Cs", "f8", (4,)),
     ("h", "f8"), ("m_t", "f8"), ("m_r", "f8"), ("k_drill", "f8"), ("C_raw", "f8", (9,)),
-    ("flags", "i4"), ("nonlinear", "i4"),
+    ("rho", "f8"), ("flags", "i4"), ("nonlinear", "i4"),
 ])
-assert PROP_DTYPE.itemsize == 360
+assert PROP_DTYPE.itemsize == 368
 
 
 def build():
@@ -123,6 +123,40 @@ def mitc4_NL(xyz, prop, u):
     KT = np.zeros((24, 24)); f = np.zeros(24)
     st = lib().fso_mitc4_NL(_p(xyz), _p(prop), _p(u), _p(KT), _p(f))
     return KT, f, st
+
+
+def mitc3_NL(xyz, prop, u):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(3, 3)
+    prop = as_props(prop).reshape(-1)[:1]
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(18)
+    KT = np.zeros((18, 18)); f = np.zeros(18)
+    st = lib().fso_mitc3_NL(_p(xyz), _p(prop), _p(u), _p(KT), _p(f))
+    return KT, f, st
+
+
+def shell_KG(xyz, prop, sigma):
+    """compute_geometric_stiffness(sigma_local[3]) of a MITC3 (xyz [3,3]) or MITC4 (xyz [4,3])."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    nn = xyz.shape[0]
+    prop = as_props(prop).reshape(-1)[:1]
+    sg = np.ascontiguousarray(sigma, dtype=np.float64).reshape(3)
+    KG = np.zeros((6 * nn, 6 * nn))
+    lib().fso_shell_KG(ctypes.c_int(nn), _p(xyz), _p(prop), _p(sg), _p(KG))
+    return KG
+
+
+def centrifugal(xyz, rho, omega, axis, center, shell=True):
+    """compute_centrifugal_prestress: MITC3 (local [sxx,syy,sxy]) or a linear solid (Voigt 6)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    ax = np.ascontiguousarray(axis, dtype=np.float64); ce = np.ascontiguousarray(center, dtype=np.float64)
+    if shell:
+        out = np.zeros(3)
+        lib().fso_mitc3_centrifugal(_p(xyz), ctypes.c_double(rho), ctypes.c_double(omega), _p(ax), _p(ce), _p(out))
+    else:
+        out = np.zeros(6)
+        lib().fso_solid_centrifugal(ctypes.c_int(xyz.shape[0]), _p(xyz), ctypes.c_double(rho),
+                                    ctypes.c_double(omega), _p(ax), _p(ce), _p(out))
+    return out
 
 
 def csr_assemble(dofs, ndof, vals_e):

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"{n} declared in include/femshell_hip.h but not exported"
     from fem_shell_amd import _lib
     assert set(_lib.SIGNATURES) == names
-    assert ctypes.sizeof(ctypes.c_double) * 44 + 8 == fsa.properties.PROP_DTYPE.itemsize == 360
+    assert ctypes.sizeof(ctypes.c_double) * 45 + 8 == fsa.properties.PROP_DTYPE.itemsize == 368
 
 
 def test_laminate_rows_bitwise():

@@ -132,3 +132,56 @@ def test_solids_vs_reference(oracle, nn):
         x = xyz[0]
         vol = 0.5 * abs(np.linalg.det(np.stack([x[1] - x[0], x[2] - x[0], x[3] - x[0]])))
         assert abs(g["M6"][0][0::3, 0::3].sum() / (props[0, 36] * vol) - 2.0) < 1e-12
+
+
+def test_mitc3_nonlinear_vs_reference(oracle):
+    """MITC3 / MITC3Composite TL tangent and internal force after update_configuration
+    (elements/MITC3.py:1144-1832, MITC3_composite.py:496-621), incl. the T()-from-current-coords quirk."""
+    g = golden("elem_nl3")
+    props = golden_props(g)
+    assert props["nonlinear"].min() == 0 and props["nonlinear"].max() == 1
+    worst = [0.0, 0.0]
+    for e in range(g["xyz"].shape[0]):
+        KT, f, st = oracle.mitc3_NL(g["xyz"][e], props[e:e + 1], g["u"][e])
+        assert st == 0
+        ek = np.abs(KT - g["KT"][e]).max() / np.abs(g["KT"][e]).max()
+        fs = np.abs(g["f_int"][e]).max()
+        ef = np.abs(f - g["f_int"][e]).max() / fs if fs > 0 else np.abs(f).max()
+        worst = [max(worst[0], ek), max(worst[1], ef)]
+        assert ek <= 1e-12 and ef <= 1e-11, (e, ek, ef)
+    print("oracle MITC3 KT / f_int vs reference", worst)
+
+
+@pytest.mark.parametrize("nn", [4, 3])
+def test_shell_geometric_stiffness_vs_reference(oracle, nn):
+    """compute_geometric_stiffness(sigma) of MITC4 / MITC3 (+ composites): MITC4.py:1191-1225,
+    MITC3.py:1501-1580."""
+    g = golden("prestress")
+    props = golden_props(g, f"prop{nn}_")
+    for e in range(g[f"xyz{nn}"].shape[0]):
+        KG = oracle.shell_KG(g[f"xyz{nn}"][e], props[e:e + 1], g[f"sigma{nn}"][e])
+        ref = g[f"KG{nn}"][e]
+        if np.abs(g[f"sigma{nn}"][e]).max() < 1e-20:      # skipped by the assembler -> zero block
+            assert not KG.any()
+            continue
+        assert np.abs(KG - ref).max() <= 1e-13 * np.abs(ref).max(), e
+
+
+def test_centrifugal_prestress_vs_reference(oracle):
+    """compute_centrifugal_prestress: MITC3.py:1633-1715 and SOLID.py:268-320."""
+    g = golden("prestress")
+    props = golden_props(g, "prop3_")
+    hit_zero = False
+    for e in range(g["xyz3"].shape[0]):
+        om, axis, cen = g["cfpar3"][e][0], g["cfpar3"][e][1:4], g["cfpar3"][e][4:7]
+        s = oracle.centrifugal(g["xyz3"][e], float(props["rho"][e]), om, axis, cen, shell=True)
+        ref = g["cf3"][e]
+        hit_zero |= not ref.any()
+        assert np.abs(s - ref).max() <= 1e-13 * max(np.abs(ref).max(), 1e-300), e
+    assert hit_zero
+    for nn in (8, 4, 6, 5):
+        for e in range(g[f"sxyz{nn}"].shape[0]):
+            par = g[f"scfpar{nn}"][e]
+            s = oracle.centrifugal(g[f"sxyz{nn}"][e], float(g[f"srho{nn}"][e]), par[0], par[1:4], par[4:7], shell=False)
+            ref = g[f"scf{nn}"][e]
+            assert np.abs(s - ref).max() <= 1e-13 * max(np.abs(ref).max(), 1e-300), (nn, e)

@@ -11,10 +11,12 @@ def golden(name):
     return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
 
 
-def golden_props(g):
+def golden_props(g, prefix="prop_"):
     """fs_shell_prop rows as the REFERENCE evaluated them (prop_* arrays of a fixture)."""
-    n = g["prop_h"].shape[0]
+    n = g[prefix + "h"].shape[0]
     t = np.zeros(n, dtype=PROP_DTYPE)
     for k in ("A", "B", "D", "Cs", "h", "m_t", "m_r", "k_drill", "C_raw", "flags", "nonlinear"):
-        t[k] = g["prop_" + k]
+        t[k] = g[prefix + k]
+    if prefix + "rho" in g.files:        # fixtures written before the centrifugal prestress rows
+        t["rho"] = g[prefix + "rho"]
     return t

@@ -61,7 +61,7 @@ def ref_prop_row(el, laminate=None):
         k_drill=float(el._drilling_stiffness_factor()),
         C_raw=np.asarray(el._membrane_constitutive_raw(), float).ravel(),
         flags=int((2 if laminate is not None else 0) | (1 if el._has_membrane_bending_coupling else 0)),
-        nonlinear=int(bool(el.nonlinear)),
+        nonlinear=int(bool(el.nonlinear)), rho=float(el.material.rho),
     )
 
 
@@ -248,6 +248,99 @@ def gen_elem_nl():
     print("elem_nl.npz", N)
 
 
+def gen_elem_nl3():
+    """MITC3 / MITC3Composite: update_configuration + compute_tangent_stiffness +
+    compute_internal_forces (elements/MITC3.py:1144-1832, MITC3_composite.py:496-621).  Displacements
+    up to ~5 % of the element size so that T() of the CURRENT triangle differs from the initial frame."""
+    from fem_shell.elements import MITC3, MITC3Composite
+    rng = np.random.default_rng(13)
+    N = 32
+    xyz = tris(N + 7, rng)[7:]
+    rows, KT, F, U = [], [], [], []
+    for i in range(N):
+        size = np.linalg.norm(xyz[i, 1] - xyz[i, 0])
+        nl = (i % 4) != 3
+        if i % 2 == 0:
+            E, nu, rho = ISO[i % len(ISO)]
+            el = MITC3(xyz[i], (0, 1, 2), IsotropicMaterial("m", E, nu, rho), 0.05 * size, nonlinear=nl)
+            lam = None
+        else:
+            ang, t = LAYUPS[(i // 2) % len(LAYUPS)]
+            lam = create_laminate_from_angles(t300(), t * size, ang)
+            el = MITC3Composite(xyz[i], (0, 1, 2), lam, nonlinear=nl)
+        amp = [1e-3, 5e-2, 0.0][i % 3] if i != 5 else 0.0
+        u = rng.standard_normal(18) * amp * size
+        u[3::6] /= size; u[4::6] /= size; u[5::6] /= size
+        el.update_configuration(u)
+        rows.append(ref_prop_row(el, lam))
+        KT.append(el.compute_tangent_stiffness())
+        F.append(el.compute_internal_forces())
+        U.append(u)
+    save = {k: np.array([r[k] for r in rows]) for k in rows[0]}
+    np.savez_compressed(os.path.join(OUT, "elem_nl3.npz"), xyz=xyz, u=np.array(U), KT=np.array(KT),
+                        f_int=np.array(F), **{"prop_" + k: v for k, v in save.items()})
+    print("elem_nl3.npz", N)
+
+
+def gen_prestress():
+    """compute_geometric_stiffness(sigma) of MITC4 / MITC3 (+ composites) (MITC4.py:1191-1225,
+    MITC3.py:1501-1580) and compute_centrifugal_prestress of MITC3 (MITC3.py:1633-1715) and of the
+    linear solids (SOLID.py:268-320)."""
+    from fem_shell.elements import MITC3, MITC3Composite
+    from fem_shell.elements.SOLID import HEXA8, PYRAMID5, TETRA4, WEDGE6
+    rng = np.random.default_rng(21)
+    out = {}
+    for nn, gen, iso_cls, lam_cls in ((4, quads, MITC4, MITC4Composite), (3, tris, MITC3, MITC3Composite)):
+        N = 20
+        xyz = gen(N, rng)
+        rows, KG, SIG, CF, PAR = [], [], [], [], []
+        for i in range(N):
+            size = np.linalg.norm(xyz[i, 1] - xyz[i, 0])
+            if i % 2 == 0:
+                E, nu, rho = ISO[i % len(ISO)]
+                el = iso_cls(xyz[i], tuple(range(nn)), IsotropicMaterial("m", E, nu, rho), 0.03 * size)
+                lam = None
+            else:
+                ang, t = LAYUPS[(i // 2) % len(LAYUPS)]
+                lam = create_laminate_from_angles(t300(), t * size, ang)
+                el = lam_cls(xyz[i], tuple(range(nn)), lam)
+            sg = rng.standard_normal(3) * 1e6
+            if i == 4:
+                sg = sg * 1e-30          # below the assembler's skip threshold (core/assembler.py:498-500)
+            rows.append(ref_prop_row(el, lam))
+            KG.append(el.compute_geometric_stiffness(sg)); SIG.append(sg)
+            if nn == 3:
+                om = float(rng.uniform(0.5, 3.0))
+                axis = rng.standard_normal(3) * 2.0       # deliberately not unit length
+                cen = xyz[i].mean(axis=0) + rng.standard_normal(3) * 5 * size
+                if i == 6:                                # element centroid on the axis -> zeros
+                    cen = xyz[i].mean(axis=0) + 3.0 * axis
+                CF.append(el.compute_centrifugal_prestress(om, axis, cen)); PAR.append(np.concatenate([[om], axis, cen]))
+        save = {k: np.array([r[k] for r in rows]) for k in rows[0]}
+        out.update({f"xyz{nn}": xyz, f"KG{nn}": np.array(KG), f"sigma{nn}": np.array(SIG),
+                    **{f"prop{nn}_" + k: v for k, v in save.items()}})
+        if nn == 3:
+            out.update(cf3=np.array(CF), cfpar3=np.array(PAR))
+    cls = {8: HEXA8, 4: TETRA4, 6: WEDGE6, 5: PYRAMID5}
+    for nn in (8, 4, 6, 5):
+        xs, CF, PAR, RHO = [], [], [], []
+        for t in range(8):
+            x = SOLID_REF[nn] + 0.15 * rng.standard_normal((nn, 3))
+            x = x * rng.choice([1.0, 1e-2, 30.0]) + rng.choice([0.0, 5.0]) * rng.standard_normal(3)
+            E, nu, rho = ISO[t % len(ISO)]
+            el = cls[nn](x, tuple(range(nn)), IsotropicMaterial("m", E, nu, rho))
+            om = float(rng.uniform(0.5, 3.0)); axis = rng.standard_normal(3) * 2.0
+            cen = x.mean(axis=0) + rng.standard_normal(3) * 5 * np.ptp(x)
+            if t == 3:
+                cen = x.mean(axis=0) - 2.0 * axis
+            xs.append(x); CF.append(el.compute_centrifugal_prestress(om, axis, cen))
+            PAR.append(np.concatenate([[om], axis, cen])); RHO.append(rho)
+        out.update({f"sxyz{nn}": np.array(xs), f"scf{nn}": np.array(CF), f"scfpar{nn}": np.array(PAR),
+                    f"srho{nn}": np.array(RHO)})
+    np.savez_compressed(os.path.join(OUT, "prestress.npz"), **out)
+    print("prestress.npz")
+
+
 def gen_laminate():
     out = dict(angles=[], n=[], t=[], A=[], B=[], D=[], Cs=[], h=[], m_t=[], m_r=[], k_drill=[], sym=[])
     unit = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], float)
@@ -324,9 +417,8 @@ def gen_scordelis(n=16):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_elem_mitc4()
-    gen_elem_nl()
-    gen_elem_mitc3()
-    gen_elem_solid()
-    gen_laminate()
-    gen_scordelis(16)
+    ALL = dict(elem_mitc4=gen_elem_mitc4, elem_nl=gen_elem_nl, elem_mitc3=gen_elem_mitc3,
+               elem_solid=gen_elem_solid, laminate=gen_laminate, scordelis=lambda: gen_scordelis(16),
+               elem_nl3=gen_elem_nl3, prestress=gen_prestress)
+    for name in (sys.argv[1:] or list(ALL)):      # python tools/gen_golden.py [fixture ...]
+        ALL[name]()
