@@ -33,6 +33,10 @@ SIGNATURES = {
     "fs_csr_numeric_desc": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_numeric_sym": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_pattern_blk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "fs_csr_symbolic_begin": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _i64,
+                                             ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),
+    "fs_csr_symbolic_finish": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_csr_symbolic_free": (None, [_vp]),
     "fs_halo_pack": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -22,7 +22,7 @@ from . import _lib, batch
 from .elements import ElementFactory, ElementFamily
 from .properties import (CompositeShellProperty, ShellProperty, build_prop_table, iso_row,
                          laminate_row, solid_row, PROP_DTYPE)
-from .symbolic import BlockPlan, vector_plan
+from .symbolic import BlockPlan, DeviceBlockPlan, vector_plan
 
 
 class CsrMatrix:
@@ -220,7 +220,8 @@ class MeshAssembler:
             self._prop_objects = [self.model["material"]]
             self._props_d = batch.to_device_solid_props(self._prop_table)
             allowed = (4, 5, 6, 8)
-        self._plan = self._given_plan or BlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node)
+        # symbolic phase on the device (fs_csr_symbolic_*); a precomputed host BlockPlan is accepted too
+        self._plan = self._given_plan or DeviceBlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node, dev)
         p = self._plan
         coords_d = torch.from_numpy(coords).to(dev)
         # element groups (uniform node count each); their block buffers lie back to back
@@ -238,12 +239,9 @@ class MeshAssembler:
         self._is_mixed_mesh = len(self._groups) > 1
         g0 = self._groups[0]
         self._conn_d, self._xyz_d, self._pid_d = g0["conn_d"], g0["xyz_d"], g0["pid_d"]
-        self._plan_d = {k: torch.from_numpy(getattr(p, k)).to(dev)
-                        for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
-        self._desc_d = torch.from_numpy(p.descriptors().view(np.uint8).reshape(-1)).to(dev)
-        sd = p.sym_descriptors()
-        self._n_sym = sd.shape[0]
-        self._sdesc_d = torch.from_numpy(sd.view(np.uint8).reshape(-1)).to(dev)
+        self._plan_d = p.to_device(dev)
+        self._desc_d = self._plan_d["desc"]
+        self._sdesc_d = None     # symmetric descriptors: built on first use (use_symmetric)
         self.refresh_element_matrices()
 
     def _group_view(self, buf, g):
@@ -352,6 +350,10 @@ class MeshAssembler:
         lib, p, d = _lib.load(), self._plan, self._plan_d
         data = torch.empty(p.nnz, dtype=torch.float64, device=self.device)
         if self.use_symmetric and self.use_descriptors:
+            if self._sdesc_d is None:
+                sd = p.sym_descriptors()
+                self._n_sym = sd.shape[0]
+                self._sdesc_d = torch.from_numpy(sd.view(np.uint8).reshape(-1)).to(self.device)
             _lib.check(lib.fs_csr_numeric_sym(_lib.ptr(blk), _lib.ptr(self._sdesc_d), _lib.ptr(d["contrib"]),
                                               self._n_sym, p.d, _lib.ptr(data), _lib.stream_ptr()),
                        "fs_csr_numeric_sym")

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "femshell_hip.h"
+#include "femshell_internal.h"
 
 namespace {
 
@@ -2123,6 +2124,8 @@ inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
 }
 
 }  // namespace
+
+int fs_fail_(int code, const char *what, int hip_error) { return fail(code, what, (hipError_t)hip_error); }
 
 extern "C" {
 

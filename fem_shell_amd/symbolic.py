@@ -118,6 +118,14 @@ class BlockPlan:
     def nnz(self):
         return self.nblk * self.d * self.d
 
+    def to_device(self, device):
+        """Device copies of the plan arrays (+ fs_blk_desc rows as a byte tensor)."""
+        import torch
+        out = {k: torch.from_numpy(getattr(self, k)).to(device)
+               for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib")}
+        out["desc"] = torch.from_numpy(self.descriptors().view(np.uint8).reshape(-1)).to(device)
+        return out
+
     def descriptors(self):
         """fs_blk_desc rows (include/femshell_hip.h): output position + inline contributions."""
         d = self.d
@@ -177,6 +185,94 @@ class BlockPlan:
             for l in range(d):
                 indices[base + k * d * mb + l] = self.nbr * d + l
         return indptr, indices
+
+
+class DeviceBlockPlan:
+    """The same plan as BlockPlan, built on the GPU by fs_csr_symbolic_begin / _finish (stable radix
+    sort of node-pair keys generated in element order).  The arrays are device tensors; `host()`
+    gives a BlockPlan view for the host-side consumers (symmetric descriptors, tests)."""
+
+    def __init__(self, conn: np.ndarray, n_nodes: int, d: int, device, extra_pairs=None):
+        import ctypes
+        import torch
+        from . import _lib
+        lib = _lib.load()
+        groups = split_groups(conn)
+        conn = np.ascontiguousarray(conn, dtype=np.int64)
+        self.n_nodes, self.d, self.E = int(n_nodes), int(d), int(conn.shape[0])
+        self.device = torch.device(device)
+        self.groups, off = [], 0
+        for nn, pos, cg in groups:
+            self.groups.append((nn, pos, cg.shape[0], off))
+            off += cg.shape[0] * (nn * (nn + 1) // 2)
+        self.n_src_blocks = off
+        self.nn = groups[0][0] if len(groups) == 1 else None
+        nnmax = conn.shape[1]
+        entry_ptr = src_base = None
+        n_entries = self.E * nnmax * nnmax
+        if len(groups) > 1:                      # ragged rows: per-element entry offsets and source bases
+            cnt = (conn >= 0).sum(axis=1)
+            ep = np.zeros(self.E + 1, dtype=np.int64)
+            np.cumsum(cnt * cnt, out=ep[1:])
+            sb = np.empty(self.E, dtype=np.int64)
+            for nn, pos, Eg, boff in self.groups:
+                sb[pos] = boff + np.arange(Eg, dtype=np.int64) * (nn * (nn + 1) // 2)
+            n_entries = int(ep[-1])
+            entry_ptr, src_base = torch.from_numpy(ep).to(self.device), torch.from_numpy(sb).to(self.device)
+        conn_d = torch.from_numpy(conn).to(self.device)
+        extra_d, n_extra = None, 0
+        if extra_pairs is not None and len(extra_pairs):
+            ep2 = np.asarray(extra_pairs, dtype=np.int64)
+            extra_d = torch.from_numpy(np.ascontiguousarray(ep2[:, 0] * self.n_nodes + ep2[:, 1])).to(self.device)
+            n_extra = int(extra_d.numel())
+        stream = _lib.stream_ptr()
+        handle, nblk, ncontrib = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.fs_csr_symbolic_begin(_lib.ptr(conn_d), _lib.ptr(entry_ptr), _lib.ptr(src_base), self.E,
+                                             nnmax, n_entries, self.n_nodes, _lib.ptr(extra_d), n_extra,
+                                             ctypes.byref(handle), ctypes.byref(nblk), ctypes.byref(ncontrib),
+                                             stream), "fs_csr_symbolic_begin")
+        self.nblk = int(nblk.value)
+        i64, i32 = torch.int64, torch.int32
+        self.nbr_ptr = torch.empty(self.n_nodes + 1, dtype=i64, device=self.device)
+        self.nbr = torch.empty(self.nblk, dtype=i32, device=self.device)
+        self.blk_row = torch.empty(self.nblk, dtype=i32, device=self.device)
+        self.blk_ptr = torch.empty(self.nblk + 1, dtype=i64, device=self.device)
+        self.contrib = torch.empty(int(ncontrib.value), dtype=i64, device=self.device)
+        self.desc = torch.empty(self.nblk * BLK_DESC_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        _lib.check(lib.fs_csr_symbolic_finish(handle, self.d, _lib.ptr(self.nbr_ptr), _lib.ptr(self.nbr),
+                                              _lib.ptr(self.blk_row), _lib.ptr(self.blk_ptr), _lib.ptr(self.contrib),
+                                              _lib.ptr(self.desc), stream), "fs_csr_symbolic_finish")
+        self._host = None
+
+    @property
+    def nnz(self):
+        return self.nblk * self.d * self.d
+
+    def to_device(self, device):
+        return {k: getattr(self, k) for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib", "desc")}
+
+    def row_nnz(self):
+        m = (self.nbr_ptr[1:] - self.nbr_ptr[:-1]).cpu().numpy()
+        return np.repeat(m * self.d, self.d).astype(np.int32)
+
+    def host(self) -> "BlockPlan":
+        if self._host is None:
+            h = BlockPlan.__new__(BlockPlan)
+            h.n_nodes, h.d, h.E, h.groups = self.n_nodes, self.d, self.E, self.groups
+            h.n_src_blocks, h.nn, h.nblk = self.n_src_blocks, self.nn, self.nblk
+            for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib"):
+                setattr(h, k, getattr(self, k).cpu().numpy())
+            self._host = h
+        return self._host
+
+    def descriptors(self):
+        return np.frombuffer(self.desc.cpu().numpy().tobytes(), dtype=BLK_DESC_DTYPE)
+
+    def sym_descriptors(self):
+        return self.host().sym_descriptors()
+
+    def host_pattern(self):
+        return self.host().host_pattern()
 
 
 def generic_plan(dofs_list, sizes, ndof):

@@ -227,6 +227,36 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
                        int64_t n_nodes, int64_t nblk, int32_t d, int64_t *indptr,
                        int32_t *indices, void *stream);
 
+/*
+ * Device symbolic phase: everything fs_csr_numeric_desc / fs_csr_pattern_blk need, built on the GPU
+ * from the connectivity.  Replaces MeshAssembler._precompute_elements' DOF map and
+ * _compute_sparsity_pattern (core/assembler.py:166-187, 222-241: per-row Python sets) by a stable
+ * radix sort of node-pair keys I * n_nodes + J generated in element order, so each block's
+ * contributions keep the reference's insertion order (core/assembler.py:295-300).
+ *
+ * fs_csr_symbolic_begin (synchronises `stream`; allocates its own workspace):
+ *   conn       [E][nnmax] int64 device, node indices; rows of shorter elements padded with trailing -1
+ *   entry_ptr  [E+1] exclusive prefix sum of nn_e^2, or NULL for uniform meshes (nn_e == nnmax)
+ *   src_base   [E] index of element e's first FS_LAYOUT_SYMBLK block in the value buffer, or NULL
+ *              for a uniform mesh stored in element order (e * nn(nn+1)/2)
+ *   n_entries  sum of nn_e^2 (E * nnmax^2 for uniform meshes)
+ *   extra_keys [n_extra] keys I * n_nodes + J of pattern-only blocks (ghost columns of a distributed
+ *              run), or NULL
+ *   nblk, ncontrib (host, out): number of node-pair blocks / of contributions
+ * fs_csr_symbolic_finish (consumes the handle): nbr_ptr [n_nodes+1], nbr [nblk], blk_row [nblk],
+ *   blk_ptr [nblk+1], contrib [ncontrib] as documented at fs_csr_numeric_blk; desc [nblk] (may be NULL)
+ *   as documented at fs_blk_desc for d dofs per node.
+ * fs_csr_symbolic_free: drop a handle without finishing.
+ */
+typedef struct fs_symbolic fs_symbolic;
+int fs_csr_symbolic_begin(const int64_t *conn, const int64_t *entry_ptr, const int64_t *src_base, int64_t E,
+                          int32_t nnmax, int64_t n_entries, int64_t n_nodes, const int64_t *extra_keys,
+                          int64_t n_extra, fs_symbolic **handle, int64_t *nblk, int64_t *ncontrib,
+                          void *stream);
+int fs_csr_symbolic_finish(fs_symbolic *handle, int32_t d, int64_t *nbr_ptr, int32_t *nbr, int32_t *blk_row,
+                           int64_t *blk_ptr, int64_t *contrib, fs_blk_desc *desc, void *stream);
+void fs_csr_symbolic_free(fs_symbolic *handle);
+
 /* f[dof] = sum of fe contributions in element order (core/assembler.py:338-384 and the new
  * assemble_internal_forces): same segmented form as fs_csr_numeric. */
 int fs_vec_gather_sum(const double *vals, const int64_t *src, const int64_t *seg_ptr,

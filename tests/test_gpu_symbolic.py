@@ -1,0 +1,62 @@
+"""GPU: device symbolic phase (fs_csr_symbolic_begin / _finish) vs the host BlockPlan, which
+tests/test_host.py pins against the reference's set-union pattern (core/assembler.py:222-241).
+Integer work: everything must be bit-exact."""
+import numpy as np
+import pytest
+
+from fem_shell_amd import meshes, symbolic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _same(dp, hp):
+    assert dp.nblk == hp.nblk and dp.nnz == hp.nnz and dp.n_src_blocks == hp.n_src_blocks
+    for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib"):
+        a, b = getattr(dp, k).cpu().numpy(), getattr(hp, k)
+        assert a.dtype == b.dtype and np.array_equal(a, b), k
+    assert np.array_equal(dp.descriptors(), hp.descriptors())
+    assert np.array_equal(dp.row_nnz(), hp.row_nnz())
+    assert np.array_equal(dp.sym_descriptors(), hp.sym_descriptors())
+
+
+@pytest.mark.parametrize("case", ["quads", "tris", "mixed", "hexa", "extra", "shuffled"])
+def test_device_plan_equals_host_plan(case):
+    d = 6
+    extra = None
+    if case == "quads":
+        mesh = meshes.jittered_plate(37, 23, n_sets=4)
+        conn, n = mesh.conn, mesh.node_count
+    elif case == "tris":
+        mesh = meshes.cylindrical_patch(25.0, 25.0, 40.0, 12, 10, triangular=True)
+        conn, n = mesh.conn, mesh.node_count
+    elif case == "mixed":
+        conn, n = meshes.mixed_conn(9, 7), 10 * 8
+    elif case == "hexa":
+        from tests.test_gpu_assembly import _hex_block
+        coords, conn = _hex_block(6, 5, 4)
+        n, d = coords.shape[0], 3
+    elif case == "extra":
+        mesh = meshes.jittered_plate(11, 9, n_sets=2)
+        conn, n = mesh.conn, mesh.node_count
+        rng = np.random.default_rng(0)
+        extra = np.stack([rng.integers(0, n, 200), rng.integers(0, n, 200)], 1)
+        extra = np.concatenate([extra, extra[:, ::-1], extra[:5]])      # symmetric, with duplicates
+    else:   # element and node numbering without locality
+        mesh = meshes.jittered_plate(29, 31, n_sets=2)
+        rng = np.random.default_rng(1)
+        perm = rng.permutation(mesh.node_count)
+        conn, n = perm[mesh.conn][rng.permutation(mesh.conn.shape[0])], mesh.node_count
+    hp = symbolic.BlockPlan(conn, n, d, extra_pairs=extra)
+    dp = symbolic.DeviceBlockPlan(conn, n, d, DEV, extra_pairs=extra)
+    _same(dp, hp)
+    assert np.array_equal(dp.host_pattern()[1], hp.host_pattern()[1])
+
+
+def test_device_plan_errors_and_empty():
+    from fem_shell_amd._lib import FemShellHipError
+    conn = np.array([[0, 1, 2, 7]])
+    with pytest.raises(FemShellHipError):
+        symbolic.DeviceBlockPlan(conn, 4, 6, DEV)           # node 7 outside [0, 4)
+    dp = symbolic.DeviceBlockPlan(np.zeros((0, 4), dtype=np.int64), 5, 6, DEV)
+    assert dp.nblk == 0 and dp.nnz == 0 and not dp.nbr_ptr.cpu().numpy().any()
