@@ -37,6 +37,12 @@ SIGNATURES = {
                                              ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),
     "fs_csr_symbolic_finish": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_csr_symbolic_free": (None, [_vp]),
+    "fs_csr_zero_rows": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp]),
+    "fs_csr_reduce_symbolic": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64),
+                                              ctypes.POINTER(_i64), _vp]),
+    "fs_csr_reduce_fill": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_expand_solution": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "fs_csr_row_sums": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_pack": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -53,9 +53,8 @@ class CsrMatrix:
 
     def lump_rows(self):
         """Row-sum lumping (solvers/fsi/linear_dynamic.py:227-234) as a device vector."""
-        rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.data.device),
-                                       self.indptr[1:] - self.indptr[:-1])
-        return torch.zeros(self.shape[0], dtype=self.data.dtype, device=self.data.device).index_add_(0, rows, self.data)
+        from .bc import lump_mass_matrix
+        return lump_mass_matrix(self)
 
 
 class _LazyElementMap:

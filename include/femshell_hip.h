@@ -257,6 +257,35 @@ int fs_csr_symbolic_finish(fs_symbolic *handle, int32_t d, int64_t *nbr_ptr, int
                            int64_t *blk_ptr, int64_t *contrib, fs_blk_desc *desc, void *stream);
 void fs_csr_symbolic_free(fs_symbolic *handle);
 
+/*
+ * Dirichlet reduction and mass lumping on the device CSR (the step right after the assembly path).
+ * The reference does this through PETSc (core/bc.py:116-239, solvers/fsi/linear_dynamic.py:227-234);
+ * no reference test pins these PETSc calls, so their parity is pinned through the reduced solve of
+ * the Scordelis-Lo fixture (tests/golden/asm_scordelis_16.npz).
+ *
+ * fs_csr_zero_rows: Mat.zeroRows(rows, diag, x, b) -- every entry of the listed rows becomes 0, the
+ *   diagonal entry `diag`, and (x, b non-NULL) b[r] = diag * x[r]; the pattern is kept (explicit zeros).
+ * fs_csr_reduce_symbolic (synchronises `stream`): free_rank[ndof] (rank among the free dofs, -1 for
+ *   fixed ones) and the row pointer red_indptr[n_free+1] (caller provides ndof+1 entries) of the
+ *   free x free sub-matrix, createSubMatrix(free_is, free_is); n_free / nnz_red returned on the host.
+ * fs_csr_reduce_fill: column indices (renumbered) and values of the sub-matrix -- either may be NULL,
+ *   so K and M share one symbolic pass -- and, with f_red, the adjusted load
+ *   f_red = f[free] - K[free, fixed] u_fixed (u_fixed: full-length vector read at fixed dofs; NULL = 0).
+ * fs_expand_solution: u_full[free] = u_red, u_full[fixed] = u_fixed (NULL = 0)  (core/bc.py:241-290).
+ * fs_csr_row_sums: out[r] = sum of row r (M.getRowSum: lumped mass diagonal).
+ */
+int fs_csr_zero_rows(const int64_t *indptr, const int32_t *indices, double *data, const int64_t *rows,
+                     int64_t n_rows, double diag, const double *x, double *b, void *stream);
+int fs_csr_reduce_symbolic(const int64_t *indptr, const int32_t *indices, int64_t ndof,
+                           const uint8_t *fixed_mask, int32_t *free_rank, int64_t *red_indptr,
+                           int64_t *n_free, int64_t *nnz_red, void *stream);
+int fs_csr_reduce_fill(const int64_t *indptr, const int32_t *indices, const double *data, int64_t ndof,
+                       const int32_t *free_rank, const int64_t *red_indptr, int32_t *red_indices,
+                       double *red_data, const double *u_fixed, const double *f, double *f_red, void *stream);
+int fs_expand_solution(const double *u_red, const int32_t *free_rank, const double *u_fixed, int64_t ndof,
+                       double *u_full, void *stream);
+int fs_csr_row_sums(const int64_t *indptr, const double *data, int64_t nrows, double *out, void *stream);
+
 /* f[dof] = sum of fe contributions in element order (core/assembler.py:338-384 and the new
  * assemble_internal_forces): same segmented form as fs_csr_numeric. */
 int fs_vec_gather_sum(const double *vals, const int64_t *src, const int64_t *seg_ptr,

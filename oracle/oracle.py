@@ -196,3 +196,39 @@ def csr_assemble_mixed(dofs_list, ndof, ke_list):
             pos = lo + np.searchsorted(indices[lo:hi], dofs)
             data[pos] += ke[a]
     return indptr, indices, data
+
+
+# ---------------------------------------------------------------------------------------------
+# Dirichlet reduction / lumping restated with SciPy (core/bc.py:116-290,
+# solvers/fsi/linear_dynamic.py:227-234).  PARITY UNPINNED for the PETSc calls themselves (petsc4py
+# is absent and no reference test pins them): Mat.zeroRows / createSubMatrix / getRowSum are restated
+# from their documented semantics; the reduced solve is pinned by tests/golden/asm_scordelis_16.npz.
+# ---------------------------------------------------------------------------------------------
+def bc_apply(K, F, fixed: dict, M=None):
+    """K.zeroRows(fixed, 1.0, U_fixed, F); M.zeroRows(fixed, 0.0) on scipy CSR copies (pattern kept)."""
+    import scipy.sparse as sp
+    K = sp.csr_matrix(K, copy=True); F = np.array(F, dtype=float)
+    M = sp.csr_matrix(M, copy=True) if M is not None else None
+    for r, v in fixed.items():
+        lo, hi = K.indptr[r], K.indptr[r + 1]
+        K.data[lo:hi] = np.where(K.indices[lo:hi] == r, 1.0, 0.0)
+        F[r] = 1.0 * v
+        if M is not None:
+            M.data[M.indptr[r]:M.indptr[r + 1]] = 0.0
+    return K, F, M
+
+
+def bc_reduced(K, F, fixed: dict, M=None):
+    """(K_red, F_red, M_red, free): createSubMatrix(free, free) and F_free - K_free,fixed u_fixed."""
+    n = K.shape[0]
+    fx = np.array(sorted(fixed), dtype=np.int64)
+    free = np.setdiff1d(np.arange(n), fx)
+    uf = np.array([fixed[d] for d in fx], dtype=float)
+    K_red = K[free, :][:, free].tocsr()
+    K_red.sort_indices()
+    F_red = F[free] - (K[free, :][:, fx] @ uf if len(fx) else 0.0)
+    M_red = None
+    if M is not None:
+        M_red = M[free, :][:, free].tocsr()
+        M_red.sort_indices()
+    return K_red, F_red, M_red, free

@@ -1,0 +1,104 @@
+"""GPU: Dirichlet reduction, solution expansion and mass lumping on the device CSR
+(fem_shell_amd/bc.py -> femshell_sparse.hip) vs the SciPy restatement of core/bc.py in the oracle,
+and the reduced Scordelis-Lo solve vs the displacement the reference's own route produced
+(tests/golden/asm_scordelis_16.npz; test_ko2017_performance.py:365-408)."""
+import numpy as np
+import pytest
+import torch
+
+import fem_shell_amd as fsa
+from fem_shell_amd import meshes
+from fem_shell_amd.assembler import MeshAssembler
+from fem_shell_amd.bc import BoundaryConditionManager, DirichletCondition, lump_mass_matrix
+from fem_shell_amd.elements import ElementFamily
+from tests.util_golden import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _asm(g):
+    mesh = meshes.ArrayMesh(g["coords"], g["conn"])
+    mat = fsa.IsotropicMaterial("sc", float(g["E"]), float(g["nu"]), float(g["rho"]))
+    return MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat,
+                                             "thickness": float(g["t"])}})
+
+
+def test_reduced_solve_matches_reference_displacement(oracle):
+    from scipy.sparse.linalg import spsolve
+    g = golden("asm_scordelis_16")
+    asm = _asm(g)
+    K, M = asm.assemble_stiffness_matrix(), asm.assemble_mass_matrix()
+    K0, M0 = K.to_scipy().copy(), M.to_scipy().copy()
+    bcm = BoundaryConditionManager(K, g["F"], mass=M, dof_per_node=6)
+    with pytest.raises(RuntimeError):
+        bcm.reduced_system
+    bcm.apply_dirichlet([DirichletCondition(g["fixed"].tolist(), 0.0)])
+    K_red, F_red, M_red = bcm.reduced_system
+    fixed = {int(d): 0.0 for d in g["fixed"]}
+    # zeroRows restatement (in place on K, M; F copied)
+    Kz, Fz, Mz = oracle.bc_apply(K0, g["F"], fixed, M0)
+    assert np.array_equal(K.data.cpu().numpy(), Kz.data) and np.array_equal(M.data.cpu().numpy(), Mz.data)
+    assert np.array_equal(bcm.F.cpu().numpy(), Fz)
+    Kr, Fr, Mr, free = oracle.bc_reduced(Kz, Fz, fixed, Mz)
+    assert np.array_equal(bcm.free_dofs, free) and len(bcm.fixed_dofs) == len(fixed)
+    for A, B in ((K_red, Kr), (M_red, Mr)):
+        S = A.to_scipy()
+        assert np.array_equal(S.indptr, B.indptr) and np.array_equal(S.indices, B.indices)
+        assert np.array_equal(S.data, B.data)           # a pure gather: bit-exact
+    assert np.abs(F_red.cpu().numpy() - Fr).max() <= 1e-14 * np.abs(Fr).max()
+    u_red = spsolve(K_red.to_scipy().tocsc(), F_red.cpu().numpy())
+    u = bcm.expand_solution(u_red).cpu().numpy()
+    err = np.abs(u - g["u"]).max() / np.abs(g["u"]).max()
+    print("reduced solve vs reference displacement", err)
+    assert err < 1e-9 and not u[g["fixed"]].any()
+    assert abs(abs(u[int(g["node"]) * 6]) / 3.0240e-1 - 0.9973) < 0.05 * 0.9973   # Ko-2017 table value
+    v = bcm.expand_state_vector(np.ones(len(free))).cpu().numpy()
+    assert v.sum() == len(free) and not v[g["fixed"]].any()
+
+
+def test_nonzero_prescribed_values_and_errors(oracle):
+    g = golden("asm_scordelis_16")
+    asm = _asm(g)
+    K = asm.assemble_stiffness_matrix()
+    K0 = K.to_scipy().copy()
+    n = K.shape[0]
+    rng = np.random.default_rng(0)
+    F = rng.standard_normal(n)
+    conds = [DirichletCondition([0, 1, 2, 7, 7, 100], 0.25), DirichletCondition(range(600, 660), -1.5e-3),
+             DirichletCondition([2], 0.25)]
+    bcm = BoundaryConditionManager(K, F, dof_per_node=6)
+    bcm.apply_dirichlet(conds)
+    fixed = {d: c.value for c in conds for d in c.dofs}
+    K_red, F_red, M_red = bcm.reduced_system
+    assert M_red is None
+    Kz, Fz, _ = oracle.bc_apply(K0, F, fixed)
+    Kr, Fr, _, free = oracle.bc_reduced(Kz, Fz, fixed)
+    assert np.array_equal(K_red.to_scipy().data, Kr.data) and np.array_equal(K_red.to_scipy().indices, Kr.indices)
+    assert np.abs(F_red.cpu().numpy() - Fr).max() <= 1e-13 * np.abs(Fr).max()
+    u = bcm.expand_solution(np.arange(len(free), dtype=float)).cpu().numpy()
+    assert u[7] == 0.25 and u[601] == -1.5e-3 and np.array_equal(u[free], np.arange(len(free), dtype=float))
+    with pytest.raises(ValueError):
+        bcm.apply_dirichlet([DirichletCondition([n], 0.0)])
+    with pytest.raises(ValueError):
+        bcm.apply_dirichlet([DirichletCondition([3], 0.0), DirichletCondition([3], 1.0)])
+    with pytest.raises(ValueError):
+        BoundaryConditionManager(K, np.zeros(5))
+    # no fixed dofs at all: the reduced system is the system
+    K2 = asm.assemble_stiffness_matrix()
+    b2 = BoundaryConditionManager(K2, F)
+    b2.apply_dirichlet([])
+    Kr2, Fr2, _ = b2.reduced_system
+    assert np.array_equal(Kr2.to_scipy().data, K2.to_scipy().data) and np.array_equal(Fr2.cpu().numpy(), F)
+
+
+def test_lumped_mass(oracle):
+    g = golden("asm_scordelis_16")
+    asm = _asm(g)
+    M = asm.assemble_mass_matrix()
+    d = lump_mass_matrix(M).cpu().numpy()
+    ref = np.asarray(M.to_scipy().sum(axis=1)).ravel()
+    assert np.abs(d - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.array_equal(M.lump_rows().cpu().numpy(), d)
+    # total translational mass = rho * t * area (consistent mass rows sum to the nodal masses)
+    area = 25.0 * np.radians(40.0) * 25.0
+    assert abs(d[0::6].sum() / (float(g["rho"]) * float(g["t"]) * area) - 1.0) < 2e-3
