@@ -183,3 +183,14 @@ def jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=0):
     band = max(1, -(-nx // n_sets))
     set_id = np.tile((np.arange(nx) // band).astype(np.int32) % n_sets, ny)
     return ArrayMesh(coords, conn, set_id, [f"band_{i}" for i in range(n_sets)])
+
+
+def twisted_beam(length, width, twist_deg, nx, ny, triangular=False):
+    """MacNeal-Harder twisted beam (test_ko2017_performance.py:1195-1229): a flat strip along x whose
+    cross-section rotates linearly by `twist_deg` from root to tip."""
+    mesh = flat_patch(0.0, length, -width / 2.0, width / 2.0, nx, ny, triangular)
+    phi = np.radians(twist_deg) * (mesh.coords[:, 0] / length)
+    y = mesh.coords[:, 1].copy()
+    mesh.coords[:, 1] = y * np.cos(phi)
+    mesh.coords[:, 2] = y * np.sin(phi)
+    return mesh
