@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("FEMSHELL_HIP_LIB") or os.path.join(_HERE, "csrc", "li
 
 FS_WANT_K, FS_WANT_M, FS_WANT_KT, FS_WANT_FINT = 1, 2, 4, 8
 FS_WANT_FBODY, FS_WANT_KG = 16, 32
-FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK = 0, 1
+FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK, FS_LAYOUT_SYMBLK_T16 = 0, 1, 2
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
 
@@ -26,14 +26,14 @@ SIGNATURES = {
     "fs_centrifugal_prestress": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, ctypes.c_double, _vp, _vp,
                                                 _i64, _vp, _vp]),
     "fs_shell_quad_geom": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "fs_blk_expand": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "fs_blk_expand": (ctypes.c_int, [_vp, _u32, _i64, _i32, _i32, _vp, _vp]),
     "fs_csr_numeric": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fs_vec_gather_sum": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fs_csr_numeric_blk": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_numeric_desc": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_numeric_sym": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_pattern_blk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
-    "fs_csr_symbolic_begin": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _i64,
+    "fs_csr_symbolic_begin": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _u32, _i64, _i64, _vp, _i64,
                                              ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),
     "fs_csr_symbolic_finish": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_csr_symbolic_free": (None, [_vp]),

@@ -22,7 +22,7 @@ from . import _lib, batch
 from .elements import ElementFactory, ElementFamily
 from .properties import (CompositeShellProperty, ShellProperty, build_prop_table, iso_row,
                          laminate_row, solid_row, PROP_DTYPE)
-from .symbolic import BlockPlan, DeviceBlockPlan, vector_plan
+from .symbolic import BlockPlan, DeviceBlockPlan, can_tile, vector_plan
 
 
 class CsrMatrix:
@@ -220,8 +220,11 @@ class MeshAssembler:
             self._props_d = batch.to_device_solid_props(self._prop_table)
             allowed = (4, 5, 6, 8)
         # symbolic phase on the device (fs_csr_symbolic_*); a precomputed host BlockPlan is accepted too
-        self._plan = self._given_plan or DeviceBlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node, dev)
+        # (uniform quad meshes: element matrices in the tiled layout the stiffness kernel writes fastest)
+        self._plan = self._given_plan or DeviceBlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node, dev,
+                                                         tiled=(fam == ElementFamily.SHELL and can_tile(conn, self.dofs_per_node)))
         p = self._plan
+        self._layout = _lib.FS_LAYOUT_SYMBLK_T16 if getattr(p, "tiled", False) else _lib.FS_LAYOUT_SYMBLK
         coords_d = torch.from_numpy(coords).to(dev)
         # element groups (uniform node count each); their block buffers lie back to back
         self._groups = []
@@ -245,6 +248,8 @@ class MeshAssembler:
 
     def _group_view(self, buf, g):
         dd = self.dofs_per_node ** 2
+        if self._layout == _lib.FS_LAYOUT_SYMBLK_T16:      # one quad group: the whole tiled buffer
+            return buf
         return buf[g["boff"]:g["boff"] + g["E"] * g["npair"]].view(g["E"], g["npair"], dd)
 
     def refresh_element_matrices(self, want_K=True, want_M=True, check=True):
@@ -263,7 +268,8 @@ class MeshAssembler:
                       K_out=self._group_view(self._K_blk, g) if want_K else None,
                       M_out=self._group_view(self._M_blk, g) if want_M else None)
             if self._family == ElementFamily.SHELL:
-                out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table), **kw)
+                out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
+                                        layout=self._layout, **kw)
             else:
                 out = batch.solid_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
                                         reduced=self._reduced, **kw)
@@ -303,7 +309,7 @@ class MeshAssembler:
         if self._is_mixed_mesh == uniform:
             return None
         d = self.dofs_per_node
-        per_group = [batch.expand_blocks(self._group_view(buf, g), g["nn"], d).cpu().numpy()
+        per_group = [batch.expand_blocks(self._group_view(buf, g), g["nn"], d, self._layout, g["E"]).cpu().numpy()
                      for g in self._groups]
         if uniform:
             return per_group[0]
@@ -408,7 +414,7 @@ class MeshAssembler:
         for g, ue in zip(self._groups, ues):
             out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
                                     want_K=False, status=False, validate=False, u_e=ue, want_KT=want_KT,
-                                    want_F=want_F, KT_out=self._group_view(buf, g))
+                                    want_F=want_F, KT_out=self._group_view(buf, g), layout=self._layout)
             if want_F:
                 fparts.append(out["f_int"].reshape(-1))
         f = None
@@ -508,7 +514,7 @@ class MeshAssembler:
                 self._group_view(buf, g).copy_(out["KG"])
             else:
                 batch.shell_kg_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table), sg,
-                                     KG_out=self._group_view(buf, g))
+                                     KG_out=self._group_view(buf, g), layout=self._layout)
         return self._assemble(buf)
 
 

@@ -23,8 +23,19 @@ def to_device_props(props: np.ndarray) -> torch.Tensor:
     return raw.to(_dev())
 
 
-def _out_buf(given, E, npair, dev, dd=36):
+def n_blocks(E, npair, layout=_lib.FS_LAYOUT_SYMBLK):
+    """Blocks in the element-matrix buffer of E elements (FS_LAYOUT_SYMBLK_T16 pads to whole tiles)."""
+    return -(-E // 16) * 160 if layout == _lib.FS_LAYOUT_SYMBLK_T16 else E * npair
+
+
+def _out_buf(given, E, npair, dev, dd=36, layout=_lib.FS_LAYOUT_SYMBLK):
     """Caller-provided output view (element groups of one mesh share a block buffer) or a new one."""
+    if layout == _lib.FS_LAYOUT_SYMBLK_T16:
+        nb = n_blocks(E, npair, layout)
+        if given is None:      # the padding of the last tile is never read: keep it finite anyway
+            return torch.zeros((nb, dd), dtype=torch.float64, device=dev)
+        assert given.dtype == torch.float64 and given.is_cuda and given.is_contiguous() and given.numel() == nb * dd
+        return given.view(nb, dd)
     if given is None:
         return torch.empty((E, npair, dd), dtype=torch.float64, device=dev)
     assert given.dtype == torch.float64 and given.is_cuda and given.is_contiguous()
@@ -34,11 +45,12 @@ def _out_buf(given, E, npair, dev, dd=36):
 
 def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
                status=True, validate=True, u_e=None, want_KT=False, want_F=False, K_out=None,
-               M_out=None, KT_out=None):
+               M_out=None, KT_out=None, layout=_lib.FS_LAYOUT_SYMBLK):
     """MITC4+ element matrices for E quads.
 
     xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
-    Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,10,36], or dense [E,24,24]) and 'status'.
+    Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,10,36] -- or FS_LAYOUT_SYMBLK_T16 [ceil(E/16)*160,36]
+    with layout=_lib.FS_LAYOUT_SYMBLK_T16 -- or dense [E,24,24]) and 'status'.
     """
     lib = _lib.load()
     dev = _dev()
@@ -51,8 +63,8 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
         if pmin < 0 or pmax >= n_props:
             raise ValueError("prop_id out of range of the property table")
     out = {}
-    K = _out_buf(K_out, E, NPAIR4, dev) if want_K else None
-    M = _out_buf(M_out, E, NPAIR4, dev) if want_M else None
+    K = _out_buf(K_out, E, NPAIR4, dev, layout=layout) if want_K else None
+    M = _out_buf(M_out, E, NPAIR4, dev, layout=layout) if want_M else None
     st = torch.zeros(E, dtype=torch.int32, device=dev) if status else None
     want = (_lib.FS_WANT_K if want_K else 0) | (_lib.FS_WANT_M if want_M else 0)
     KT = F = None
@@ -61,19 +73,19 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
             raise ValueError("KT / f_int need the element displacement vectors u_e [E,24]")
         u_e = u_e.contiguous()
         assert u_e.dtype == torch.float64 and u_e.shape == (E, 24) and u_e.is_cuda
-        KT = _out_buf(KT_out, E, NPAIR4, dev)   # also the FINT workspace
+        KT = _out_buf(KT_out, E, NPAIR4, dev, layout=layout)   # also the FINT workspace
         F = torch.empty((E, 24), dtype=torch.float64, device=dev) if want_F else None
         want |= (_lib.FS_WANT_KT if want_KT else 0) | (_lib.FS_WANT_FINT if want_F else 0)
     _lib.check(lib.fs_shell_quad_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
-                                       n_props, _lib.ptr(u_e), E, want, _lib.FS_LAYOUT_SYMBLK,
+                                       n_props, _lib.ptr(u_e), E, want, layout,
                                        _lib.ptr(K), _lib.ptr(M), _lib.ptr(KT), _lib.ptr(F), _lib.ptr(st),
                                        _lib.stream_ptr()), "fs_shell_quad_batch")
     if not want_KT:
         KT = None
     if dense:
-        K = expand_blocks(K, 4, 6) if K is not None else None
-        M = expand_blocks(M, 4, 6) if M is not None else None
-        KT = expand_blocks(KT, 4, 6) if KT is not None else None
+        K = expand_blocks(K, 4, 6, layout, E) if K is not None else None
+        M = expand_blocks(M, 4, 6, layout, E) if M is not None else None
+        KT = expand_blocks(KT, 4, 6, layout, E) if KT is not None else None
     out["K"], out["M"], out["KT"], out["f_int"], out["status"] = K, M, KT, F, st
     return out
 
@@ -124,7 +136,8 @@ def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense
     return {"K": K, "M": M, "KT": KT, "f_int": F, "status": st}
 
 
-def shell_kg_batch(nn, xyz, prop_id, props_dev, n_props, sigma, dense=False, KG_out=None):
+def shell_kg_batch(nn, xyz, prop_id, props_dev, n_props, sigma, dense=False, KG_out=None,
+                   layout=_lib.FS_LAYOUT_SYMBLK):
     """Shell geometric stiffness from local membrane stresses sigma [E,3] (fs_shell_kg_batch):
     FS_LAYOUT_SYMBLK [E, nn(nn+1)/2, 36] or dense [E,6nn,6nn]."""
     lib = _lib.load()
@@ -137,11 +150,11 @@ def shell_kg_batch(nn, xyz, prop_id, props_dev, n_props, sigma, dense=False, KG_
     assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
     sigma = sigma.contiguous()
     assert sigma.dtype == torch.float64 and sigma.shape == (E, 3) and sigma.is_cuda
-    KG = _out_buf(KG_out, E, nn * (nn + 1) // 2, dev)
+    KG = _out_buf(KG_out, E, nn * (nn + 1) // 2, dev, layout=layout)
     _lib.check(lib.fs_shell_kg_batch(nn, _lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev), n_props,
-                                     _lib.ptr(sigma), E, _lib.FS_LAYOUT_SYMBLK, _lib.ptr(KG),
+                                     _lib.ptr(sigma), E, layout, _lib.ptr(KG),
                                      _lib.stream_ptr()), "fs_shell_kg_batch")
-    return expand_blocks(KG, nn, 6) if dense else KG
+    return expand_blocks(KG, nn, 6, layout, E) if dense else KG
 
 
 def centrifugal_prestress(solid, nn, xyz, prop_id, props_dev, n_props, omega, rotation_axis, rotation_center):
@@ -221,15 +234,21 @@ def shell_batch(nn, *args, **kw):
     if nn == 4:
         return quad_batch(*args, **kw)
     if nn == 3:
+        if kw.pop("layout", _lib.FS_LAYOUT_SYMBLK) != _lib.FS_LAYOUT_SYMBLK:
+            raise ValueError("FS_LAYOUT_SYMBLK_T16 is a quad layout")
         return tri_batch(*args, **kw)
     raise ValueError(f"unsupported shell element with {nn} nodes")
 
 
-def expand_blocks(packed, nn, d):
+def expand_blocks(packed, nn, d, layout=_lib.FS_LAYOUT_SYMBLK, E=None):
+    """Element-matrix blocks -> dense [E, nn*d, nn*d] (E must be given for FS_LAYOUT_SYMBLK_T16)."""
     lib = _lib.load()
-    E = packed.shape[0]
+    if E is None:
+        if layout != _lib.FS_LAYOUT_SYMBLK:
+            raise ValueError("expand_blocks: pass E for the tiled layout")
+        E = packed.shape[0]
     dense = torch.empty((E, nn * d, nn * d), dtype=torch.float64, device=packed.device)
-    _lib.check(lib.fs_blk_expand(_lib.ptr(packed), E, nn, d, _lib.ptr(dense), _lib.stream_ptr()),
+    _lib.check(lib.fs_blk_expand(_lib.ptr(packed), layout, E, nn, d, _lib.ptr(dense), _lib.stream_ptr()),
                "fs_blk_expand")
     return dense
 

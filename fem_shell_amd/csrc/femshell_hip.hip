@@ -72,6 +72,25 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
 }
 __device__ __forceinline__ double norm3(const double *a) { return __builtin_sqrt(dot3(a, a)); }
 
+// IEEE division with a SHARED reciprocal: the same arithmetic as the compiler's f64 fdiv expansion
+// (v_rcp_f64, two Newton steps, quotient, residual, correction) minus the v_div_scale / v_div_fixup
+// range handling, which is the identity for the magnitudes met here (no operand near 2^+-1000).
+// Several numerators over one denominator (a vector / its norm, cofactors / det) then cost one
+// reciprocal instead of one per quotient; results are bit-identical (tests: geometry bitwise).
+__device__ __forceinline__ double recip(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = FMA(-b, r, 1.0);
+    r = FMA(r, e, r);
+    e = FMA(-b, r, 1.0);
+    r = FMA(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double divr(double a, double b, double r) {
+    const double q = a * r;
+    const double d = FMA(-b, q, a);
+    return FMA(d, r, q);
+}
+
 constexpr double kGP = 0.57735026918962584;  // 1.0/np.sqrt(3.0)  (MITC4.py:87)
 
 struct QuadGeom {
@@ -89,20 +108,22 @@ __device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom 
     cross3(v1, v2, c1);
     const double l1 = norm3(c1);
     const bool ok1 = l1 > 1e-12;
-    for (int k = 0; k < 3; k++) n1[k] = c1[k] / l1;
+    const double rl1 = recip(l1);
+    for (int k = 0; k < 3; k++) n1[k] = divr(c1[k], l1, rl1);
     for (int k = 0; k < 3; k++) { v1[k] = x[2][k] - x[0][k]; v2[k] = x[3][k] - x[0][k]; }
     cross3(v1, v2, c2);
     const double l2 = norm3(c2);
     const bool ok2 = l2 > 1e-12;
-    for (int k = 0; k < 3; k++) n2[k] = c2[k] / l2;
+    const double rl2 = recip(l2);
+    for (int k = 0; k < 3; k++) n2[k] = divr(c2[k], l2, rl2);
     double e3[3];
     for (int k = 0; k < 3; k++) {
         const double both = (n1[k] + n2[k]) / 2.0;
         e3[k] = (ok1 && ok2) ? both : (ok1 ? n1[k] : (ok2 ? n2[k] : (k == 2 ? 1.0 : 0.0)));
     }
     if (ok1 || ok2) {
-        const double l = norm3(e3);
-        for (int k = 0; k < 3; k++) e3[k] = e3[k] / l;
+        const double l = norm3(e3), rl = recip(l);
+        for (int k = 0; k < 3; k++) e3[k] = divr(e3[k], l, rl);
     }
     double e1[3];
     for (int k = 0; k < 3; k++) e1[k] = x[1][k] - x[0][k];
@@ -113,12 +134,13 @@ __device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom 
         d = dot3(e1, e3);
         for (int k = 0; k < 3; k++) { const double t = d * e3[k]; e1[k] = e1[k] - t; }
     }
-    double l = norm3(e1);
-    for (int k = 0; k < 3; k++) e1[k] = e1[k] / l;
+    double l = norm3(e1), rl = recip(l);
+    for (int k = 0; k < 3; k++) e1[k] = divr(e1[k], l, rl);
     double e2[3];
     cross3(e3, e1, e2);
     l = norm3(e2);
-    for (int k = 0; k < 3; k++) e2[k] = e2[k] / l;
+    rl = recip(l);
+    for (int k = 0; k < 3; k++) e2[k] = divr(e2[k], l, rl);
     for (int k = 0; k < 3; k++) { g.e1[k] = e1[k]; g.e2[k] = e2[k]; g.e3[k] = e3[k]; }
     for (int i = 0; i < 4; i++) { g.xl[i][0] = dot3(x[i], e1); g.xl[i][1] = dot3(x[i], e2); }
     if (!(l == l) || !(g.xl[0][0] == g.xl[0][0])) g.status |= FS_ST_NAN_FRAME;
@@ -138,7 +160,8 @@ __device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom 
         cross3(a, b, nv);
         nn = norm3(nv);
     }
-    for (int k = 0; k < 3; k++) nh[k] = nv[k] / nn;
+    const double rnn = recip(nn);
+    for (int k = 0; k < 3; k++) nh[k] = divr(nv[k], nn, rnn);
     const double A00 = dot3(xr, xr), A01 = dot3(xr, xs), A02 = dot3(xr, nh);
     const double A10 = dot3(xs, xr), A11 = dot3(xs, xs), A12 = dot3(xs, nh);
     const double A20 = dot3(nh, xr), A21 = dot3(nh, xs), A22 = dot3(nh, nh);
@@ -148,8 +171,9 @@ __device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom 
     double mr[3], ms[3];
     if (det != 0.0) {
         const double c10 = A02 * A21 - A01 * A22, c11 = A00 * A22 - A02 * A20, c12 = A01 * A20 - A00 * A21;
-        const double r0 = c00 / det, r1 = c01 / det, r2 = c02 / det;
-        const double s0 = c10 / det, s1 = c11 / det, s2 = c12 / det;
+        const double rdet = recip(det);
+        const double r0 = divr(c00, det, rdet), r1 = divr(c01, det, rdet), r2 = divr(c02, det, rdet);
+        const double s0 = divr(c10, det, rdet), s1 = divr(c11, det, rdet), s2 = divr(c12, det, rdet);
         for (int k = 0; k < 3; k++) {
             mr[k] = r0 * xr[k] + r1 * xs[k] + r2 * nh[k];
             ms[k] = s0 * xr[k] + s1 * xs[k] + s2 * nh[k];
@@ -160,10 +184,11 @@ __device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom 
     const double c_r = dot3(xd, mr), c_s = dot3(xd, ms);
     double dd = c_r * c_r + c_s * c_s - 1.0;
     if (__builtin_fabs(dd) < 1e-12) dd = (dd >= 0) ? 1e-12 : -1e-12;
-    g.a[0] = c_r * (c_r - 1.0) / (2.0 * dd);
-    g.a[1] = c_r * (c_r + 1.0) / (2.0 * dd);
-    g.a[2] = c_s * (c_s - 1.0) / (2.0 * dd);
-    g.a[3] = c_s * (c_s + 1.0) / (2.0 * dd);
+    const double dd2 = 2.0 * dd, rdd2 = recip(dd2);
+    g.a[0] = divr(c_r * (c_r - 1.0), dd2, rdd2);
+    g.a[1] = divr(c_r * (c_r + 1.0), dd2, rdd2);
+    g.a[2] = divr(c_s * (c_s - 1.0), dd2, rdd2);
+    g.a[3] = divr(c_s * (c_s + 1.0), dd2, rdd2);
     g.a[4] = -2.0 * c_r * c_s / dd;
     if (!(g.a[0] == g.a[0])) g.status |= FS_ST_BAD_COEFF;
 }
@@ -185,7 +210,8 @@ __device__ __forceinline__ double jacobian(const QuadGeom &g, const double *dxi,
     const double J11 = dots4(deta[0], deta[1], deta[2], deta[3], g.xl[0][1], g.xl[1][1], g.xl[2][1], g.xl[3][1]);
     const double p = J00 * J11, q = J01 * J10;
     const double det = p - q;
-    ia = J11 / det; ib = -J01 / det; ic = -J10 / det; id = J00 / det;
+    const double rdet = recip(det);
+    ia = divr(J11, det, rdet); ib = divr(-J01, det, rdet); ic = divr(-J10, det, rdet); id = divr(J00, det, rdet);
     return det;
 }
 
@@ -202,15 +228,42 @@ constexpr int C_DN = 0, C_BS = 2;
 constexpr int LDS_DET = NC * 4 * 64;       // detJ[g][Q]
 constexpr int LDS_KNB = LDS_DET + 64;      // condensation rows Knb[c<6][node][Q]
 constexpr int LDS_U = LDS_KNB + 6 * 64;    // coupling U[c<10][node][Q] (only written when coupled)
+constexpr int STG_SLOT = 38;               // staging slot of one 6x6 block: 36 doubles + 2 pad (304 B: the
+                                           // 8-lane groups of ds_write_b128 then hit 32 distinct banks)
 constexpr int LDS_WAVE = LDS_U + 10 * 64;  // 3136 doubles = 25088 B
+constexpr int LDS_STG = LDS_WAVE;          // output staging of the tiled layout, 32 slots (half a wave per pass)
+constexpr int LDS_WAVE_T16 = LDS_STG + 32 * STG_SLOT;  // 4352 doubles = 34816 B
+
+// FS_LAYOUT_SYMBLK_T16 (quads only): tiles of 16 elements, 160 blocks per tile, stored in the order the
+// stiffness kernel produces them -- round 0: pairs (g,g); round 1: (g,g+1),(0,3); round 2: (0,2),(1,3);
+// within rounds 0/1 by half-tile, then task, then element.  Index of block (element e, pair p):
+__host__ __device__ __forceinline__ int64_t blk_t16(int64_t e, int p) {
+    // p -> round*4 + task:      p = 0  1  2  3  4  5  6  7  8  9
+    const int rg = (int)((0x3629517840ull >> (4 * p)) & 15);   // nibbles (p = 0..9): 0,4,8,7,1,5,9,2,6,3
+    const int round = rg >> 2, g = rg & 3, Q = (int)(e & 15);
+    const int pos = (round < 2) ? (round * 64 + ((Q >> 3) << 5) + (g << 3) + (Q & 7)) : (128 + (g << 4) + Q);
+    return (e >> 4) * 160 + pos;
+}
+__host__ __device__ __forceinline__ int64_t quad_blk(int tiled, int64_t e, int p) {
+    return tiled ? blk_t16(e, p) : e * 10 + p;
+}
 
 __device__ __forceinline__ int lds_slot(int c, int g, int node, int Q) {
     return ((c * 4 + g) << 6) + ((Q >> 2) << 4) + (((node + g) & 3) << 2) + (Q & 3);
 }
 
+// Exchange inside a quad of lanes through DPP quad_perm (VALU rate) instead of __shfl_xor, which
+// compiles to ds_bpermute_b32 pairs through the LDS crossbar.  Needs all four lanes of the quad active.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double quad_sum(double v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
+    v += quad_perm<0xB1>(v);   // quad_perm:[1,0,3,2] == lane ^ 1
+    v += quad_perm<0x4E>(v);   // quad_perm:[2,3,0,1] == lane ^ 2
     return v;
 }
 
@@ -234,15 +287,13 @@ __device__ __forceinline__ void tying_weights(int i, double *w) {
 // which is the same sum of products as MITC4.py:934-944 re-associated (eps-level difference) and
 // removes B_m from LDS and from the Gauss-point loop of every node-pair task.
 // ------------------------------------------------------------------------------------------
-#ifndef FS_K_WAVES
-#define FS_K_WAVES 1
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_K_WAVES, FS_K_WAVES))) void mitc4_k_kernel(const double *__restrict__ xyz,
+template <bool TILED>
+__global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
                                                      const int32_t *__restrict__ prop_id,
                                                      const fs_shell_prop *__restrict__ props,
                                                      int64_t E, double *__restrict__ out,
                                                      int32_t *__restrict__ status) {
-    __shared__ double lds[LDS_WAVE];
+    __shared__ double lds[TILED ? LDS_WAVE_T16 : LDS_WAVE];
     const int lane = threadIdx.x;
     const int Q = lane >> 2, g = lane & 3;
     const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
@@ -385,7 +436,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_K_WAVES, 
         }
         // Rot = [[sin b, -sin a], [-cos b, cos a]], a = atan2(Ay,Ax), b = pi/2 - atan2(Cx,Cy)
         const double nA = __builtin_sqrt(Ax * Ax + Ay * Ay), nC = __builtin_sqrt(Cx * Cx + Cy * Cy);
-        const double sa = Ay / nA, ca = Ax / nA, sb = Cy / nC, cb = Cx / nC;
+        const double rnA = recip(nA), rnC = recip(nC);
+        const double sa = divr(Ay, nA, rnA), ca = divr(Ax, nA, rnA), sb = divr(Cy, nC, rnC), cb = divr(Cx, nC, rnC);
         double r1, r2;
         {
 #pragma clang fp contract(off)
@@ -394,7 +446,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_K_WAVES, 
             const double q0 = Ax + eta * Bx, q1 = Ay + eta * By;
             r2 = __builtin_sqrt(FMA(q1, q1, q0 * q0));
         }
-        const double f1 = r1 / (8.0 * detJ), f2 = r2 / (8.0 * detJ);
+        const double d8 = 8.0 * detJ, rd8 = recip(d8);
+        const double f1 = divr(r1, d8, rd8), f2 = divr(r2, d8, rd8);
         // node -> (edge of row 0 [eta-edges 21/34], weight), (edge of row 1 [xi-edges 41/32], weight)
         const double me = 1.0 - eta, pe = 1.0 + eta, mx = 1.0 - xi, px = 1.0 + xi;
         const int e0[4] = {1, 1, 3, 3}, e1[4] = {0, 2, 2, 0};
@@ -448,13 +501,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_K_WAVES, 
     }
     for (int n = 0; n < 15; n++) S[n] = quad_sum(S[n]);
     kbb00 = quad_sum(kbb00); kbb01 = quad_sum(kbb01); kbb11 = quad_sum(kbb11);
-    st |= __shfl_xor(st, 1);
-    st |= __shfl_xor(st, 2);
+    st |= __builtin_amdgcn_update_dpp(0, st, 0xB1, 0xF, 0xF, true);
+    st |= __builtin_amdgcn_update_dpp(0, st, 0x4E, 0xF, 0xF, true);
     // Kbb^-1 (MITC4.py:994-998; singular -> no condensation)
     const double kdet = kbb00 * kbb11 - kbb01 * kbb01;
     const bool cond_ok = (kdet != 0.0) && (kdet == kdet);
-    const double i00 = cond_ok ? kbb11 / kdet : 0.0, i01 = cond_ok ? -kbb01 / kdet : 0.0,
-                 i11 = cond_ok ? kbb00 / kdet : 0.0;
+    const double rkdet = recip(kdet);
+    const double i00 = cond_ok ? divr(kbb11, kdet, rkdet) : 0.0, i01 = cond_ok ? divr(-kbb01, kdet, rkdet) : 0.0,
+                 i11 = cond_ok ? divr(kbb00, kdet, rkdet) : 0.0;
     if (status && valid && g == 0) status[e] = st;
 
     __syncthreads();
@@ -597,7 +651,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FS_K_WAVES, 
                     G[a][b] = m; G[b][a] = m;
                 }
         }
-        if (active) {
+        if constexpr (TILED) {
+            // ---- FS_LAYOUT_SYMBLK_T16 output.  A lane that stores its own 288-byte block issues 18
+            // instructions of 64 scattered 16-byte pieces; that form costs 0.45 ms of 1.58 ms per 1.25 M
+            // elements (L2 write-request rate, not bandwidth).  Here the blocks go through an LDS staging
+            // area, half a wave per pass (round 2 has 32 tasks: one pass), and leave as 9 instructions of
+            // 1024 contiguous, line-aligned bytes: the tile layout stores blocks in exactly this
+            // production order, so the global address is linear in (instruction, lane) -- no per-store
+            // index arithmetic (which cost more than the coalescing gained when tried on other layouts).
+            const int npass = (round == 2) ? 1 : 2;
+            for (int h = 0; h < npass; h++) {
+                const bool mine = (round == 2) ? (g < 2) : ((lane >> 5) == h);
+                const int slot = (round == 2) ? ((g << 4) + Q) : ((g << 3) + (Q & 7));
+                if (mine) {
+                    double2 *sp = reinterpret_cast<double2 *>(lds + LDS_STG + slot * STG_SLOT);
+                    for (int t = 0; t < 18; t++) sp[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
+                }
+                __syncthreads();
+                double2 *gp = reinterpret_cast<double2 *>(out + ((int64_t)blockIdx.x * 160 + round * 64 + h * 32) * 36) + lane;
+                const double2 *sp2 = reinterpret_cast<const double2 *>(lds + LDS_STG);
+                for (int i = 0; i < 9; i++) {
+                    const int c = i * 64 + lane;            // 16-byte chunk of the pass's 32 blocks
+                    const int bl = (c * 3641) >> 16;        // c / 18 for c < 576
+                    gp[i * 64] = sp2[c + bl];               // staging slots are 19 chunks apart
+                }
+                __syncthreads();
+            }
+        } else if (active) {
             const int p = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
             double2 *dst = reinterpret_cast<double2 *>(out + (e * 10 + p) * 36);
             for (int t = 0; t < 18; t++) dst[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
@@ -654,7 +734,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
                                                       const fs_shell_prop *__restrict__ props,
                                                       const double *__restrict__ ue, int64_t E,
                                                       double *__restrict__ kt, int want_kt,
-                                                      double *__restrict__ fe) {
+                                                      double *__restrict__ fe, int tiled) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     double x[4][3], u[4][6];
@@ -664,7 +744,8 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
     QuadGeom geo;
     quad_geometry(x, geo);
     const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
-    double *blk = kt + e * 360;
+    double *blkp[10];   // the element's 10 node-pair blocks (layout-dependent)
+    for (int p = 0; p < 10; p++) blkp[p] = kt + quad_blk(tiled, e, p) * 36;
     const int pidx[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
 
     {
@@ -675,7 +756,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
     if (fe) {
         for (int i = 0; i < 4; i++)
             for (int j = i; j < 4; j++) {
-                const double *B = blk + pidx[i][j] * 36;
+                const double *B = blkp[pidx[i][j]];
                 for (int a = 0; a < 6; a++)
                     for (int b = 0; b < 6; b++) {
                         const double v = B[a * 6 + b];
@@ -845,13 +926,13 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
                     for (int a = 0; a < 3; a++)
                         for (int b = 0; b < 3; b++) {
                             const double v = Yt[a][0] * R[0][b] + Yt[a][1] * R[1][b] + Yt[a][2] * R[2][b];
-                            blk[p * 36 + a * 6 + b] += v;
+                            blkp[p][a * 6 + b] += v;
                         }
                     if (i == j) {  // keep the diagonal block exactly symmetric
                         for (int a = 0; a < 3; a++)
                             for (int b = a + 1; b < 3; b++) {
-                                const double m = 0.5 * (blk[p * 36 + a * 6 + b] + blk[p * 36 + b * 6 + a]);
-                                blk[p * 36 + a * 6 + b] = m; blk[p * 36 + b * 6 + a] = m;
+                                const double m = 0.5 * (blkp[p][a * 6 + b] + blkp[p][b * 6 + a]);
+                                blkp[p][a * 6 + b] = m; blkp[p][b * 6 + a] = m;
                             }
                     }
                 }
@@ -868,7 +949,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
 __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
                                                       const fs_shell_prop *__restrict__ props,
-                                                      int64_t E, double *__restrict__ out) {
+                                                      int64_t E, double *__restrict__ out, int tiled) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E * 10) return;
     const int64_t e = t / 10;
@@ -909,7 +990,7 @@ __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__
             G[p3][q] = st;
             G[3 + p3][3 + q] = sr;
         }
-    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
+    double2 *dst = reinterpret_cast<double2 *>(out + quad_blk(tiled, e, p) * 36);
     for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
 }
 
@@ -1438,7 +1519,7 @@ __global__ __launch_bounds__(256) void shell_kg_kernel(const double *__restrict_
                                                        const int32_t *__restrict__ prop_id,
                                                        const fs_shell_prop *__restrict__ props,
                                                        const double *__restrict__ sigma, int64_t E,
-                                                       double *__restrict__ out) {
+                                                       double *__restrict__ out, int tiled) {
     constexpr int NP = NN * (NN + 1) / 2;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E * NP) return;
@@ -1492,7 +1573,7 @@ __global__ __launch_bounds__(256) void shell_kg_kernel(const double *__restrict_
     if (ti == tj)   // diagonal block exactly symmetric (K_sigma is symmetrised, MITC4.py:1219)
         for (int a = 0; a < 3; a++)
             for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (G[a][b] + G[b][a]); G[a][b] = m; G[b][a] = m; }
-    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
+    double2 *dst = reinterpret_cast<double2 *>(out + ((NN == 4) ? quad_blk(tiled, e, p) : t) * 36);
     for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
 }
 
@@ -1782,7 +1863,7 @@ __global__ void mitc4_geom_kernel(const double *xyz, int64_t E, double *frame, d
 
 // FS_LAYOUT_SYMBLK -> dense [E][nn*d][nn*d]
 __global__ void blk_expand_kernel(const double *__restrict__ packed, int64_t E, int nn, int d,
-                                  double *__restrict__ dense) {
+                                  double *__restrict__ dense, int tiled) {
     const int nd = nn * d;
     const int64_t total = E * nd * nd;
     const int npair = nn * (nn + 1) / 2;
@@ -1794,7 +1875,8 @@ __global__ void blk_expand_kernel(const double *__restrict__ packed, int64_t E, 
         int i = r / d, k = r - i * d, j = c / d, l = c - j * d;
         if (i > j) { int tmp = i; i = j; j = tmp; tmp = k; k = l; l = tmp; }
         const int p = i * nn - (i * (i - 1)) / 2 + (j - i);
-        dense[t] = packed[(e * npair + p) * (d * d) + k * d + l];
+        const int64_t blk = tiled ? blk_t16(e, p) : e * npair + p;
+        dense[t] = packed[blk * (d * d) + k * d + l];
     }
 }
 
@@ -2148,29 +2230,32 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
     if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_quad_batch: bad sizes");
     if (E == 0) return FS_OK;
     if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_shell_quad_batch: null input");
-    if (layout != FS_LAYOUT_SYMBLK)
-        return fail(FS_EINVAL, "fs_shell_quad_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
+    if (layout != FS_LAYOUT_SYMBLK && layout != FS_LAYOUT_SYMBLK_T16)
+        return fail(FS_EINVAL, "fs_shell_quad_batch: kernels emit FS_LAYOUT_SYMBLK / _T16; use fs_blk_expand for dense");
+    const int tiled = layout == FS_LAYOUT_SYMBLK_T16;
     hipStream_t s = (hipStream_t)stream;
     if (want & (FS_WANT_KT | FS_WANT_FINT)) {
         if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_quad_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_quad_batch: fe is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
-        hipLaunchKernelGGL(mitc4_k_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+        else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
         FS_LAUNCH_CHECK("mitc4_k_kernel");
         hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
-                           E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+                           E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled);
         FS_LAUNCH_CHECK("mitc4_nl_kernel");
     }
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_quad_batch: Ke is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
-        hipLaunchKernelGGL(mitc4_k_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
+        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
+        else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
         FS_LAUNCH_CHECK("mitc4_k_kernel");
     }
     if (want & FS_WANT_M) {
         if (!Me) return fail(FS_EINVAL, "fs_shell_quad_batch: Me is null");
         hipLaunchKernelGGL(mitc4_m_kernel, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz,
-                           prop_id, props, E, Me);
+                           prop_id, props, E, Me, tiled);
         FS_LAUNCH_CHECK("mitc4_m_kernel");
     }
     return FS_OK;
@@ -2294,15 +2379,16 @@ int fs_shell_kg_batch(int32_t nn, const double *xyz, const int32_t *prop_id, con
     if (nn != 3 && nn != 4) return fail(FS_EINVAL, "fs_shell_kg_batch: nn must be 3 (MITC3) or 4 (MITC4)");
     if (E == 0) return FS_OK;
     if (!xyz || !prop_id || !props || !sigma || !KGe) return fail(FS_EINVAL, "fs_shell_kg_batch: null argument");
-    if (layout != FS_LAYOUT_SYMBLK)
-        return fail(FS_EINVAL, "fs_shell_kg_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
+    if (layout != FS_LAYOUT_SYMBLK && !(layout == FS_LAYOUT_SYMBLK_T16 && nn == 4))
+        return fail(FS_EINVAL, "fs_shell_kg_batch: kernels emit FS_LAYOUT_SYMBLK (or _T16 for quads); use fs_blk_expand for dense");
+    const int tiled = layout == FS_LAYOUT_SYMBLK_T16;
     hipStream_t s = (hipStream_t)stream;
     if (nn == 3)
         hipLaunchKernelGGL(shell_kg_kernel<3>, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, sigma, E, KGe);
+                           props, sigma, E, KGe, 0);
     else
         hipLaunchKernelGGL(shell_kg_kernel<4>, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, sigma, E, KGe);
+                           props, sigma, E, KGe, tiled);
     FS_LAUNCH_CHECK("shell_kg_kernel");
     return FS_OK;
 }
@@ -2349,11 +2435,14 @@ int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, 
     return FS_OK;
 }
 
-int fs_blk_expand(const double *packed, int64_t E, int32_t nn, int32_t d, double *dense, void *stream) {
+int fs_blk_expand(const double *packed, uint32_t layout, int64_t E, int32_t nn, int32_t d, double *dense,
+                  void *stream) {
     if (E <= 0) return E == 0 ? FS_OK : fail(FS_EINVAL, "fs_blk_expand: E < 0");
     if (nn <= 0 || d <= 0) return fail(FS_EINVAL, "fs_blk_expand: bad nn/d");
+    if (layout != FS_LAYOUT_SYMBLK && !(layout == FS_LAYOUT_SYMBLK_T16 && nn == 4 && d == 6))
+        return fail(FS_EINVAL, "fs_blk_expand: layout must be FS_LAYOUT_SYMBLK, or FS_LAYOUT_SYMBLK_T16 for quads");
     hipLaunchKernelGGL(blk_expand_kernel, dim3(grid_for(E * nn * d * nn * d, 256, 65536)), dim3(256), 0,
-                       (hipStream_t)stream, packed, E, nn, d, dense);
+                       (hipStream_t)stream, packed, E, nn, d, dense, layout == FS_LAYOUT_SYMBLK_T16 ? 1 : 0);
     FS_LAUNCH_CHECK("blk_expand_kernel");
     return FS_OK;
 }

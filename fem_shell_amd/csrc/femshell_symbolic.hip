@@ -43,7 +43,7 @@ inline unsigned grid_of(int64_t n, int block) { return (unsigned)((n + block - 1
 __global__ __launch_bounds__(256) void sym_keys_kernel(const int64_t *__restrict__ conn,
                                                        const int64_t *__restrict__ entry_ptr,
                                                        const int64_t *__restrict__ src_base, int64_t E,
-                                                       int nnmax, int64_t n_nodes,
+                                                       int nnmax, int64_t n_nodes, int tiled,
                                                        int64_t *__restrict__ keys, int64_t *__restrict__ vals,
                                                        int *__restrict__ bad) {
     const int per = nnmax * nnmax;
@@ -63,8 +63,14 @@ __global__ __launch_bounds__(256) void sym_keys_kernel(const int64_t *__restrict
     const int i = a < b ? a : b, j = a < b ? b : a;
     const int p = i * nn - (i * (i - 1)) / 2 + (j - i);       // FS_LAYOUT_SYMBLK pair index
     const int64_t base = src_base ? src_base[e] : e * (int64_t)(nn * (nn + 1) / 2);
+    int64_t src = base + p;
+    if (tiled) {   // FS_LAYOUT_SYMBLK_T16 (uniform quads): same formula as blk_t16() of femshell_hip.hip
+        const int rg = (int)((0x3629517840ull >> (4 * p)) & 15);
+        const int round = rg >> 2, g = rg & 3, Q = (int)(e & 15);
+        src = (e >> 4) * 160 + ((round < 2) ? (round * 64 + ((Q >> 3) << 5) + (g << 3) + (Q & 7)) : (128 + (g << 4) + Q));
+    }
     keys[pos] = I * n_nodes + J;
-    vals[pos] = ((base + p) << 1) | (a > b ? 1 : 0);
+    vals[pos] = (src << 1) | (a > b ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void sym_extra_kernel(const int64_t *__restrict__ extra, int64_t n_extra,
@@ -154,7 +160,7 @@ void release(fs_symbolic *h) {
 extern "C" {
 
 int fs_csr_symbolic_begin(const int64_t *conn, const int64_t *entry_ptr, const int64_t *src_base, int64_t E,
-                          int32_t nnmax, int64_t n_entries, int64_t n_nodes, const int64_t *extra_keys,
+                          int32_t nnmax, uint32_t layout, int64_t n_entries, int64_t n_nodes, const int64_t *extra_keys,
                           int64_t n_extra, fs_symbolic **handle, int64_t *nblk, int64_t *ncontrib, void *stream) {
     if (!handle || !nblk || !ncontrib) return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: null output", 0);
     *handle = nullptr; *nblk = 0; *ncontrib = 0;
@@ -162,6 +168,8 @@ int fs_csr_symbolic_begin(const int64_t *conn, const int64_t *entry_ptr, const i
         return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: bad sizes", 0);
     if (E > 0 && !conn) return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: conn is null", 0);
     if (n_extra > 0 && !extra_keys) return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: extra_keys is null", 0);
+    if (layout != FS_LAYOUT_SYMBLK && !(layout == FS_LAYOUT_SYMBLK_T16 && nnmax == 4 && !entry_ptr && !src_base))
+        return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: layout must be FS_LAYOUT_SYMBLK, or _T16 for uniform quads", 0);
     if (!entry_ptr && n_entries != E * nnmax * nnmax)
         return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: n_entries must be E*nnmax^2 without entry_ptr", 0);
     if ((double)n_nodes * (double)n_nodes >= 9.0e18)
@@ -194,7 +202,7 @@ int fs_csr_symbolic_begin(const int64_t *conn, const int64_t *entry_ptr, const i
     SYM_TRY(hipMemsetAsync(bad, 0, sizeof(int), s), "hipMemsetAsync");
     if (E > 0) {
         hipLaunchKernelGGL(sym_keys_kernel, dim3(grid_of(E * nnmax * nnmax, 256)), dim3(256), 0, s, conn, entry_ptr,
-                           src_base, E, (int)nnmax, n_nodes, kin, vin, bad);
+                           src_base, E, (int)nnmax, n_nodes, layout == FS_LAYOUT_SYMBLK_T16 ? 1 : 0, kin, vin, bad);
         SYM_TRY(hipGetLastError(), "sym_keys_kernel");
     }
     if (n_extra > 0) {

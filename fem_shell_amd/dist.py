@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .symbolic import BlockPlan
+from .symbolic import BlockPlan, can_tile
 
 
 def _comm_device():
@@ -118,7 +118,8 @@ class DistributedPlan:
         X = self.nodes_g
         self.conn_x = np.searchsorted(X, gconn)
         extra = [np.searchsorted(X, v) for v in recv_pairs.values()]
-        self.plan = BlockPlan(self.conn_x, X.shape[0], d, np.concatenate(extra) if extra else None)
+        self.plan = BlockPlan(self.conn_x, X.shape[0], d, np.concatenate(extra) if extra else None,
+                              tiled=can_tile(self.conn_x, d))
         own_x = np.zeros(X.shape[0], dtype=bool)
         own_x[np.searchsorted(X, mine[owner == rank])] = True
         self.owned = own_x

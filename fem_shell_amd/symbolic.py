@@ -33,6 +33,24 @@ def pair_index(nn):
     return P, T
 
 
+_T16_RG = np.array([0, 4, 8, 7, 1, 5, 9, 2, 6, 3])     # pair p -> round * 4 + task (include/femshell_hip.h)
+
+
+def blk_t16(e, p):
+    """Block index of (element e, pair p) in FS_LAYOUT_SYMBLK_T16 (include/femshell_hip.h)."""
+    e, p = np.asarray(e, dtype=np.int64), np.asarray(p, dtype=np.int64)
+    rg = _T16_RG[p]
+    r, g, Q = rg >> 2, rg & 3, e & 15
+    pos = np.where(r < 2, r * 64 + ((Q >> 3) << 5) + (g << 3) + (Q & 7), 128 + (g << 4) + Q)
+    return (e >> 4) * 160 + pos
+
+
+def can_tile(conn, d):
+    """FS_LAYOUT_SYMBLK_T16 applies to uniform quad shell meshes."""
+    conn = np.asarray(conn)
+    return d == 6 and conn.ndim == 2 and conn.shape[1] == 4 and (conn.shape[0] == 0 or conn.min() >= 0)
+
+
 def split_groups(conn):
     """Padded connectivity [E, nnmax] (-1 = absent, trailing) -> list of (nn, pos, conn_g):
     pos = positions of the group's elements in the mesh's element order (None: all, in order)."""
@@ -57,11 +75,15 @@ class BlockPlan:
     """Node-pair block scatter plan (uniform d dofs/node; one or more element groups, each with a
     uniform node count; the groups' FS_LAYOUT_SYMBLK buffers are laid out back to back)."""
 
-    def __init__(self, conn: np.ndarray, n_nodes: int, d: int, extra_pairs=None):
+    def __init__(self, conn: np.ndarray, n_nodes: int, d: int, extra_pairs=None, tiled=False):
         """conn: [E,nn] (or -1-padded for mixed node counts).  extra_pairs: optional int64 [n,2]
         node pairs (I,J) that must exist in the pattern even without a local contribution (ghost
-        columns of interface rows in a distributed run)."""
+        columns of interface rows in a distributed run).  tiled: the element matrices are stored in
+        FS_LAYOUT_SYMBLK_T16 (uniform quad meshes only)."""
         groups = split_groups(conn)
+        if tiled and not can_tile(conn, d):
+            raise ValueError("FS_LAYOUT_SYMBLK_T16 needs a uniform quad mesh with 6 dofs per node")
+        self.tiled = bool(tiled)
         self.n_nodes, self.d = int(n_nodes), int(d)
         self.E = int(np.asarray(conn).shape[0])
         self.groups = []          # (nn, pos, E_g, block offset)
@@ -76,7 +98,7 @@ class BlockPlan:
             keys_l.append((cg[:, :, None] * n_nodes + cg[:, None, :]).reshape(-1))
             self.groups.append((nn, pos, Eg, off))
             off += Eg * npair
-        self.n_src_blocks = off
+        self.n_src_blocks = off if not self.tiled else -(-self.E // 16) * 160
         self.nn = groups[0][0] if len(groups) == 1 else None
         if len(groups) == 1:
             keys = keys_l[0]
@@ -109,7 +131,10 @@ class BlockPlan:
             o = order[sel] - lo
             P, T = pair_index(nn)
             ab = o % (nn * nn)
-            src_blk = boff + (o // (nn * nn)) * (nn * (nn + 1) // 2) + P.reshape(-1)[ab]
+            if self.tiled:
+                src_blk = blk_t16(o // 16, P.reshape(-1)[ab])
+            else:
+                src_blk = boff + (o // (nn * nn)) * (nn * (nn + 1) // 2) + P.reshape(-1)[ab]
             contrib[sel] = (src_blk << 1) | T.reshape(-1)[ab]
             lo = hi
         self.contrib = contrib
@@ -192,20 +217,23 @@ class DeviceBlockPlan:
     sort of node-pair keys generated in element order).  The arrays are device tensors; `host()`
     gives a BlockPlan view for the host-side consumers (symmetric descriptors, tests)."""
 
-    def __init__(self, conn: np.ndarray, n_nodes: int, d: int, device, extra_pairs=None):
+    def __init__(self, conn: np.ndarray, n_nodes: int, d: int, device, extra_pairs=None, tiled=False):
         import ctypes
         import torch
         from . import _lib
         lib = _lib.load()
         groups = split_groups(conn)
         conn = np.ascontiguousarray(conn, dtype=np.int64)
+        if tiled and not can_tile(conn, d):
+            raise ValueError("FS_LAYOUT_SYMBLK_T16 needs a uniform quad mesh with 6 dofs per node")
+        self.tiled = bool(tiled)
         self.n_nodes, self.d, self.E = int(n_nodes), int(d), int(conn.shape[0])
         self.device = torch.device(device)
         self.groups, off = [], 0
         for nn, pos, cg in groups:
             self.groups.append((nn, pos, cg.shape[0], off))
             off += cg.shape[0] * (nn * (nn + 1) // 2)
-        self.n_src_blocks = off
+        self.n_src_blocks = off if not self.tiled else -(-self.E // 16) * 160
         self.nn = groups[0][0] if len(groups) == 1 else None
         nnmax = conn.shape[1]
         entry_ptr = src_base = None
@@ -228,7 +256,8 @@ class DeviceBlockPlan:
         stream = _lib.stream_ptr()
         handle, nblk, ncontrib = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
         _lib.check(lib.fs_csr_symbolic_begin(_lib.ptr(conn_d), _lib.ptr(entry_ptr), _lib.ptr(src_base), self.E,
-                                             nnmax, n_entries, self.n_nodes, _lib.ptr(extra_d), n_extra,
+                                             nnmax, _lib.FS_LAYOUT_SYMBLK_T16 if self.tiled else _lib.FS_LAYOUT_SYMBLK,
+                                             n_entries, self.n_nodes, _lib.ptr(extra_d), n_extra,
                                              ctypes.byref(handle), ctypes.byref(nblk), ctypes.byref(ncontrib),
                                              stream), "fs_csr_symbolic_begin")
         self.nblk = int(nblk.value)
@@ -258,7 +287,7 @@ class DeviceBlockPlan:
     def host(self) -> "BlockPlan":
         if self._host is None:
             h = BlockPlan.__new__(BlockPlan)
-            h.n_nodes, h.d, h.E, h.groups = self.n_nodes, self.d, self.E, self.groups
+            h.n_nodes, h.d, h.E, h.groups, h.tiled = self.n_nodes, self.d, self.E, self.groups, self.tiled
             h.n_src_blocks, h.nn, h.nblk = self.n_src_blocks, self.nn, self.nblk
             for k in ("nbr_ptr", "nbr", "blk_row", "blk_ptr", "contrib"):
                 setattr(h, k, getattr(self, k).cpu().numpy())

@@ -40,6 +40,15 @@ extern "C" {
 #define FS_LAYOUT_DENSE 0u  /* [E][nd][nd] C-order == reference `_ke_array` (core/assembler.py:213-215) */
 #define FS_LAYOUT_SYMBLK 1u /* [E][npair][d*d]: node-pair blocks (i<=j) only, row-major d x d each;
                                block (j,i) is the transpose.  pair index p(i,j)=i*nn-i*(i-1)/2+(j-i) */
+#define FS_LAYOUT_SYMBLK_T16 2u /* quads (nn = 4, d = 6) only: the same 10 blocks per element, grouped in
+                               tiles of 16 elements (160 blocks, buffer = ceil(E/16)*160 blocks) and
+                               stored in the order the stiffness kernel produces them, so that it can
+                               write whole 128-byte lines.  Block (e, p) has index
+                                 (e/16)*160 + (r < 2 ? r*64 + (Q/8)*32 + g*8 + Q%8 : 128 + g*16 + Q),
+                               Q = e%16, (r, g) = (0,0) (1,0) (2,0) (1,3) (0,1) (1,1) (2,1) (0,2) (1,2) (0,3)
+                               for p = 0..9.  Accepted by fs_shell_quad_batch, fs_shell_kg_batch (nn = 4),
+                               fs_blk_expand and fs_csr_symbolic_begin; consumers that take block
+                               indices (fs_csr_numeric_*) are layout-agnostic. */
 
 /* status[E] bits */
 #define FS_ST_NAN_FRAME 1   /* zero-area / zero-norm local frame (MITC4.py:436-476 silently NaNs) */
@@ -159,8 +168,9 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
 int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
                        double *acoef, void *stream);
 
-/* FS_LAYOUT_SYMBLK -> FS_LAYOUT_DENSE ([E][nn*d][nn*d]); nn nodes/element, d dofs/node. */
-int fs_blk_expand(const double *packed, int64_t E, int32_t nn, int32_t d, double *dense,
+/* FS_LAYOUT_SYMBLK / FS_LAYOUT_SYMBLK_T16 (`layout`) -> FS_LAYOUT_DENSE ([E][nn*d][nn*d]);
+ * nn nodes/element, d dofs/node. */
+int fs_blk_expand(const double *packed, uint32_t layout, int64_t E, int32_t nn, int32_t d, double *dense,
                   void *stream);
 
 /*
@@ -239,6 +249,8 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
  *   entry_ptr  [E+1] exclusive prefix sum of nn_e^2, or NULL for uniform meshes (nn_e == nnmax)
  *   src_base   [E] index of element e's first FS_LAYOUT_SYMBLK block in the value buffer, or NULL
  *              for a uniform mesh stored in element order (e * nn(nn+1)/2)
+ *   layout     layout of the element-matrix buffers the plan will index: FS_LAYOUT_SYMBLK, or
+ *              FS_LAYOUT_SYMBLK_T16 (uniform quad meshes, entry_ptr == src_base == NULL)
  *   n_entries  sum of nn_e^2 (E * nnmax^2 for uniform meshes)
  *   extra_keys [n_extra] keys I * n_nodes + J of pattern-only blocks (ghost columns of a distributed
  *              run), or NULL
@@ -250,7 +262,7 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
  */
 typedef struct fs_symbolic fs_symbolic;
 int fs_csr_symbolic_begin(const int64_t *conn, const int64_t *entry_ptr, const int64_t *src_base, int64_t E,
-                          int32_t nnmax, int64_t n_entries, int64_t n_nodes, const int64_t *extra_keys,
+                          int32_t nnmax, uint32_t layout, int64_t n_entries, int64_t n_nodes, const int64_t *extra_keys,
                           int64_t n_extra, fs_symbolic **handle, int64_t *nblk, int64_t *ncontrib,
                           void *stream);
 int fs_csr_symbolic_finish(fs_symbolic *handle, int32_t d, int64_t *nbr_ptr, int32_t *nbr, int32_t *blk_row,

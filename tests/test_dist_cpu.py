@@ -49,7 +49,8 @@ def _worker(rank, world, port, nx, ny, q):
         eg = (np.arange(ny)[:, None] * (world * nx) + ecol[None, :]).reshape(-1)     # global element ids
         dp = DistributedPlan(loc.conn, l2g, 6)
         Kl, _ = O.mitc4_K_batch(loc.coords[loc.conn], gpid[eg], props)
-        data = util.host_block_assemble(dp.plan, util.pack_symblk(Kl))
+        assert dp.plan.tiled      # quad strips use the tiled element-matrix layout
+        data = util.host_block_assemble(dp.plan, util.pack_symblk(Kl, tiled=dp.plan.tiled))
         data = dp.exchange_host(data)
         ip, ix = dp.plan.host_pattern()
         X = dp.nodes_g

@@ -133,3 +133,23 @@ def test_nonlinear_KT_fint_vs_reference_golden_and_oracle(oracle):
         worstF = max(worstF, np.abs(F[e] - fo).max() / np.abs(fo).max())
     print("HIP vs oracle: KT", worstK, "f_int", worstF)
     assert worstK < 1e-12 and worstF < 1e-11
+
+
+def test_tiled_layout_equals_element_major(setup):
+    """FS_LAYOUT_SYMBLK_T16 (LDS-staged whole-line stores) carries bit for bit the same blocks as
+    FS_LAYOUT_SYMBLK: K, M, K_T, f_int on 1003 elements (partial last tile)."""
+    import torch
+    from fem_shell_amd import _lib, batch
+    props = fsa.build_prop_table(util.standard_props(), nonlinear=True)
+    pd = batch.to_device_props(props)
+    rng = np.random.default_rng(4)
+    u = torch.from_numpy(rng.standard_normal((setup["xyz"].shape[0], 24)) * 1e-3).to("cuda:0")
+    kw = dict(want_K=True, want_M=True, want_KT=True, want_F=True, u_e=u, dense=True)
+    a = batch.quad_batch(setup["xyz_d"], setup["pid_d"], pd, len(props), **kw)
+    b = batch.quad_batch(setup["xyz_d"], setup["pid_d"], pd, len(props), layout=_lib.FS_LAYOUT_SYMBLK_T16, **kw)
+    for k in ("K", "M", "KT", "f_int", "status"):
+        assert torch.equal(a[k], b[k]), k
+    raw = batch.quad_batch(setup["xyz_d"], setup["pid_d"], pd, len(props), layout=_lib.FS_LAYOUT_SYMBLK_T16)["K"]
+    assert raw.shape == (-(-1003 // 16) * 160, 36)
+    with pytest.raises(ValueError):
+        batch.expand_blocks(raw, 4, 6, _lib.FS_LAYOUT_SYMBLK_T16)

@@ -20,11 +20,12 @@ def _same(dp, hp):
     assert np.array_equal(dp.sym_descriptors(), hp.sym_descriptors())
 
 
-@pytest.mark.parametrize("case", ["quads", "tris", "mixed", "hexa", "extra", "shuffled"])
+@pytest.mark.parametrize("case", ["quads", "quads_t16", "tris", "mixed", "hexa", "extra", "shuffled"])
 def test_device_plan_equals_host_plan(case):
     d = 6
     extra = None
-    if case == "quads":
+    tiled = case in ("quads_t16", "extra")
+    if case in ("quads", "quads_t16"):
         mesh = meshes.jittered_plate(37, 23, n_sets=4)
         conn, n = mesh.conn, mesh.node_count
     elif case == "tris":
@@ -47,8 +48,10 @@ def test_device_plan_equals_host_plan(case):
         rng = np.random.default_rng(1)
         perm = rng.permutation(mesh.node_count)
         conn, n = perm[mesh.conn][rng.permutation(mesh.conn.shape[0])], mesh.node_count
-    hp = symbolic.BlockPlan(conn, n, d, extra_pairs=extra)
-    dp = symbolic.DeviceBlockPlan(conn, n, d, DEV, extra_pairs=extra)
+    hp = symbolic.BlockPlan(conn, n, d, extra_pairs=extra, tiled=tiled)
+    dp = symbolic.DeviceBlockPlan(conn, n, d, DEV, extra_pairs=extra, tiled=tiled)
+    if tiled:   # 37*23 = 851 elements: the last tile is partial
+        assert hp.n_src_blocks == -(-conn.shape[0] // 16) * 160 and (hp.contrib >> 1).max() < hp.n_src_blocks
     _same(dp, hp)
     assert np.array_equal(dp.host_pattern()[1], hp.host_pattern()[1])
 

@@ -44,14 +44,21 @@ def random_quads(n, seed=0, far=True):
     return xyz
 
 
-def pack_symblk(dense, nn=4, d=6):
-    """dense [E, nn*d, nn*d] -> FS_LAYOUT_SYMBLK [E, npair, d*d] (host, tests only)."""
-    from fem_shell_amd.symbolic import pair_index
+def pack_symblk(dense, nn=4, d=6, tiled=False):
+    """dense [E, nn*d, nn*d] -> FS_LAYOUT_SYMBLK [E, npair, d*d], or FS_LAYOUT_SYMBLK_T16
+    [ceil(E/16)*160, 36] with tiled=True (host, tests only)."""
+    from fem_shell_amd.symbolic import blk_t16, pair_index
     P, _ = pair_index(nn)
-    out = np.empty((dense.shape[0], nn * (nn + 1) // 2, d * d))
+    E = dense.shape[0]
+    out = np.empty((E, nn * (nn + 1) // 2, d * d))
     for i in range(nn):
         for j in range(i, nn):
             out[:, P[i, j]] = dense[:, d * i:d * i + d, d * j:d * j + d].reshape(-1, d * d)
+    if tiled:
+        t16 = np.zeros((-(-E // 16) * 160, d * d))
+        for p in range(10):
+            t16[blk_t16(np.arange(E), p)] = out[:, p]
+        return t16
     return out
 
 
