@@ -1,0 +1,114 @@
+"""GPU parity against the reference's UNMODIFIED MeshAssembler (tests/golden/asm_ref.npz, made by
+tools/gen_golden_asm.py through the recording PETSc stand-in): dofs_count, _row_nnz, DOF maps and the
+assembled CSR of K / M / K_G and the load vector -- mixed MITC3/MITC4 with a 'properties' map, uniform
+MITC4 / MITC3, mixed HEXA8 / WEDGE6 / PYRAMID5 / TETRA4 and uniform HEXA8 (core/assembler.py:58-516).
+Pattern bit-exact, values 1e-12 relative to the largest entry (fp64 tolerance of BASELINE.json)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fem_shell_amd as fsa
+from fem_shell_amd import meshes
+from fem_shell_amd.elements import ElementFamily
+from tests import util
+from tests.util_golden import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _model(case):
+    steel = fsa.IsotropicMaterial("steel", 2.1e11, 0.3, 7800.0)
+    soft = fsa.IsotropicMaterial("scordelis", 4.32e8, 0.0, 360.0)
+    if case == "smix":
+        lam = fsa.create_laminate_from_angles(util.t300(), 2.5e-2, [0, 45, 90])
+        props = {"skin": fsa.ShellProperty(steel, 0.25), "web": fsa.ShellProperty(soft, 0.1),
+                 "cap": fsa.CompositeShellProperty(lam)}
+        return {"elements": {"element_family": ElementFamily.SHELL, "properties": props}}
+    if case == "quad":
+        return {"elements": {"element_family": ElementFamily.SHELL, "material": soft, "thickness": 0.25}}
+    if case == "tri":
+        return {"elements": {"element_family": ElementFamily.SHELL, "material": steel, "thickness": 0.05}}
+    if case == "somix":
+        return {"elements": {"element_family": ElementFamily.SOLID, "material": util.t300()}}
+    return {"elements": {"element_family": ElementFamily.SOLID, "material": steel}}
+
+
+def build(case, g):
+    from fem_shell_amd.assembler import MeshAssembler
+    kw = {}
+    if case == "smix":
+        kw = dict(set_id=g["smix_set_id"], set_names=["skin", "web", "cap"])
+    mesh = meshes.ArrayMesh(g[case + "_coords"], g[case + "_conn"], **kw)
+    return mesh, MeshAssembler(mesh, _model(case))
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def _same_matrix(A, g, tag, n):
+    """A (our CSR, K's full pattern) vs a reference matrix that holds only the inserted entries."""
+    ref = sp.csr_matrix((g[tag + "_data"], g[tag + "_indices"], g[tag + "_indptr"]), shape=(n, n))
+    ours = A.to_scipy()
+    diff = (ours - ref)
+    err = np.abs(diff.data).max() / np.abs(ref.data).max() if diff.nnz else 0.0
+    # every reference entry lies inside our pattern
+    pat = ours.copy(); pat.data[:] = 1.0
+    refp = ref.copy(); refp.data[:] = 1.0
+    assert (refp - refp.multiply(pat)).nnz == 0
+    return err
+
+
+@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex"])
+def test_reference_assembler_golden(case):
+    g = golden("asm_ref")
+    mesh, asm = build(case, g)
+    pre = case + "_"
+    assert asm.dofs_count == int(g[pre + "dofs_count"]) and asm.dofs_per_node == int(g[pre + "dofs_per_node"])
+    assert asm._is_mixed_mesh == bool(g[pre + "is_mixed"])
+    assert np.array_equal(asm._row_nnz, g[pre + "row_nnz"])                     # a17: bit-exact
+    if asm._is_mixed_mesh:
+        assert asm._dofs_array is None
+        assert np.array_equal(np.concatenate(asm._dofs_list), g[pre + "dofs_list"])
+    elif case == "quad":
+        assert np.array_equal(asm._dofs_array, g["quad_dofs_array"])
+    K = asm.assemble_stiffness_matrix()
+    assert np.array_equal(K.indptr.cpu().numpy(), g[pre + "K_indptr"])           # a18 pattern: bit-exact
+    assert np.array_equal(K.indices.cpu().numpy(), g[pre + "K_indices"])
+    eK = _rel(K.data.cpu().numpy(), g[pre + "K_data"])
+    eM = _rel(asm.assemble_mass_matrix().data.cpu().numpy(), g[pre + "M_data"])
+    print(case, "nnz", K.nnz, "K", eK, "M", eM)
+    assert eK < TOL and eM < TOL
+    n = asm.dofs_count
+    if case == "quad":      # K_G from a partial stress_field dict (elements without an entry are skipped)
+        sig, has = g["quad_sigma"], g["quad_has"]
+        KG = asm.assemble_geometric_stiffness(stress_field={int(e): sig[e] for e in np.flatnonzero(has)})
+        e = _same_matrix(KG, g, "quad_KG", n)
+        print("  K_G(stress_field)", e)
+        assert e < TOL
+        with pytest.raises(AttributeError):                                      # MITC4 has no centrifugal prestress
+            asm.assemble_geometric_stiffness(omega=1.0)
+    if case == "tri":       # omega mode (MITC3.compute_centrifugal_prestress)
+        p = g["tri_cfpar"]
+        KG = asm.assemble_geometric_stiffness(omega=float(p[0]), rotation_axis=p[1:4], rotation_center=p[4:7])
+        e = _same_matrix(KG, g, "tri_KG", n)
+        print("  K_G(omega)", e)
+        assert e < TOL
+    if case in ("somix", "hex"):
+        body = g["somix_body"]
+        F = asm.assemble_load_vector(SimpleNamespace(value=body)).cpu().numpy()
+        e = _rel(F, g[pre + "F"])
+        print("  load vector", e)
+        assert e < TOL
+    if case == "hex":
+        sig = g["hex_sigma"]
+        e1 = _same_matrix(asm.assemble_geometric_stiffness(stress_field={e: sig[e] for e in range(sig.shape[0])}),
+                          g, "hex_KG", n)
+        p = g["hex_cfpar"]
+        e2 = _same_matrix(asm.assemble_geometric_stiffness(omega=float(p[0]), rotation_axis=p[1:4],
+                                                           rotation_center=p[4:7]), g, "hex_KGo", n)
+        print("  K_G(stress_field)", e1, "K_G(omega)", e2)
+        assert e1 < TOL and e2 < TOL

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Golden fixtures from the reference's UNMODIFIED MeshAssembler and StressRecovery
+(core/assembler.py:12-516, postprocess/stress_recovery.py:280-1402), run through tools/ref_shim.py
+with its recording PETSc stand-in.  Build container only.
+
+    python tools/gen_golden_asm.py        # rewrites tests/golden/asm_ref.npz, stress_ref.npz
+
+Fixtures are DATA: seeded meshes (coords, connectivity, set ids, property parameters) and what the
+reference returns for them (dofs_count, _row_nnz, CSR of K / M / K_G, load vector, stress fields).
+Cases (prefix of every key):
+  smix_   mixed MITC3/MITC4 cylindrical patch, 3 element sets -> 2 ShellProperty + 1 asymmetric
+          CompositeShellProperty ('properties' map, core/assembler.py:113-143)
+  quad_   uniform MITC4 patch, material + thickness; K_G from a partial stress_field dict
+  tri_    uniform MITC3 patch; K_G in the omega mode (MITC3.compute_centrifugal_prestress)
+  somix_  HEXA8 + WEDGE6 + PYRAMID5 + TETRA4 beam (mixed node counts), orthotropic material, body load
+  hex_    uniform HEXA8 block; load vector; K_G from stress_field and from omega
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install_assembler_backend()
+ref_shim.ns_extra("fem_shell.postprocess", ref_shim.REF + "/postprocess")
+
+from fem_shell.core.assembler import MeshAssembler  # noqa: E402
+from fem_shell.core.laminate import create_laminate_from_angles  # noqa: E402
+from fem_shell.core.material import IsotropicMaterial, OrthotropicMaterial  # noqa: E402
+from fem_shell.core.properties import CompositeShellProperty, ShellProperty  # noqa: E402
+from fem_shell.elements import ElementFamily  # noqa: E402
+from fem_shell.postprocess.stress_recovery import StressLocation, StressRecovery, StressType  # noqa: E402
+
+from fem_shell_amd import meshes  # noqa: E402  (array mesh generators only; no kernels involved)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+T300 = dict(E=(181e9, 10.3e9, 10.3e9), G=(7.17e9, 3.0e9, 7.17e9), nu=(0.28, 0.28, 0.28), rho=1600.0)
+
+
+class RefMesh:
+    """The mesh protocol the reference assembler touches (core/assembler.py:72,107,113-119,220) and
+    StressRecovery needs (coords_array, node_id_to_index)."""
+
+    def __init__(self, coords, conn, set_id=None, set_names=None):
+        self.coords_array = coords
+        self.node_count = coords.shape[0]
+        self.node_id_to_index = {i: i for i in range(coords.shape[0])}
+        self.elements = []
+        for e, row in enumerate(conn):
+            ids = tuple(int(i) for i in row if i >= 0)
+            self.elements.append(SimpleNamespace(id=e, node_ids=ids, node_count=len(ids),
+                                                 node_coords=coords[list(ids)], thickness=None))
+        self.element_sets = {}
+        if set_id is not None:
+            for s, name in enumerate(set_names):
+                self.element_sets[name] = SimpleNamespace(
+                    elements=[self.elements[i] for i in np.flatnonzero(set_id == s)])
+
+
+def csr(mat, tag, out):
+    out[tag + "_indptr"], out[tag + "_indices"], out[tag + "_data"] = mat.indptr, mat.indices, mat.data
+
+
+def asm_common(asm, pre, out):
+    out[pre + "dofs_count"] = asm.dofs_count
+    out[pre + "dofs_per_node"] = asm.dofs_per_node
+    out[pre + "row_nnz"] = np.asarray(asm._row_nnz)
+    out[pre + "is_mixed"] = bool(asm._is_mixed_mesh)
+    csr(asm.assemble_stiffness_matrix(), pre + "K", out)
+    M = asm.assemble_mass_matrix()
+    out[pre + "M_data"] = M.data
+
+
+LOCS = (StressLocation.TOP, StressLocation.MIDDLE, StressLocation.BOTTOM)
+TYPES = (StressType.TOTAL, StressType.MEMBRANE, StressType.BENDING)
+
+
+def stress_fields(asm, u, pre, out, shell):
+    """Every public StressRecovery product (stress_recovery.py:710-1081) for a seeded u."""
+    sr = StressRecovery(asm, u)
+    out[pre + "u"] = u
+    combos = [(l, t) for l in LOCS for t in TYPES] if shell else [(StressLocation.MIDDLE, StressType.TOTAL)]
+    for loc, typ in combos:
+        tag = f"{pre}{loc.value}_{typ.value}_"
+        for name, res in (("elem", sr.compute_element_stresses(loc, typ)),
+                          ("nodal", sr.compute_nodal_stresses(loc, typ)),
+                          ("nodalw", sr.compute_nodal_stresses(loc, typ, smoothing="area_weighted"))):
+            for k, v in res.to_dict().items():
+                out[tag + name + "_" + k] = np.asarray(v)
+    if shell:
+        res = sr.compute_element_stresses(StressLocation.TOP, StressType.TOTAL, gauss_point=(0.3, -0.2)
+                                          if asm._element_map[0].node_count == 4 else (0.2, 0.5))
+        for k, v in res.to_dict().items():
+            out[pre + "elem_offcentre_" + k] = np.asarray(v)
+    for loc in (LOCS if shell else LOCS[1:2]):
+        tag = f"{pre}{loc.value}_"
+        for name, res in (("elem", sr.compute_element_strains(loc)), ("nodal", sr.compute_nodal_strains(loc)),
+                          ("nodalw", sr.compute_nodal_strains(loc, smoothing="area_weighted"))):
+            for k, v in res.to_dict().items():
+                out[tag + name + "_strain_" + k] = np.asarray(v)
+
+
+def seeded_u(rng, coords, d, amp=1e-3):
+    size = np.ptp(coords, axis=0).max()
+    u = rng.standard_normal((coords.shape[0], d)) * amp * size
+    if d == 6:
+        u[:, 3:] /= size
+    return u.reshape(-1)
+
+
+def shell_cases(out, sout):
+    rng = np.random.default_rng(41)
+    steel = IsotropicMaterial("steel", 2.1e11, 0.3, 7800.0)
+    soft = IsotropicMaterial("scordelis", 4.32e8, 0.0, 360.0)
+    t300 = OrthotropicMaterial(name="T300/5208", **T300)
+    # --- smix_: mixed tri/quad, property map -------------------------------------------------
+    base = meshes.cylindrical_patch(25.0, 25.0, 40.0, 6, 5)
+    coords = base.coords + 0.05 * rng.standard_normal(base.coords.shape)
+    conn = meshes.mixed_conn(6, 5)
+    set_id = (np.arange(conn.shape[0]) % 3).astype(np.int32)
+    names = ["skin", "web", "cap"]
+    lam = create_laminate_from_angles(t300, 2.5e-2, [0, 45, 90])
+    props = {"skin": ShellProperty(steel, 0.25), "web": ShellProperty(soft, 0.1), "cap": CompositeShellProperty(lam)}
+    mesh = RefMesh(coords, conn, set_id, names)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "properties": props}})
+    out.update(smix_coords=coords, smix_conn=conn, smix_set_id=set_id)
+    asm_common(asm, "smix_", out)
+    out["smix_dofs_list"] = np.concatenate(asm._dofs_list)
+    stress_fields(asm, seeded_u(rng, coords, 6), "smix_", sout, shell=True)
+    # --- quad_: uniform MITC4, K_G from a partial stress_field -------------------------------
+    base = meshes.cylindrical_patch(25.0, 25.0, 40.0, 7, 6)
+    coords = base.coords + 0.03 * rng.standard_normal(base.coords.shape)
+    conn = base.conn
+    mesh = RefMesh(coords, conn)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": soft, "thickness": 0.25}})
+    out.update(quad_coords=coords, quad_conn=conn)
+    asm_common(asm, "quad_", out)
+    out["quad_dofs_array"] = asm._dofs_array
+    sig = rng.standard_normal((conn.shape[0], 3)) * 1e6
+    has = rng.random(conn.shape[0]) < 0.7
+    sig[3] *= 1e-30
+    out.update(quad_sigma=sig, quad_has=has)
+    KG = asm.assemble_geometric_stiffness(stress_field={int(e): sig[e] for e in np.flatnonzero(has)})
+    csr(KG, "quad_KG", out)
+    stress_fields(asm, seeded_u(rng, coords, 6), "quad_", sout, shell=True)
+    # --- tri_: uniform MITC3, omega mode -----------------------------------------------------
+    base = meshes.twisted_beam(12.0, 1.1, 90.0, 8, 3, triangular=True)
+    coords, conn = base.coords + 0.01 * rng.standard_normal(base.coords.shape), base.conn
+    mesh = RefMesh(coords, conn)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": steel, "thickness": 0.05}})
+    out.update(tri_coords=coords, tri_conn=conn)
+    asm_common(asm, "tri_", out)
+    par = dict(omega=1.7, rotation_axis=np.array([0.3, -0.2, 2.0]), rotation_center=np.array([-1.0, 0.5, 0.2]))
+    out["tri_cfpar"] = np.concatenate([[par["omega"]], par["rotation_axis"], par["rotation_center"]])
+    csr(asm.assemble_geometric_stiffness(**par), "tri_KG", out)
+    stress_fields(asm, seeded_u(rng, coords, 6), "tri_", sout, shell=True)
+
+
+def hex_grid(nx, ny, nz, rng, jitter=0.08):
+    ids = np.arange((nx + 1) * (ny + 1) * (nz + 1)).reshape(nz + 1, ny + 1, nx + 1)
+    Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
+    coords = np.stack([X, Y, Z], -1).reshape(-1, 3) + jitter * rng.standard_normal((ids.size, 3))
+    c = [ids[:-1, :-1, :-1], ids[:-1, :-1, 1:], ids[:-1, 1:, 1:], ids[:-1, 1:, :-1],
+         ids[1:, :-1, :-1], ids[1:, :-1, 1:], ids[1:, 1:, 1:], ids[1:, 1:, :-1]]
+    return coords, np.stack(c, -1).reshape(-1, 8)
+
+
+def solid_cases(out, sout):
+    rng = np.random.default_rng(43)
+    # --- somix_: hexes, two of them split into wedges / pyramids + tets ----------------------
+    coords, hexes = hex_grid(5, 1, 1, rng)
+    rows = []
+    for e, h in enumerate(hexes):
+        if e == 1:      # two wedges (triangles n0 n1 n2 / n0 n2 n3 extruded)
+            rows += [(h[0], h[1], h[2], h[4], h[5], h[6], -1, -1), (h[0], h[2], h[3], h[4], h[6], h[7], -1, -1)]
+        elif e == 3:    # six pyramids on the faces, apex = new centre node
+            cen = coords.shape[0]
+            coords = np.vstack([coords, coords[h].mean(axis=0)])
+            faces = [(h[0], h[1], h[2], h[3]), (h[4], h[7], h[6], h[5]), (h[0], h[4], h[5], h[1]),
+                     (h[1], h[5], h[6], h[2]), (h[2], h[6], h[7], h[3]), (h[3], h[7], h[4], h[0])]   # normals inwards
+            rows += [(f[0], f[1], f[2], f[3], cen, -1, -1, -1) for f in faces]
+        elif e == 4:    # wedge 1 kept, wedge 2 cut into three tetrahedra
+            rows.append((h[0], h[1], h[2], h[4], h[5], h[6], -1, -1))
+            a, b, c, d, e_, f = h[0], h[2], h[3], h[4], h[6], h[7]
+            for t in ((a, b, c, f), (a, b, f, e_), (a, e_, f, d)):
+                x = coords[list(t)]
+                if np.linalg.det(x[1:] - x[0]) < 0:
+                    t = (t[0], t[2], t[1], t[3])
+                rows.append(t + (-1,) * 4)
+        else:
+            rows.append(tuple(h))
+    conn = np.array(rows, dtype=np.int64)
+    ortho = OrthotropicMaterial(name="T300/5208", **T300)
+    mesh = RefMesh(coords, conn)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SOLID, "material": ortho}})
+    out.update(somix_coords=coords, somix_conn=conn)
+    asm_common(asm, "somix_", out)
+    out["somix_dofs_list"] = np.concatenate(asm._dofs_list)
+    body = np.array([1.0, -2.0, -9.81])
+    out["somix_body"] = body
+    out["somix_F"] = asm.assemble_load_vector(SimpleNamespace(value=body)).array
+    stress_fields(asm, seeded_u(rng, coords, 3), "somix_", sout, shell=False)
+    # --- hex_: uniform HEXA8 -----------------------------------------------------------------
+    coords, conn = hex_grid(4, 3, 2, rng)
+    iso = IsotropicMaterial("steel", 2.1e11, 0.3, 7800.0)
+    mesh = RefMesh(coords, conn)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SOLID, "material": iso}})
+    out.update(hex_coords=coords, hex_conn=conn)
+    asm_common(asm, "hex_", out)
+    out["hex_F"] = asm.assemble_load_vector(SimpleNamespace(value=body)).array
+    sig = rng.standard_normal((conn.shape[0], 6)) * 1e6
+    out["hex_sigma"] = sig
+    csr(asm.assemble_geometric_stiffness(stress_field={e: sig[e] for e in range(conn.shape[0])}), "hex_KG", out)
+    par = dict(omega=2.3, rotation_axis=np.array([0.0, 0.4, 1.0]), rotation_center=np.array([-3.0, 0.5, 0.2]))
+    out["hex_cfpar"] = np.concatenate([[par["omega"]], par["rotation_axis"], par["rotation_center"]])
+    csr(asm.assemble_geometric_stiffness(**par), "hex_KGo", out)
+    stress_fields(asm, seeded_u(rng, coords, 3), "hex_", sout, shell=False)
+
+
+if __name__ == "__main__":
+    out, sout = {}, {}
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):      # the reference prints progress lines
+        shell_cases(out, sout)
+        solid_cases(out, sout)
+    np.savez_compressed(os.path.join(OUT, "asm_ref.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "stress_ref.npz"), **sout)
+    print("asm_ref.npz", len(out), "arrays;", "stress_ref.npz", len(sout), "arrays")
+    for f in ("asm_ref.npz", "stress_ref.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
