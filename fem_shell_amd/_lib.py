@@ -9,6 +9,8 @@ LIB_PATH = os.environ.get("FEMSHELL_HIP_LIB") or os.path.join(_HERE, "csrc", "li
 FS_WANT_K, FS_WANT_M, FS_WANT_KT, FS_WANT_FINT = 1, 2, 4, 8
 FS_WANT_FBODY, FS_WANT_KG = 16, 32
 FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK, FS_LAYOUT_SYMBLK_T16 = 0, 1, 2
+FS_STRESS_MEMBRANE, FS_STRESS_BENDING = 1, 2
+FS_SOLID_STRESS_GP, FS_SOLID_STRESS_MEAN, FS_SOLID_STRESS_NODES = 0, 1, 2
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
 
@@ -46,6 +48,12 @@ SIGNATURES = {
     "fs_halo_pack": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "fs_shell_stress_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _u32, _i32,
+                                             _vp, _vp, _vp]),
+    "fs_solid_stress_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp,
+                                             _vp, _vp]),
+    "fs_nodal_average": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "fs_stress_invariants": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -387,8 +387,6 @@ class MeshAssembler:
     # --- new (SURVEY.md 8a "New"): Newton re-assembly of K_T(u) and f_int(u) -----------------
     def _element_displacements(self, u):
         """u_e[e] = u[dofs_e] for every element group (fs_gather_dofs)."""
-        if self._family != ElementFamily.SHELL:
-            raise NotImplementedError("K_T / f_int re-assembly is available for shell meshes (MITC4 / MITC3)")
         lib = _lib.load()
         u = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
         if u.numel() != self.dofs_count:
@@ -408,6 +406,8 @@ class MeshAssembler:
 
     def _nl_pass(self, u, want_KT, want_F):
         """Per group: update_configuration(u_e) + compute_tangent_stiffness / compute_internal_forces."""
+        if self._family != ElementFamily.SHELL:
+            raise NotImplementedError("K_T / f_int re-assembly is available for shell meshes (MITC4 / MITC3)")
         ues = self._element_displacements(u)
         buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
         fparts = []

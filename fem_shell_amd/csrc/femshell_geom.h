@@ -1,0 +1,290 @@
+// femshell_geom.h -- device geometry helpers shared by the element-matrix kernels (femshell_hip.hip)
+// and the stress-recovery kernels (femshell_stress.hip).  Internal; included inside each file's
+// anonymous namespace region.  Compile with -ffp-contract=off (see femshell_hip.hip header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "femshell_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// rounding-pinned primitives (file default: contraction OFF)
+// ------------------------------------------------------------------------------------------
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+__device__ __forceinline__ double dot3(const double *a, const double *b) {
+    // np.dot on contiguous length-3 float64 == sequential FMA chain
+    double s = a[0] * b[0];
+    s = FMA(a[1], b[1], s);
+    s = FMA(a[2], b[2], s);
+    return s;
+}
+__device__ __forceinline__ double dots4(double a0, double a1, double a2, double a3, double b0,
+                                        double b1, double b2, double b3) {
+    // np.dot(dN, xl[:, k]) (strided operand, n = 4): OpenBLAS generic-stride ddot
+    double m2 = a2 * b2, m3 = a3 * b3;
+    double t1 = FMA(a0, b0, m2), t2 = FMA(a1, b1, m3);
+    return t1 + t2;
+}
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
+    // np.cross: rounded products, then subtraction
+    double p, q;
+    p = a[1] * b[2]; q = a[2] * b[1]; c[0] = p - q;
+    p = a[2] * b[0]; q = a[0] * b[2]; c[1] = p - q;
+    p = a[0] * b[1]; q = a[1] * b[0]; c[2] = p - q;
+}
+__device__ __forceinline__ double norm3(const double *a) { return __builtin_sqrt(dot3(a, a)); }
+
+// IEEE division with a SHARED reciprocal: the same arithmetic as the compiler's f64 fdiv expansion
+// (v_rcp_f64, two Newton steps, quotient, residual, correction) minus the v_div_scale / v_div_fixup
+// range handling, which is the identity for the magnitudes met here (no operand near 2^+-1000).
+// Several numerators over one denominator (a vector / its norm, cofactors / det) then cost one
+// reciprocal instead of one per quotient; results are bit-identical (tests: geometry bitwise).
+__device__ __forceinline__ double recip(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = FMA(-b, r, 1.0);
+    r = FMA(r, e, r);
+    e = FMA(-b, r, 1.0);
+    r = FMA(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double divr(double a, double b, double r) {
+    const double q = a * r;
+    const double d = FMA(-b, q, a);
+    return FMA(d, r, q);
+}
+
+constexpr double kGP = 0.57735026918962584;  // 1.0/np.sqrt(3.0)  (MITC4.py:87)
+
+struct QuadGeom {
+    double e1[3], e2[3], e3[3];
+    double xl[4][2];
+    double a[5];  // a_A..a_E
+    int status;
+};
+
+// MITC4.py:436-476 (_compute_local_coordinates) + :157-208 (characteristic vectors, coefficients)
+__device__ __forceinline__ void quad_geometry(const double (&x)[4][3], QuadGeom &g) {
+    g.status = 0;
+    double v1[3], v2[3], c1[3], c2[3], n1[3], n2[3];
+    for (int k = 0; k < 3; k++) { v1[k] = x[1][k] - x[0][k]; v2[k] = x[2][k] - x[0][k]; }
+    cross3(v1, v2, c1);
+    const double l1 = norm3(c1);
+    const bool ok1 = l1 > 1e-12;
+    const double rl1 = recip(l1);
+    for (int k = 0; k < 3; k++) n1[k] = divr(c1[k], l1, rl1);
+    for (int k = 0; k < 3; k++) { v1[k] = x[2][k] - x[0][k]; v2[k] = x[3][k] - x[0][k]; }
+    cross3(v1, v2, c2);
+    const double l2 = norm3(c2);
+    const bool ok2 = l2 > 1e-12;
+    const double rl2 = recip(l2);
+    for (int k = 0; k < 3; k++) n2[k] = divr(c2[k], l2, rl2);
+    double e3[3];
+    for (int k = 0; k < 3; k++) {
+        const double both = (n1[k] + n2[k]) / 2.0;
+        e3[k] = (ok1 && ok2) ? both : (ok1 ? n1[k] : (ok2 ? n2[k] : (k == 2 ? 1.0 : 0.0)));
+    }
+    if (ok1 || ok2) {
+        const double l = norm3(e3), rl = recip(l);
+        for (int k = 0; k < 3; k++) e3[k] = divr(e3[k], l, rl);
+    }
+    double e1[3];
+    for (int k = 0; k < 3; k++) e1[k] = x[1][k] - x[0][k];
+    double d = dot3(e1, e3);
+    for (int k = 0; k < 3; k++) { const double t = d * e3[k]; e1[k] = e1[k] - t; }
+    if (norm3(e1) < 1e-12) {
+        for (int k = 0; k < 3; k++) e1[k] = x[2][k] - x[0][k];
+        d = dot3(e1, e3);
+        for (int k = 0; k < 3; k++) { const double t = d * e3[k]; e1[k] = e1[k] - t; }
+    }
+    double l = norm3(e1), rl = recip(l);
+    for (int k = 0; k < 3; k++) e1[k] = divr(e1[k], l, rl);
+    double e2[3];
+    cross3(e3, e1, e2);
+    l = norm3(e2);
+    rl = recip(l);
+    for (int k = 0; k < 3; k++) e2[k] = divr(e2[k], l, rl);
+    for (int k = 0; k < 3; k++) { g.e1[k] = e1[k]; g.e2[k] = e2[k]; g.e3[k] = e3[k]; }
+    for (int i = 0; i < 4; i++) { g.xl[i][0] = dot3(x[i], e1); g.xl[i][1] = dot3(x[i], e2); }
+    if (!(l == l) || !(g.xl[0][0] == g.xl[0][0])) g.status |= FS_ST_NAN_FRAME;
+
+    // characteristic vectors (Ko, Lee, Bathe 2017, eqs 9-12)
+    double xr[3], xs[3], xd[3], nv[3], nh[3];
+    for (int k = 0; k < 3; k++) {
+        xr[k] = 0.25 * (((-x[0][k] + x[1][k]) + x[2][k]) - x[3][k]);
+        xs[k] = 0.25 * (((-x[0][k] - x[1][k]) + x[2][k]) + x[3][k]);
+        xd[k] = 0.25 * (((x[0][k] - x[1][k]) + x[2][k]) - x[3][k]);
+    }
+    cross3(xr, xs, nv);
+    double nn = norm3(nv);
+    if (nn < 1e-12) {
+        double a[3], b[3];
+        for (int k = 0; k < 3; k++) { a[k] = x[1][k] - x[0][k]; b[k] = x[2][k] - x[0][k]; }
+        cross3(a, b, nv);
+        nn = norm3(nv);
+    }
+    const double rnn = recip(nn);
+    for (int k = 0; k < 3; k++) nh[k] = divr(nv[k], nn, rnn);
+    const double A00 = dot3(xr, xr), A01 = dot3(xr, xs), A02 = dot3(xr, nh);
+    const double A10 = dot3(xs, xr), A11 = dot3(xs, xs), A12 = dot3(xs, nh);
+    const double A20 = dot3(nh, xr), A21 = dot3(nh, xs), A22 = dot3(nh, nh);
+    // dual vectors: np.linalg.solve(A, e_k) -> closed-form adjugate (eps-level difference only)
+    const double c00 = A11 * A22 - A12 * A21, c01 = A12 * A20 - A10 * A22, c02 = A10 * A21 - A11 * A20;
+    const double det = A00 * c00 + A01 * c01 + A02 * c02;
+    double mr[3], ms[3];
+    if (det != 0.0) {
+        const double c10 = A02 * A21 - A01 * A22, c11 = A00 * A22 - A02 * A20, c12 = A01 * A20 - A00 * A21;
+        const double rdet = recip(det);
+        const double r0 = divr(c00, det, rdet), r1 = divr(c01, det, rdet), r2 = divr(c02, det, rdet);
+        const double s0 = divr(c10, det, rdet), s1 = divr(c11, det, rdet), s2 = divr(c12, det, rdet);
+        for (int k = 0; k < 3; k++) {
+            mr[k] = r0 * xr[k] + r1 * xs[k] + r2 * nh[k];
+            ms[k] = s0 * xr[k] + s1 * xs[k] + s2 * nh[k];
+        }
+    } else {
+        for (int k = 0; k < 3; k++) { mr[k] = xr[k] / A00; ms[k] = xs[k] / A11; }
+    }
+    const double c_r = dot3(xd, mr), c_s = dot3(xd, ms);
+    double dd = c_r * c_r + c_s * c_s - 1.0;
+    if (__builtin_fabs(dd) < 1e-12) dd = (dd >= 0) ? 1e-12 : -1e-12;
+    const double dd2 = 2.0 * dd, rdd2 = recip(dd2);
+    g.a[0] = divr(c_r * (c_r - 1.0), dd2, rdd2);
+    g.a[1] = divr(c_r * (c_r + 1.0), dd2, rdd2);
+    g.a[2] = divr(c_s * (c_s - 1.0), dd2, rdd2);
+    g.a[3] = divr(c_s * (c_s + 1.0), dd2, rdd2);
+    g.a[4] = -2.0 * c_r * c_s / dd;
+    if (!(g.a[0] == g.a[0])) g.status |= FS_ST_BAD_COEFF;
+}
+
+// MITC4.py:141-155
+__device__ __forceinline__ void dshape(double xi, double eta, double *dxi, double *deta) {
+    dxi[0] = -0.25 * (1.0 - eta); dxi[1] = +0.25 * (1.0 - eta);
+    dxi[2] = +0.25 * (1.0 + eta); dxi[3] = -0.25 * (1.0 + eta);
+    deta[0] = -0.25 * (1.0 - xi); deta[1] = -0.25 * (1.0 + xi);
+    deta[2] = +0.25 * (1.0 + xi); deta[3] = +0.25 * (1.0 - xi);
+}
+
+// MITC4.py:614-632 (J) ; returns detJ, fills J^-1 = [[ia, ib],[ic, id]]
+__device__ __forceinline__ double jacobian(const QuadGeom &g, const double *dxi, const double *deta,
+                                           double &ia, double &ib, double &ic, double &id) {
+    const double J00 = dots4(dxi[0], dxi[1], dxi[2], dxi[3], g.xl[0][0], g.xl[1][0], g.xl[2][0], g.xl[3][0]);
+    const double J01 = dots4(dxi[0], dxi[1], dxi[2], dxi[3], g.xl[0][1], g.xl[1][1], g.xl[2][1], g.xl[3][1]);
+    const double J10 = dots4(deta[0], deta[1], deta[2], deta[3], g.xl[0][0], g.xl[1][0], g.xl[2][0], g.xl[3][0]);
+    const double J11 = dots4(deta[0], deta[1], deta[2], deta[3], g.xl[0][1], g.xl[1][1], g.xl[2][1], g.xl[3][1]);
+    const double p = J00 * J11, q = J01 * J10;
+    const double det = p - q;
+    const double rdet = recip(det);
+    ia = divr(J11, det, rdet); ib = divr(-J01, det, rdet); ic = divr(-J10, det, rdet); id = divr(J00, det, rdet);
+    return det;
+}
+
+
+struct TriGeom {
+    double e1[3], e2[3], e3[3];
+    double x2, x3, y3, area, J00, J10, J11;
+    int status;
+};
+
+// MITC3.py:375-418 (_compute_local_coordinates), :427-469 (area, J), :527-558 (dH)
+__device__ __forceinline__ void tri_geometry(const double (&x)[3][3], TriGeom &t) {
+    double v12[3], v13[3], n[3];
+    for (int k = 0; k < 3; k++) { v12[k] = x[1][k] - x[0][k]; v13[k] = x[2][k] - x[0][k]; }
+    const double L12 = norm3(v12);
+    for (int k = 0; k < 3; k++) t.e1[k] = v12[k] / L12;
+    cross3(v12, v13, n);
+    const double nl = norm3(n);
+    t.status = (nl >= 1e-12) ? 0 : FS_ST_NAN_FRAME;  // ValueError("Degenerate triangle")
+    for (int k = 0; k < 3; k++) t.e3[k] = n[k] / nl;
+    cross3(t.e3, t.e1, t.e2);
+    t.x2 = L12; t.x3 = dot3(v13, t.e1); t.y3 = dot3(v13, t.e2);
+    const double det = t.x2 * t.y3;      // J = [[x2, 0], [x3, y3]]
+    t.area = 0.5 * __builtin_fabs(det);
+    t.J00 = t.y3 / det; t.J10 = -t.x3 / det; t.J11 = t.x2 / det;   // J^-1, J01^-1 == 0
+}
+
+
+struct SolidRule { double pt[8][3]; double w[8]; int ng; };
+
+template <int NN>
+__device__ __forceinline__ void solid_shape(double xi, double eta, double zeta, double *N, double *dxi,
+                                            double *deta, double *dzeta) {
+    if constexpr (NN == 8) {  // SOLID.py:1768-1818
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const double sx = ((i & 3) == 1 || (i & 3) == 2) ? 1.0 : -1.0, sy = (i & 2) ? 1.0 : -1.0, sz = (i & 4) ? 1.0 : -1.0;
+            const double fx = 1.0 + sx * xi, fy = 1.0 + sy * eta, fz = 1.0 + sz * zeta;
+            N[i] = 0.125 * (fx * fy * fz);
+            dxi[i] = 0.125 * (sx * fy * fz); deta[i] = 0.125 * (sy * fx * fz); dzeta[i] = 0.125 * (sz * fx * fy);
+        }
+    } else if constexpr (NN == 4) {  // SOLID.py:1581-1597
+        N[0] = 1.0 - xi - eta - zeta; N[1] = xi; N[2] = eta; N[3] = zeta;
+        dxi[0] = -1.0; dxi[1] = 1.0; dxi[2] = 0.0; dxi[3] = 0.0;
+        deta[0] = -1.0; deta[1] = 0.0; deta[2] = 1.0; deta[3] = 0.0;
+        dzeta[0] = -1.0; dzeta[1] = 0.0; dzeta[2] = 0.0; dzeta[3] = 1.0;
+    } else if constexpr (NN == 6) {  // SOLID.py:756-829
+        const double L[3] = {1.0 - xi - eta, xi, eta}, Lm = 0.5 * (1.0 - zeta), Lp = 0.5 * (1.0 + zeta);
+        const double dLx[3] = {-1.0, 1.0, 0.0}, dLe[3] = {-1.0, 0.0, 1.0};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            N[i] = L[i] * Lm; N[3 + i] = L[i] * Lp;
+            dxi[i] = dLx[i] * Lm; dxi[3 + i] = dLx[i] * Lp;
+            deta[i] = dLe[i] * Lm; deta[3 + i] = dLe[i] * Lp;
+            dzeta[i] = L[i] * -0.5; dzeta[3 + i] = L[i] * 0.5;
+        }
+    } else {  // PYRAMID5, SOLID.py:1129-1218
+        static_assert(NN == 5, "unsupported solid");
+        double r = 1.0 - zeta;
+        r = (r < 1e-14) ? 1e-14 : r;
+        const double r2 = r * r, rmx = r - xi, rpx = r + xi, rme = r - eta, rpe = r + eta;
+        N[0] = 0.25 * rmx * rme / r; N[1] = 0.25 * rpx * rme / r; N[2] = 0.25 * rpx * rpe / r; N[3] = 0.25 * rmx * rpe / r; N[4] = zeta;
+        dxi[0] = -0.25 * rme / r; dxi[1] = 0.25 * rme / r; dxi[2] = 0.25 * rpe / r; dxi[3] = -0.25 * rpe / r; dxi[4] = 0.0;
+        deta[0] = -0.25 * rmx / r; deta[1] = -0.25 * rpx / r; deta[2] = 0.25 * rpx / r; deta[3] = 0.25 * rmx / r; deta[4] = 0.0;
+        dzeta[0] = -0.25 * (rme + rmx) / r + 0.25 * rmx * rme / r2;
+        dzeta[1] = -0.25 * (rme + rpx) / r + 0.25 * rpx * rme / r2;
+        dzeta[2] = -0.25 * (rpe + rpx) / r + 0.25 * rpx * rpe / r2;
+        dzeta[3] = -0.25 * (rpe + rmx) / r + 0.25 * rmx * rpe / r2;
+        dzeta[4] = 1.0;
+    }
+}
+
+
+// Integration rule of a linear solid as the reference builds it (SOLID.py:731-754 WEDGE6 -- weights sum
+// to 2, kept; :1099-1127 PYRAMID5; :1575-1579 TETRA4; :1744-1766 HEXA8, reduced = one point, weight 8).
+inline void make_solid_rule(int nn, int reduced, SolidRule &rule) {
+    memset(&rule, 0, sizeof rule);
+    const double gp = 0.57735026918962584;   // 1/np.sqrt(3)
+    if (nn == 8) {
+        if (reduced) { rule.ng = 1; rule.w[0] = 8.0; }
+        else {
+            rule.ng = 8;
+            for (int q = 0; q < 8; q++) {
+                rule.pt[q][0] = (q & 1) ? gp : -gp; rule.pt[q][1] = (q & 2) ? gp : -gp; rule.pt[q][2] = (q & 4) ? gp : -gp;
+                rule.w[q] = 1.0;
+            }
+        }
+    } else if (nn == 4) {
+        rule.ng = 1; rule.pt[0][0] = rule.pt[0][1] = rule.pt[0][2] = 0.25; rule.w[0] = 1.0 / 6;
+    } else if (nn == 6) {
+        const double tp[3][2] = {{1.0 / 6, 1.0 / 6}, {2.0 / 3, 1.0 / 6}, {1.0 / 6, 2.0 / 3}};
+        rule.ng = 6;
+        for (int q = 0; q < 6; q++) {
+            rule.pt[q][0] = tp[q / 2][0]; rule.pt[q][1] = tp[q / 2][1]; rule.pt[q][2] = (q & 1) ? gp : -gp;
+            rule.w[q] = (1.0 / 6) * 1.0 * 2;
+        }
+    } else {
+        const double a = 0.26318405556971359557, za = 0.54415184401122528880, wa = 0.10078588207982543059;
+        const double b = 0.50661630334978742377, zb = 0.12251482265544137787, wb = 0.23254745125350790274;
+        const double sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+        rule.ng = 8;
+        for (int q = 0; q < 4; q++) {
+            rule.pt[q][0] = sx[q] * a; rule.pt[q][1] = sy[q] * a; rule.pt[q][2] = za; rule.w[q] = wa;
+            rule.pt[4 + q][0] = sx[q] * b; rule.pt[4 + q][1] = sy[q] * b; rule.pt[4 + q][2] = zb; rule.w[4 + q] = wb;
+        }
+    }
+}
+
+}  // namespace

@@ -163,6 +163,64 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
                              const void *props, int32_t n_props, double omega, const double *axis_host,
                              const double *center_host, int64_t E, double *sigma, void *stream);
 
+/*
+ * Batched stress / strain recovery (postprocess/stress_recovery.py:280-1402).
+ *
+ * fs_shell_stress_batch: StressRecovery._compute_shell_stress / _compute_shell_strain (:529-650) of
+ * every MITC4 (nn = 4) / MITC3 (nn = 3) element at `npts` parametric points.
+ *   u_e       [E][6 nn] element displacement vectors (slices of the global vector, global axes -- the
+ *             reference applies B_m / B_kappa to them without a T-transformation; kept)
+ *   pts_host  [npts][2] (r, s) in HOST memory, 1 <= npts <= 4 (element centre, or the nn parametric node
+ *             positions of compute_nodal_stresses, :355-358)
+ *   location  +1 TOP (z = +h/2), 0 MIDDLE, -1 BOTTOM (z = -h/2)
+ *   parts     FS_STRESS_MEMBRANE | FS_STRESS_BENDING (StressType MEMBRANE / BENDING / TOTAL); ignored for
+ *             strains (always eps_m + z kappa)
+ *   strain    0: stress (Cm / h)(...), 1: strain
+ *   out       [E][npts][3]  [xx, yy, xy];   weight [E][npts] or NULL: element area (:1372-1388) repeated
+ *             per point (the weight of the area-weighted smoothing)
+ */
+#define FS_STRESS_MEMBRANE 1u
+#define FS_STRESS_BENDING 2u
+int fs_shell_stress_batch(int32_t nn, const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                          int32_t n_props, const double *u_e, int64_t E, const double *pts_host, int32_t npts,
+                          int32_t location, uint32_t parts, int32_t strain, double *out, double *weight,
+                          void *stream);
+
+/*
+ * fs_solid_stress_batch: _compute_solid_gauss_stresses (:655-705) of TETRA4 / PYRAMID5 / WEDGE6 / HEXA8.
+ *   u_e [E][3 nn];  props as for fs_solid_batch (C is used as stored);  mode:
+ *   FS_SOLID_STRESS_GP     sigma / eps [E][ngp][6] at the Gauss points (Voigt xx,yy,zz,xy,yz,zx)
+ *   FS_SOLID_STRESS_MEAN   [E][6] mean over the Gauss points (compute_element_stresses, :761-764)
+ *   FS_SOLID_STRESS_NODES  [E][nn][6] = extrap @ Gauss values, extrap [nn][ngp] on the device
+ *                          (E = inv / pinv of N_gp, :437-492, evaluated on the host like the reference)
+ *   sigma, eps  either may be NULL;  weight [E] or NULL: element volume sum |det J| w (:1391-1402)
+ */
+#define FS_SOLID_STRESS_GP 0
+#define FS_SOLID_STRESS_MEAN 1
+#define FS_SOLID_STRESS_NODES 2
+int fs_solid_stress_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t *prop_id,
+                          const double *props, int32_t n_props, const double *u_e, int64_t E,
+                          const double *extrap, int32_t mode, double *sigma, double *eps, double *weight,
+                          void *stream);
+
+/*
+ * fs_nodal_average: the smoothing loop of compute_nodal_stresses / compute_nodal_strains (:844-864):
+ * out[n][c] = sum_q w_q vals[src[q]][c] / sum_q w_q over q in [seg_ptr[n], seg_ptr[n+1]) (element
+ * order), 0 where a node has no source; c < ncomp, the remaining columns of out [n_nodes][6] are 0.
+ *   vals [n_src][ncomp];  w_src [n_src] or NULL (weights 1)
+ */
+int fs_nodal_average(const double *vals, int32_t ncomp, const double *w_src, const int64_t *seg_ptr,
+                     const int64_t *src, int64_t n_nodes, double *out, void *stream);
+
+/*
+ * fs_stress_invariants: _build_stress_result / _build_strain_result (:1087-1341) of N Voigt rows
+ * [xx, yy, zz, xy, yz, zx].
+ *   strain = 0: out [6][N] = von Mises, s1, s2, s3, tau_max, principal angle (rad); is_3d selects the
+ *               Cardano form (s3 valid, angle 0) or the Mohr circle on (xx, yy, xy) (s3 = 0)
+ *   strain = 1: out [3][N] = e1, e2, gamma_max
+ */
+int fs_stress_invariants(const double *voigt, int64_t N, int32_t is_3d, int32_t strain, double *out, void *stream);
+
 /* Geometry stage only, for bit-exactness tests against the oracle:
  * frame[E][9] (e1,e2,e3), xl[E][8], detJ[E][4], acoef[E][5] (a_A..a_E). */
 int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
