@@ -24,6 +24,7 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp]),
     "fs_solid_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _i64, _u32, _u32, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp]),
+    "fs_solid2_table": (ctypes.c_int, [_i32, _vp, _vp, _vp, ctypes.POINTER(_i32)]),
     "fs_shell_kg_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _u32, _vp, _vp]),
     "fs_centrifugal_prestress": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, ctypes.c_double, _vp, _vp,
                                                 _i64, _vp, _vp]),

@@ -218,7 +218,7 @@ class MeshAssembler:
             self._prop_id = np.zeros(E, dtype=np.int32)
             self._prop_objects = [self.model["material"]]
             self._props_d = batch.to_device_solid_props(self._prop_table)
-            allowed = (4, 5, 6, 8)
+            allowed = (4, 5, 6, 8, 10, 15, 20)
         # symbolic phase on the device (fs_csr_symbolic_*); a precomputed host BlockPlan is accepted too
         # (uniform quad meshes: element matrices in the tiled layout the stiffness kernel writes fastest)
         self._plan = self._given_plan or DeviceBlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node, dev,

@@ -287,4 +287,135 @@ inline void make_solid_rule(int nn, int reduced, SolidRule &rule) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Quadratic solids TETRA10 / WEDGE15 / HEXA20 (SOLID.py:832-1059, 1600-1708, 1821-1946).  Their shape
+// data at the integration points do not depend on the element, so they are tabulated once on the HOST
+// with the reference's own operation order (this header is compiled with contraction off; `x**2` of a
+// NumPy float64 scalar is libm pow(x, 2.0)) and handed to the kernels as a device table.  This matters
+// for HEXA20, whose derivatives are FORWARD DIFFERENCES with h = 1e-8 (:1934-1946): the difference of
+// two rounded N values divided by h carries ~1e-8 of rounding noise, which only a bit-identical N
+// reproduces (tests/golden/solid2_tables.npz pins the tables bit for bit against the reference).
+// ------------------------------------------------------------------------------------------
+constexpr int FS_SOLID2_MAX_NG = 27, FS_SOLID2_MAX_NN = 20;
+struct SolidTable {
+    int nn, ng;
+    double pt[FS_SOLID2_MAX_NG][3], w[FS_SOLID2_MAX_NG];
+    double v[FS_SOLID2_MAX_NG][FS_SOLID2_MAX_NN][4];   // N, dN/dxi, dN/deta, dN/dzeta
+};
+
+inline void hexa20_N(double xi, double eta, double zeta, double *N) {   // SOLID.py:1879-1932
+    static const double c[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+    for (int i = 0; i < 8; i++) {
+        const double a = xi * c[i][0], b = eta * c[i][1], d = zeta * c[i][2];
+        N[i] = (((0.125 * (1 + a)) * (1 + b)) * (1 + d)) * (((a + b) + d) - 2);
+    }
+    const double x2 = 1 - pow(xi, 2.0), e2 = 1 - pow(eta, 2.0), z2 = 1 - pow(zeta, 2.0);
+    N[8] = ((0.25 * x2) * (1 - eta)) * (1 - zeta);
+    N[9] = ((0.25 * (1 - xi)) * e2) * (1 - zeta);
+    N[10] = ((0.25 * (1 - xi)) * (1 - eta)) * z2;
+    N[11] = ((0.25 * (1 + xi)) * e2) * (1 - zeta);
+    N[12] = ((0.25 * (1 + xi)) * (1 - eta)) * z2;
+    N[13] = ((0.25 * x2) * (1 + eta)) * (1 - zeta);
+    N[14] = ((0.25 * (1 + xi)) * (1 + eta)) * z2;
+    N[15] = ((0.25 * (1 - xi)) * (1 + eta)) * z2;
+    N[16] = ((0.25 * x2) * (1 - eta)) * (1 + zeta);
+    N[17] = ((0.25 * (1 - xi)) * e2) * (1 + zeta);
+    N[18] = ((0.25 * (1 + xi)) * e2) * (1 + zeta);
+    N[19] = ((0.25 * x2) * (1 + eta)) * (1 + zeta);
+}
+
+inline int make_solid_table(int nn, SolidTable &t) {
+    memset(&t, 0, sizeof t);
+    t.nn = nn;
+    if (nn == 20) {          // 3x3x3 Gauss, order k-j-i, weights wi*wj*wk (SOLID.py:1862-1877)
+        const double s35 = sqrt(3.0 / 5.0), p1[3] = {-s35, 0.0, s35}, w1[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
+        t.ng = 27;
+        int n = 0;
+        for (int k = 0; k < 3; k++)
+            for (int j = 0; j < 3; j++)
+                for (int i = 0; i < 3; i++) {
+                    t.pt[n][0] = p1[i]; t.pt[n][1] = p1[j]; t.pt[n][2] = p1[k];
+                    t.w[n++] = (w1[i] * w1[j]) * w1[k];
+                }
+        const double h = 1e-8;
+        for (int q = 0; q < 27; q++) {
+            double N0[20], Na[20], Nb[20], Nc[20];
+            const double xi = t.pt[q][0], eta = t.pt[q][1], zeta = t.pt[q][2];
+            hexa20_N(xi, eta, zeta, N0);
+            hexa20_N(xi + h, eta, zeta, Na);
+            hexa20_N(xi, eta + h, zeta, Nb);
+            hexa20_N(xi, eta, zeta + h, Nc);
+            for (int i = 0; i < 20; i++) {
+                t.v[q][i][0] = N0[i]; t.v[q][i][1] = (Na[i] - N0[i]) / h;
+                t.v[q][i][2] = (Nb[i] - N0[i]) / h; t.v[q][i][3] = (Nc[i] - N0[i]) / h;
+            }
+        }
+        return 0;
+    }
+    if (nn == 10) {          // SOLID.py:1642-1708
+        const double a = (5 - sqrt(5.0)) / 20, b = (5 + 3 * sqrt(5.0)) / 20;
+        const double P[4][3] = {{a, a, a}, {b, a, a}, {a, b, a}, {a, a, b}};
+        t.ng = 4;
+        for (int q = 0; q < 4; q++) {
+            for (int k = 0; k < 3; k++) t.pt[q][k] = P[q][k];
+            t.w[q] = 1.0 / 24;
+            const double xi = P[q][0], eta = P[q][1], zeta = P[q][2];
+            const double L[4] = {((1 - xi) - eta) - zeta, xi, eta, zeta};
+            const double dL[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+            double (*v)[4] = t.v[q];
+            for (int i = 0; i < 4; i++) {
+                v[i][0] = L[i] * (2 * L[i] - 1);
+                for (int k = 0; k < 3; k++) v[i][1 + k] = (4 * L[i] - 1) * dL[i][k];
+            }
+            // edges (Gmsh): 4: 0-1, 5: 1-2, 6: 0-2, 7: 0-3, 8: 2-3, 9: 1-3; N = 4 La Lb as written in the
+            // reference, dN = 4 (Lp dLq + Lq dLp) with its operand order
+            const int na[6] = {0, 1, 2, 0, 2, 1}, nb[6] = {1, 2, 0, 3, 3, 3};       // N = 4 * L[na] * L[nb]
+            const int da[6] = {1, 2, 0, 3, 3, 3}, db[6] = {0, 1, 2, 0, 2, 1};       // dN = 4 (L[da] dL[db] + L[db] dL[da])
+            for (int m = 0; m < 6; m++) {
+                v[4 + m][0] = (4 * L[na[m]]) * L[nb[m]];
+                for (int k = 0; k < 3; k++) v[4 + m][1 + k] = 4 * (L[da[m]] * dL[db[m]][k] + L[db[m]] * dL[da[m]][k]);
+            }
+        }
+        return 0;
+    }
+    if (nn == 15) {          // SOLID.py:880-1059: 7-point triangle x 3-point Gauss, weight tri_w lin_w 2
+        const double tp[7][2] = {{1.0 / 3, 1.0 / 3}, {0.797426985353087, 0.101286507323456}, {0.101286507323456, 0.797426985353087},
+                                 {0.101286507323456, 0.101286507323456}, {0.470142064105115, 0.059715871789770},
+                                 {0.470142064105115, 0.470142064105115}, {0.059715871789770, 0.470142064105115}};
+        const double tw[7] = {0.225, 0.125939180544827, 0.125939180544827, 0.125939180544827, 0.132394152788506,
+                              0.132394152788506, 0.132394152788506};
+        const double s35 = sqrt(3.0 / 5.0), lp[3] = {-s35, 0.0, s35}, lw[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
+        t.ng = 21;
+        int n = 0;
+        for (int i = 0; i < 7; i++)
+            for (int j = 0; j < 3; j++) {
+                const double xi = tp[i][0], eta = tp[i][1], zeta = lp[j];
+                t.pt[n][0] = xi; t.pt[n][1] = eta; t.pt[n][2] = zeta;
+                t.w[n] = ((tw[i] * 0.5) * lw[j]) * 2;
+                const double L1 = (1 - xi) - eta, L2 = xi, L3 = eta;
+                const double Lm = (0.5 * zeta) * (zeta - 1), L0 = 1 - pow(zeta, 2.0), Lp = (0.5 * zeta) * (zeta + 1);
+                const double dLm = zeta - 0.5, dL0 = -2 * zeta, dLp = zeta + 0.5;
+                double (*v)[4] = t.v[n];
+                const double Lz[2] = {Lm, Lp}, dLz[2] = {dLm, dLp};
+                for (int c = 0; c < 2; c++) {       // bottom (c = 0) / top (c = 1) triangles
+                    const int o = 3 * c;
+                    v[o + 0][0] = (L1 * (2 * L1 - 1)) * Lz[c]; v[o + 1][0] = (L2 * (2 * L2 - 1)) * Lz[c]; v[o + 2][0] = (L3 * (2 * L3 - 1)) * Lz[c];
+                    v[o + 0][1] = ((4 * L1 - 1) * -1) * Lz[c]; v[o + 0][2] = ((4 * L1 - 1) * -1) * Lz[c]; v[o + 0][3] = (L1 * (2 * L1 - 1)) * dLz[c];
+                    v[o + 1][1] = (4 * L2 - 1) * Lz[c]; v[o + 1][2] = 0; v[o + 1][3] = (L2 * (2 * L2 - 1)) * dLz[c];
+                    v[o + 2][1] = 0; v[o + 2][2] = (4 * L3 - 1) * Lz[c]; v[o + 2][3] = (L3 * (2 * L3 - 1)) * dLz[c];
+                    const int e01 = c ? 12 : 6, e02 = c ? 13 : 7, e12 = c ? 14 : 9;
+                    v[e01][0] = ((4 * L1) * L2) * Lz[c]; v[e01][1] = (4 * (L1 - L2)) * Lz[c]; v[e01][2] = (-4 * L2) * Lz[c]; v[e01][3] = ((4 * L1) * L2) * dLz[c];
+                    v[e02][0] = ((4 * L1) * L3) * Lz[c]; v[e02][1] = (-4 * L3) * Lz[c]; v[e02][2] = (4 * (L1 - L3)) * Lz[c]; v[e02][3] = ((4 * L1) * L3) * dLz[c];
+                    v[e12][0] = ((4 * L2) * L3) * Lz[c]; v[e12][1] = (4 * L3) * Lz[c]; v[e12][2] = (4 * L2) * Lz[c]; v[e12][3] = ((4 * L2) * L3) * dLz[c];
+                }
+                v[8][0] = L1 * L0; v[8][1] = -L0; v[8][2] = -L0; v[8][3] = L1 * dL0;
+                v[10][0] = L2 * L0; v[10][1] = L0; v[10][2] = 0; v[10][3] = L2 * dL0;
+                v[11][0] = L3 * L0; v[11][1] = 0; v[11][2] = L0; v[11][3] = L3 * dL0;
+                n++;
+            }
+        return 0;
+    }
+    return -1;
+}
+
 }  // namespace

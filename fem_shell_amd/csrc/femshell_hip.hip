@@ -23,6 +23,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "femshell_hip.h"
 #include "femshell_internal.h"
 #include "femshell_geom.h"
@@ -1460,11 +1463,12 @@ __global__ __launch_bounds__(256) void centrifugal_solid_kernel(const double *__
 // i<=j) -> 3x3 block of K (B_i^T C B_j), M, K_G; threads p < NN also the body-load vector.
 // Output FS_LAYOUT_SYMBLK with d = 3: [E][NN(NN+1)/2][9].
 // ------------------------------------------------------------------------------------------
-template <int NN>
+template <int NN, int NG, bool TAB>
 __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ xyz,
                                                     const int32_t *__restrict__ prop_id,
                                                     const double *__restrict__ props, int64_t E,
-                                                    SolidRule rule, double bx, double by, double bz,
+                                                    SolidRule rule, const double *__restrict__ tab, int ng_tab,
+                                                    double bx, double by, double bz,
                                                     const double *__restrict__ sigma,
                                                     double *__restrict__ Ke, double *__restrict__ Me,
                                                     double *__restrict__ fe, double *__restrict__ KGe,
@@ -1472,19 +1476,28 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
     constexpr int NPAIR = NN * (NN + 1) / 2;
     constexpr int EPB = 256 / NPAIR;
     constexpr int GS = NN * 3;                     // doubles of one gradient set
-    __shared__ double s_g[EPB * 8 * GS];           // dN/dx      (SOLID.py:245-248)
-    __shared__ double s_gt[EPB * 8 * GS];          // inv_J.T form used by K_G (SOLID.py:352-354)
-    __shared__ double s_wd[EPB * 8];               // w * detJ
+    __shared__ double s_g[EPB * NG * GS];          // dN/dx      (SOLID.py:245-248)
+    __shared__ double s_gt[EPB * NG * GS];         // inv_J.T form used by K_G (SOLID.py:352-354)
+    __shared__ double s_wd[EPB * NG];              // w * detJ
+    __shared__ double s_N[EPB * NG * NN];          // shape values (mass, body load)
     const int tid = threadIdx.x;
     const int64_t e0 = (int64_t)blockIdx.x * EPB;
-    const int ng = rule.ng;
+    const int ng = TAB ? ng_tab : rule.ng;
     {
 #pragma clang fp contract(fast)
         const int el = tid / ng, q = tid - el * ng;
         const int64_t e = e0 + el;
         if (el < EPB && e < E) {
-            double N[NN], dxi[NN], deta[NN], dzeta[NN];
-            solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, dxi, deta, dzeta);
+            double N[NN], dxi[NN], deta[NN], dzeta[NN], wq;
+            if constexpr (TAB) {   // quadratic solids: host-tabulated shape data (femshell_geom.h)
+                const double *tq = tab + (int64_t)q * NN * 4;
+#pragma unroll
+                for (int i = 0; i < NN; i++) { N[i] = tq[4 * i]; dxi[i] = tq[4 * i + 1]; deta[i] = tq[4 * i + 2]; dzeta[i] = tq[4 * i + 3]; }
+                wq = tab[(int64_t)ng * NN * 4 + q];
+            } else {
+                solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, dxi, deta, dzeta);
+                wq = rule.w[q];
+            }
             double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             const double *x = xyz + e * GS;
 #pragma unroll
@@ -1504,15 +1517,17 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
             inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det; inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
             inv[2][0] = c02 / det; inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
             inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
-            double *g = s_g + (el * 8 + q) * GS, *gt = s_gt + (el * 8 + q) * GS;
+            double *g = s_g + (el * NG + q) * GS, *gt = s_gt + (el * NG + q) * GS;
 #pragma unroll
-            for (int i = 0; i < NN; i++)
+            for (int i = 0; i < NN; i++) {
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
                     g[3 * i + a] = inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i];
                     gt[3 * i + a] = inv[0][a] * dxi[i] + inv[1][a] * deta[i] + inv[2][a] * dzeta[i];
                 }
-            s_wd[el * 8 + q] = det * rule.w[q];
+                s_N[(el * NG + q) * NN + i] = N[i];
+            }
+            s_wd[el * NG + q] = det * wq;
         }
     }
     __syncthreads();
@@ -1534,9 +1549,9 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
                 for (int b = 0; b < 6; b++) C[a][b] = 0.5 * (pr[a * 6 + b] + pr[b * 6 + a]);   // 0.5 (K + K^T) of SOLID.py:565
             double K[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             for (int q = 0; q < ng; q++) {
-                const double *gi = s_g + (el * 8 + q) * GS + 3 * ti, *gj = s_g + (el * 8 + q) * GS + 3 * tj;
+                const double *gi = s_g + (el * NG + q) * GS + 3 * ti, *gj = s_g + (el * NG + q) * GS + 3 * tj;
                 const double ax = gi[0], ay = gi[1], az = gi[2], bx_ = gj[0], by_ = gj[1], bz_ = gj[2];
-                const double wd = s_wd[el * 8 + q];
+                const double wd = s_wd[el * NG + q];
                 // columns of C B_j: u -> (xx: bx, xy: by, zx: bz), v -> (yy: by, xy: bx, yz: bz), w -> (zz: bz, yz: by, zx: bx)
                 double cb[6][3];
 #pragma unroll
@@ -1565,17 +1580,10 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
             const double rho = pr[36];
             double m = 0.0, f0 = 0.0;
             for (int q = 0; q < ng; q++) {
-                double N[NN], d0[NN], d1[NN], d2[NN];
-                solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, d0, d1, d2);
-                double Ni = 0.0, Nj = 0.0;
-#pragma unroll
-                for (int i = 0; i < NN; i++) { Ni = (i == ti) ? N[i] : Ni; Nj = (i == tj) ? N[i] : Nj; }
-                const double wd = s_wd[el * 8 + q];
-                m += rho * (Ni * Nj) * wd;
-                double Np = 0.0;
-#pragma unroll
-                for (int i = 0; i < NN; i++) Np = (i == p) ? N[i] : Np;
-                f0 += Np * wd;
+                const double *N = s_N + (el * NG + q) * NN;
+                const double wd = s_wd[el * NG + q];
+                m += rho * (N[ti] * N[tj]) * wd;
+                f0 += N[p < NN ? p : 0] * wd;
             }
             if (Me) {
 #pragma unroll
@@ -1590,11 +1598,11 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
             const double S[3][3] = {{sg[0], sg[3], sg[5]}, {sg[3], sg[1], sg[4]}, {sg[5], sg[4], sg[2]}};
             double gsum = 0.0;
             for (int q = 0; q < ng; q++) {
-                const double *gi = s_gt + (el * 8 + q) * GS + 3 * ti, *gj = s_gt + (el * 8 + q) * GS + 3 * tj;
+                const double *gi = s_gt + (el * NG + q) * GS + 3 * ti, *gj = s_gt + (el * NG + q) * GS + 3 * tj;
                 double v = 0.0;
 #pragma unroll
                 for (int a = 0; a < 3; a++) v += (gi[0] * S[0][a] + gi[1] * S[1][a] + gi[2] * S[2][a]) * gj[a];
-                gsum += v * s_wd[el * 8 + q];
+                gsum += v * s_wd[el * NG + q];
             }
 #pragma unroll
             for (int c = 0; c < 9; c++) KGe[ob + c] = (c == 0 || c == 4 || c == 8) ? gsum : 0.0;
@@ -2061,17 +2069,53 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
 }  // extern "C" (reopened below)
 
 namespace {
-template <int NN>
+template <int NN, int NG, bool TAB>
 int launch_solid(const double *xyz, const int32_t *prop_id, const double *props, int64_t E, const SolidRule &rule,
-                 const double *b, const double *sigma, double *Ke, double *Me, double *fe, double *KGe,
-                 int32_t *status, hipStream_t s) {
+                 const double *tab, int ng_tab, const double *b, const double *sigma, double *Ke, double *Me,
+                 double *fe, double *KGe, int32_t *status, hipStream_t s) {
     constexpr int EPB = 256 / (NN * (NN + 1) / 2);
-    static_assert(EPB * 8 <= 256, "phase 1 needs one thread per (element, Gauss point)");
-    hipLaunchKernelGGL(solid_kernel<NN>, dim3(grid_for((E + EPB - 1) / EPB, 1, INT32_MAX)), dim3(256), 0, s, xyz,
-                       prop_id, props, E, rule, b[0], b[1], b[2], sigma, Ke, Me, fe, KGe, status);
+    static_assert(EPB >= 1 && EPB * NG <= 256, "phase 1 needs one thread per (element, Gauss point)");
+    hipLaunchKernelGGL((solid_kernel<NN, NG, TAB>), dim3(grid_for((E + EPB - 1) / EPB, 1, INT32_MAX)), dim3(256), 0, s,
+                       xyz, prop_id, props, E, rule, tab, ng_tab, b[0], b[1], b[2], sigma, Ke, Me, fe, KGe, status);
     return 0;
 }
+
+// device copies of the quadratic-solid shape tables: built once per (device, element type), kept for the
+// life of the process (17 KB at most each)
+std::mutex g_tab_mutex;
+double *g_tab_dev[16][3] = {};
+int g_tab_ng[3] = {};
+int solid_table_device(int nn, const double **tab, int *ng) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(FS_EHIP, "hipGetDevice", e);
+    if (dev < 0 || dev >= 16) return fail(FS_EINVAL, "fs_solid_batch: device ordinal above 15");
+    const int slot = nn == 10 ? 0 : (nn == 15 ? 1 : 2);
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    if (!g_tab_dev[dev][slot]) {
+        static SolidTable t;   // 18 KB: not on the stack
+        if (make_solid_table(nn, t) != 0) return fail(FS_EINVAL, "fs_solid_batch: no table for this element");
+        std::vector<double> h((size_t)t.ng * nn * 4 + t.ng);
+        for (int q = 0; q < t.ng; q++) {
+            for (int i = 0; i < nn; i++)
+                for (int c = 0; c < 4; c++) h[((size_t)q * nn + i) * 4 + c] = t.v[q][i][c];
+            h[(size_t)t.ng * nn * 4 + q] = t.w[q];
+        }
+        double *d = nullptr;
+        e = hipMalloc(&d, h.size() * sizeof(double));
+        if (e != hipSuccess) return fail(FS_EHIP, "hipMalloc(solid table)", e);
+        e = hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(FS_EHIP, "hipMemcpy(solid table)", e); }
+        g_tab_dev[dev][slot] = d;
+        g_tab_ng[slot] = t.ng;
+    }
+    *ng = g_tab_ng[slot];
+    *tab = g_tab_dev[dev][slot];
+    return FS_OK;
+}
 }  // namespace
+
+int fs_solid_table_device_(int nn, const double **tab, int *ng) { return solid_table_device(nn, tab, ng); }
 
 extern "C" {
 
@@ -2080,8 +2124,8 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
                    const double *sigma, double *Ke, double *Me, double *fe, double *KGe, int32_t *status,
                    void *stream) {
     if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_solid_batch: bad sizes");
-    if (nn != 4 && nn != 5 && nn != 6 && nn != 8)
-        return fail(FS_ENOSYS, "fs_solid_batch: only TETRA4 / PYRAMID5 / WEDGE6 / HEXA8 (nn = 4, 5, 6, 8)");
+    if (nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 15 && nn != 20)
+        return fail(FS_ENOSYS, "fs_solid_batch: TETRA4 / PYRAMID5 / WEDGE6 / HEXA8 / TETRA10 / WEDGE15 / HEXA20 (nn = 4, 5, 6, 8, 10, 15, 20)");
     if (E == 0) return FS_OK;
     if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_solid_batch: null input");
     if (layout != FS_LAYOUT_SYMBLK)
@@ -2091,19 +2135,44 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
     if ((want & FS_WANT_FBODY) && (!fe || !body_host)) return fail(FS_EINVAL, "fs_solid_batch: fe / body is null");
     if ((want & FS_WANT_KG) && (!KGe || !sigma)) return fail(FS_EINVAL, "fs_solid_batch: KGe / sigma is null");
     SolidRule rule;
-    make_solid_rule(nn, reduced, rule);
+    make_solid_rule(nn <= 8 ? nn : 8, reduced, rule);   // unused by the table-driven quadratic kernels
     const double zero3[3] = {0, 0, 0};
     const double *b3 = (want & FS_WANT_FBODY) ? body_host : zero3;
     double *k = (want & FS_WANT_K) ? Ke : nullptr, *m = (want & FS_WANT_M) ? Me : nullptr;
     double *f = (want & FS_WANT_FBODY) ? fe : nullptr, *kg = (want & FS_WANT_KG) ? KGe : nullptr;
     hipStream_t s = (hipStream_t)stream;
+    const double *tab = nullptr;
+    int ng_tab = 0;
+    if (nn > 8) {
+        const int rc = solid_table_device(nn, &tab, &ng_tab);
+        if (rc != FS_OK) return rc;
+    }
     switch (nn) {
-        case 8: launch_solid<8>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
-        case 6: launch_solid<6>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
-        case 5: launch_solid<5>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
-        default: launch_solid<4>(xyz, prop_id, props, E, rule, b3, sigma, k, m, f, kg, status, s); break;
+        case 20: launch_solid<20, 27, true>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 15: launch_solid<15, 21, true>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 10: launch_solid<10, 4, true>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 8: launch_solid<8, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 6: launch_solid<6, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 5: launch_solid<5, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        default: launch_solid<4, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
     }
     FS_LAUNCH_CHECK("solid_kernel");
+    return FS_OK;
+}
+
+int fs_solid2_table(int32_t nn, double *pts, double *w, double *vals, int32_t *ng) {
+    static SolidTable t;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (make_solid_table(nn, t) != 0) return fail(FS_EINVAL, "fs_solid2_table: nn must be 10, 15 or 20");
+    if (ng) *ng = t.ng;
+    for (int q = 0; q < t.ng; q++) {
+        if (pts) for (int k = 0; k < 3; k++) pts[3 * q + k] = t.pt[q][k];
+        if (w) w[q] = t.w[q];
+        if (vals)
+            for (int i = 0; i < nn; i++)
+                for (int c = 0; c < 4; c++) vals[((size_t)q * nn + i) * 4 + c] = t.v[q][i][c];
+    }
     return FS_OK;
 }
 
@@ -2134,7 +2203,7 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
     if (!axis_host || !center_host) return fail(FS_EINVAL, "fs_centrifugal_prestress: axis / center is null");
     if (!solid && nn == 4)   // 'MITC4' object has no attribute 'compute_centrifugal_prestress'
         return fail(FS_ENOSYS, "fs_centrifugal_prestress: the reference MITC4 has no compute_centrifugal_prestress");
-    if ((!solid && nn != 3) || (solid && nn != 4 && nn != 5 && nn != 6 && nn != 8))
+    if ((!solid && nn != 3) || (solid && nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 15 && nn != 20))
         return fail(FS_EINVAL, "fs_centrifugal_prestress: unsupported element");
     const double la = sqrt(axis_host[0] * axis_host[0] + axis_host[1] * axis_host[1] + axis_host[2] * axis_host[2]);
     if (!(la > 0.0)) return fail(FS_EINVAL, "fs_centrifugal_prestress: zero rotation axis");
@@ -2150,6 +2219,9 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
     } else {
         const double *pp = (const double *)props;
         switch (nn) {
+            case 20: hipLaunchKernelGGL(centrifugal_solid_kernel<20>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+            case 15: hipLaunchKernelGGL(centrifugal_solid_kernel<15>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+            case 10: hipLaunchKernelGGL(centrifugal_solid_kernel<10>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
             case 8: hipLaunchKernelGGL(centrifugal_solid_kernel<8>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
             case 6: hipLaunchKernelGGL(centrifugal_solid_kernel<6>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
             case 5: hipLaunchKernelGGL(centrifugal_solid_kernel<5>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;

@@ -125,24 +125,34 @@ __global__ __launch_bounds__(256) void shell_stress_kernel(const double *__restr
 // (SOLID.py:218-266 B, element.C as stored -- not symmetrised here) into LDS; phase 2: thread
 // (element, output row) -> Gauss values / their mean / E @ values.
 // ------------------------------------------------------------------------------------------
-constexpr int S_EPB = 32;
-
-template <int NN>
+template <int NN, int NG, bool TAB>
 __global__ __launch_bounds__(256) void solid_stress_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
                                                            const double *__restrict__ props,
                                                            const double *__restrict__ u_e, int64_t E,
-                                                           SolidRule rule, const double *__restrict__ extrap,
+                                                           SolidRule rule, const double *__restrict__ tab, int ng_tab,
+                                                           const double *__restrict__ extrap,
                                                            int mode, double *__restrict__ sig_out,
                                                            double *__restrict__ eps_out,
                                                            double *__restrict__ weight) {
-    __shared__ double s_sig[S_EPB * 8 * 6], s_eps[S_EPB * 8 * 6], s_vol[S_EPB * 8];
-    const int tid = threadIdx.x, el = tid >> 3, q = tid & 7;
-    const int64_t e = (int64_t)blockIdx.x * S_EPB + el;
-    const int ng = rule.ng;
-    if (e < E && q < ng) {
-        double N[NN], dxi[NN], deta[NN], dzeta[NN];
-        solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, dxi, deta, dzeta);
+    constexpr int SLOTS = (NG > NN) ? NG : NN;     // threads per element: Gauss points, then output rows
+    constexpr int EPB = 256 / SLOTS;
+    __shared__ double s_sig[EPB * NG * 6], s_eps[EPB * NG * 6], s_vol[EPB * NG];
+    const int tid = threadIdx.x, el = tid / SLOTS, q = tid - el * SLOTS;
+    const int64_t e = (int64_t)blockIdx.x * EPB + el;
+    const int ng = TAB ? ng_tab : rule.ng;
+    const bool live = el < EPB && e < E;
+    if (live && q < ng) {
+        double N[NN], dxi[NN], deta[NN], dzeta[NN], wq;
+        if constexpr (TAB) {
+            const double *tq = tab + (int64_t)q * NN * 4;
+#pragma unroll
+            for (int i = 0; i < NN; i++) { N[i] = tq[4 * i]; dxi[i] = tq[4 * i + 1]; deta[i] = tq[4 * i + 2]; dzeta[i] = tq[4 * i + 3]; }
+            wq = tab[(int64_t)ng * NN * 4 + q];
+        } else {
+            solid_shape<NN>(rule.pt[q][0], rule.pt[q][1], rule.pt[q][2], N, dxi, deta, dzeta);
+            wq = rule.w[q];
+        }
         const double *x = xyz + e * (3 * NN);
         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
@@ -178,17 +188,17 @@ __global__ __launch_bounds__(256) void solid_stress_kernel(const double *__restr
             double v = 0.0;
 #pragma unroll
             for (int b = 0; b < 6; b++) v += C[a * 6 + b] * ep[b];
-            s_sig[(el * 8 + q) * 6 + a] = v;
-            s_eps[(el * 8 + q) * 6 + a] = ep[a];
+            s_sig[(el * NG + q) * 6 + a] = v;
+            s_eps[(el * NG + q) * 6 + a] = ep[a];
         }
-        s_vol[el * 8 + q] = __builtin_fabs(det) * rule.w[q];
+        s_vol[el * NG + q] = __builtin_fabs(det) * wq;
     }
     __syncthreads();
-    if (e >= E) return;
-    const double *sg = s_sig + el * 48, *sp = s_eps + el * 48;
+    if (!live) return;
+    const double *sg = s_sig + el * NG * 6, *sp = s_eps + el * NG * 6;
     if (weight && q == 0) {                 // stress_recovery.py:1397-1402
         double v = 0.0;
-        for (int g = 0; g < ng; g++) v += s_vol[el * 8 + g];
+        for (int g = 0; g < ng; g++) v += s_vol[el * NG + g];
         weight[e] = v;
     }
     if (mode == FS_SOLID_STRESS_GP) {
@@ -290,12 +300,13 @@ __global__ __launch_bounds__(256) void strain_invariants_kernel(const double *__
     out[t] = avg + R; out[N + t] = avg - R; out[2 * N + t] = 2 * R;
 }
 
-template <int NN>
+template <int NN, int NG, bool TAB>
 void launch_solid_stress(const double *xyz, const int32_t *prop_id, const double *props, const double *u_e, int64_t E,
-                         const SolidRule &rule, const double *extrap, int mode, double *sig, double *eps, double *w,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(solid_stress_kernel<NN>, dim3(grid_of(E, S_EPB)), dim3(256), 0, s, xyz, prop_id, props, u_e, E,
-                       rule, extrap, mode, sig, eps, w);
+                         const SolidRule &rule, const double *tab, int ng_tab, const double *extrap, int mode,
+                         double *sig, double *eps, double *w, hipStream_t s) {
+    constexpr int EPB = 256 / ((NG > NN) ? NG : NN);
+    hipLaunchKernelGGL((solid_stress_kernel<NN, NG, TAB>), dim3(grid_of(E, EPB)), dim3(256), 0, s, xyz, prop_id, props,
+                       u_e, E, rule, tab, ng_tab, extrap, mode, sig, eps, w);
 }
 
 }  // namespace
@@ -333,8 +344,8 @@ int fs_solid_stress_batch(int32_t nn, int32_t reduced, const double *xyz, const 
                           const double *extrap, int32_t mode, double *sigma, double *eps, double *weight,
                           void *stream) {
     if (E < 0 || n_props <= 0) return fs_fail_(FS_EINVAL, "fs_solid_stress_batch: bad sizes", 0);
-    if (nn != 4 && nn != 5 && nn != 6 && nn != 8)
-        return fs_fail_(FS_ENOSYS, "fs_solid_stress_batch: only TETRA4 / PYRAMID5 / WEDGE6 / HEXA8 (nn = 4, 5, 6, 8)", 0);
+    if (nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 15 && nn != 20)
+        return fs_fail_(FS_ENOSYS, "fs_solid_stress_batch: nn must be 4, 5, 6, 8, 10, 15 or 20", 0);
     if (mode != FS_SOLID_STRESS_GP && mode != FS_SOLID_STRESS_MEAN && mode != FS_SOLID_STRESS_NODES)
         return fs_fail_(FS_EINVAL, "fs_solid_stress_batch: bad mode", 0);
     if (mode == FS_SOLID_STRESS_NODES && !extrap)
@@ -343,13 +354,22 @@ int fs_solid_stress_batch(int32_t nn, int32_t reduced, const double *xyz, const 
     if (!xyz || !prop_id || !props || !u_e || (!sigma && !eps))
         return fs_fail_(FS_EINVAL, "fs_solid_stress_batch: null argument", 0);
     SolidRule rule;
-    make_solid_rule(nn, reduced, rule);
+    make_solid_rule(nn <= 8 ? nn : 8, reduced, rule);
+    const double *tab = nullptr;
+    int ng_tab = 0;
+    if (nn > 8) {
+        const int rc = fs_solid_table_device_(nn, &tab, &ng_tab);
+        if (rc != FS_OK) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (nn) {
-        case 8: launch_solid_stress<8>(xyz, prop_id, props, u_e, E, rule, extrap, mode, sigma, eps, weight, s); break;
-        case 6: launch_solid_stress<6>(xyz, prop_id, props, u_e, E, rule, extrap, mode, sigma, eps, weight, s); break;
-        case 5: launch_solid_stress<5>(xyz, prop_id, props, u_e, E, rule, extrap, mode, sigma, eps, weight, s); break;
-        default: launch_solid_stress<4>(xyz, prop_id, props, u_e, E, rule, extrap, mode, sigma, eps, weight, s); break;
+        case 20: launch_solid_stress<20, 27, true>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 15: launch_solid_stress<15, 21, true>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 10: launch_solid_stress<10, 4, true>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 8: launch_solid_stress<8, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 6: launch_solid_stress<6, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 5: launch_solid_stress<5, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        default: launch_solid_stress<4, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
     }
     ST_LAUNCH_CHECK("solid_stress_kernel");
     return FS_OK;

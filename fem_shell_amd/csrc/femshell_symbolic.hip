@@ -164,7 +164,7 @@ int fs_csr_symbolic_begin(const int64_t *conn, const int64_t *entry_ptr, const i
                           int64_t n_extra, fs_symbolic **handle, int64_t *nblk, int64_t *ncontrib, void *stream) {
     if (!handle || !nblk || !ncontrib) return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: null output", 0);
     *handle = nullptr; *nblk = 0; *ncontrib = 0;
-    if (E < 0 || nnmax <= 0 || nnmax > 8 || n_nodes <= 0 || n_extra < 0 || n_entries < 0)
+    if (E < 0 || nnmax <= 0 || nnmax > 32 || n_nodes <= 0 || n_extra < 0 || n_entries < 0)
         return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: bad sizes", 0);
     if (E > 0 && !conn) return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: conn is null", 0);
     if (n_extra > 0 && !extra_keys) return fs_fail_(FS_EINVAL, "fs_csr_symbolic_begin: extra_keys is null", 0);

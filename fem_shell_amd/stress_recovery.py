@@ -171,8 +171,15 @@ class StressRecovery:
     def _get_extrapolation_matrix(self, nn) -> np.ndarray:
         """E = inv(N_gp) (n_gp == n_nodes) or pinv(N_gp), [nn, n_gp] (stress_recovery.py:437-492)."""
         if nn not in self._extrap_cache:
-            pts = _solid_rule(nn, self.domain._reduced and nn == 8)
-            N_gp = np.array([_solid_N(nn, *p) for p in pts])
+            if nn > 8:      # quadratic solids: the library's host table (bit-identical to the reference's N)
+                import ctypes
+                ng = ctypes.c_int32(0)
+                v = np.zeros(27 * nn * 4)
+                _lib.check(_lib.load().fs_solid2_table(nn, None, None, v.ctypes.data, ctypes.byref(ng)), "fs_solid2_table")
+                N_gp = v[:ng.value * nn * 4].reshape(ng.value, nn, 4)[:, :, 0].copy()
+            else:
+                pts = _solid_rule(nn, self.domain._reduced and nn == 8)
+                N_gp = np.array([_solid_N(nn, *p) for p in pts])
             self._extrap_cache[nn] = np.linalg.inv(N_gp) if N_gp.shape[0] == nn else np.linalg.pinv(N_gp)
         return self._extrap_cache[nn]
 

@@ -123,6 +123,8 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
  * rules and shape functions of the concrete classes (:731-829, :1099-1218, :1575-1597, :1744-1818;
  * `reduced` != 0 selects HEXA8's 1-point rule).  Reference quirks kept: WEDGE6 weights sum to 2;
  * K_G uses inv_J.T where B uses inv_J.
+ * nn = 10 / 15 / 20 (TETRA10 / WEDGE15 / HEXA20, SOLID.py:832-1059, 1600-1708, 1821-1946) run the same kernel
+ * from a host-built shape table (fs_solid2_table); the first call per device uploads it (one hipMalloc).
  *   xyz     [E][nn][3]
  *   props   [n_props][37]  C (6x6, global axes, Voigt xx,yy,zz,xy,yz,zx; SOLID.py:377-541 evaluated
  *                          on the host by fem_shell_amd.properties.solid_row) followed by rho
@@ -135,6 +137,14 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
                    const double *props, int32_t n_props, int64_t E, uint32_t want, uint32_t layout,
                    const double *body_host, const double *sigma, double *Ke, double *Me, double *fe,
                    double *KGe, int32_t *status, void *stream);
+
+/*
+ * Shape data of the quadratic solids at their integration points as the reference evaluates them
+ * (SOLID.py:880-1059 WEDGE15, :1642-1708 TETRA10, :1862-1946 HEXA20 -- HEXA20 derivatives are the
+ * reference's forward differences, h = 1e-8).  Host arrays: pts [ng][3], w [ng], vals [ng][nn][4] =
+ * N, dN/dxi, dN/deta, dN/dzeta; any may be NULL.  ng <= 27.  The kernels of fs_solid_batch use the same table.
+ */
+int fs_solid2_table(int32_t nn, double *pts, double *w, double *vals, int32_t *ng);
 
 /*
  * Shell geometric stiffness from a given membrane stress: per element
@@ -155,7 +165,7 @@ int fs_shell_kg_batch(int32_t nn, const double *xyz, const int32_t *prop_id, con
  * sigma [E][3] local [sxx,syy,sxy]) or of the linear solids (SOLID.py:268-320 -> sigma [E][6]
  * global Voigt [xx,yy,zz,xy,yz,zx]).
  *   solid   0: shells (nn = 3; nn = 4 returns FS_ENOSYS -- the reference MITC4 has no such method),
- *           1: solids (nn = 4, 5, 6, 8)
+ *           1: solids (nn = 4, 5, 6, 8, 10, 15, 20)
  *   props   fs_shell_prop rows (rho field) for shells, [n_props][37] rows for solids (rho = column 36)
  *   axis_host, center_host   3 doubles each in HOST memory; the axis is normalised here
  */

@@ -1258,7 +1258,7 @@ int fso_mitc3_batch(const double *xyz, const int32_t *prop_id, const fso_shell_p
 }
 
 /* ====================================================================================
- * Linear solids (elements/SOLID.py): TETRA4, PYRAMID5, WEDGE6, HEXA8.  type == node count.
+ * Solids (elements/SOLID.py): TETRA4, PYRAMID5, WEDGE6, HEXA8, TETRA10, WEDGE15, HEXA20.  type == node count.
  * ==================================================================================== */
 static int solid_rule(int nn, int reduced, double pts[][3], double *w) {
     const double gp = 1.0 / sqrt(3.0);
@@ -1294,11 +1294,119 @@ static int solid_rule(int nn, int reduced, double pts[][3], double *w) {
         }
         return 8;
     }
+    if (nn == 10) { /* SOLID.py:1642-1655 */
+        const double a = (5 - sqrt(5.0)) / 20, b = (5 + 3 * sqrt(5.0)) / 20;
+        for (int q = 0; q < 4; q++) {
+            pts[q][0] = pts[q][1] = pts[q][2] = a;
+            if (q) pts[q][q - 1] = b;
+            w[q] = 1.0 / 24;
+        }
+        return 4;
+    }
+    if (nn == 15) { /* SOLID.py:880-919: 7-point triangle x 3-point Gauss, tri_w * lin_w * 2 */
+        const double tp[7][2] = {{1.0 / 3, 1.0 / 3}, {0.797426985353087, 0.101286507323456}, {0.101286507323456, 0.797426985353087},
+                                 {0.101286507323456, 0.101286507323456}, {0.470142064105115, 0.059715871789770},
+                                 {0.470142064105115, 0.470142064105115}, {0.059715871789770, 0.470142064105115}};
+        const double tw[7] = {0.225, 0.125939180544827, 0.125939180544827, 0.125939180544827, 0.132394152788506,
+                              0.132394152788506, 0.132394152788506};
+        const double s35 = sqrt(3.0 / 5.0), lp[3] = {-s35, 0, s35}, lw[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
+        int n = 0;
+        for (int i = 0; i < 7; i++)
+            for (int j = 0; j < 3; j++) {
+                pts[n][0] = tp[i][0]; pts[n][1] = tp[i][1]; pts[n][2] = lp[j];
+                w[n++] = tw[i] * 0.5 * lw[j] * 2;
+            }
+        return 21;
+    }
+    if (nn == 20) { /* SOLID.py:1862-1877: 3x3x3, order k-j-i */
+        const double s35 = sqrt(3.0 / 5.0), p1[3] = {-s35, 0, s35}, w1[3] = {5.0 / 9, 8.0 / 9, 5.0 / 9};
+        int n = 0;
+        for (int k = 0; k < 3; k++)
+            for (int j = 0; j < 3; j++)
+                for (int i = 0; i < 3; i++) {
+                    pts[n][0] = p1[i]; pts[n][1] = p1[j]; pts[n][2] = p1[k];
+                    w[n++] = w1[i] * w1[j] * w1[k];
+                }
+        return 27;
+    }
     return -1;
+}
+
+/* HEXA20 serendipity shape functions (SOLID.py:1879-1932); x**2 of a NumPy scalar is libm pow */
+static void hexa20_shape(double xi, double eta, double zeta, double *N) {
+    static const double c[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+    for (int i = 0; i < 8; i++)
+        N[i] = 0.125 * (1 + xi * c[i][0]) * (1 + eta * c[i][1]) * (1 + zeta * c[i][2]) *
+               (xi * c[i][0] + eta * c[i][1] + zeta * c[i][2] - 2);
+    N[8] = 0.25 * (1 - pow(xi, 2)) * (1 - eta) * (1 - zeta);
+    N[9] = 0.25 * (1 - xi) * (1 - pow(eta, 2)) * (1 - zeta);
+    N[10] = 0.25 * (1 - xi) * (1 - eta) * (1 - pow(zeta, 2));
+    N[11] = 0.25 * (1 + xi) * (1 - pow(eta, 2)) * (1 - zeta);
+    N[12] = 0.25 * (1 + xi) * (1 - eta) * (1 - pow(zeta, 2));
+    N[13] = 0.25 * (1 - pow(xi, 2)) * (1 + eta) * (1 - zeta);
+    N[14] = 0.25 * (1 + xi) * (1 + eta) * (1 - pow(zeta, 2));
+    N[15] = 0.25 * (1 - xi) * (1 + eta) * (1 - pow(zeta, 2));
+    N[16] = 0.25 * (1 - pow(xi, 2)) * (1 - eta) * (1 + zeta);
+    N[17] = 0.25 * (1 - xi) * (1 - pow(eta, 2)) * (1 + zeta);
+    N[18] = 0.25 * (1 + xi) * (1 - pow(eta, 2)) * (1 + zeta);
+    N[19] = 0.25 * (1 - pow(xi, 2)) * (1 + eta) * (1 + zeta);
 }
 
 static void solid_shape(int nn, double xi, double eta, double zeta, double *N, double *dxi, double *deta,
                         double *dzeta) {
+    if (nn == 20) { /* SOLID.py:1934-1946: FORWARD DIFFERENCES, h = 1e-8 (reference quirk, kept) */
+        const double h = 1e-8;
+        double Na[20], Nb[20], Nc[20];
+        hexa20_shape(xi, eta, zeta, N);
+        hexa20_shape(xi + h, eta, zeta, Na);
+        hexa20_shape(xi, eta + h, zeta, Nb);
+        hexa20_shape(xi, eta, zeta + h, Nc);
+        for (int i = 0; i < 20; i++) { dxi[i] = (Na[i] - N[i]) / h; deta[i] = (Nb[i] - N[i]) / h; dzeta[i] = (Nc[i] - N[i]) / h; }
+        return;
+    }
+    if (nn == 10) { /* SOLID.py:1657-1708 (Gmsh edge order 0-1, 1-2, 0-2, 0-3, 2-3, 1-3) */
+        const double L[4] = {1 - xi - eta - zeta, xi, eta, zeta};
+        const double dL[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        const int ea[6] = {0, 1, 2, 0, 2, 1}, eb[6] = {1, 2, 0, 3, 3, 3};
+        double *d[3] = {dxi, deta, dzeta};
+        for (int i = 0; i < 4; i++) {
+            N[i] = L[i] * (2 * L[i] - 1);
+            for (int k = 0; k < 3; k++) d[k][i] = (4 * L[i] - 1) * dL[i][k];
+        }
+        for (int m = 0; m < 6; m++) {
+            N[4 + m] = 4 * L[ea[m]] * L[eb[m]];
+            for (int k = 0; k < 3; k++) d[k][4 + m] = 4 * (L[eb[m]] * dL[ea[m]][k] + L[ea[m]] * dL[eb[m]][k]);
+        }
+        return;
+    }
+    if (nn == 15) { /* SOLID.py:921-1059 */
+        const double L[3] = {1 - xi - eta, xi, eta}, dLx[3] = {-1, 1, 0}, dLe[3] = {-1, 0, 1};
+        const double Lz[2] = {0.5 * zeta * (zeta - 1), 0.5 * zeta * (zeta + 1)}, L0 = 1 - zeta * zeta;
+        const double dLz[2] = {zeta - 0.5, zeta + 0.5}, dL0 = -2 * zeta;
+        const int vert[3] = {8, 10, 11};                         /* vertical mid-edges at corners 0, 1, 2 */
+        const int edge[2][3] = {{6, 7, 9}, {12, 13, 14}};        /* edges 0-1, 0-2, 1-2 of the bottom / top face */
+        const int ea[3] = {0, 0, 1}, eb[3] = {1, 2, 2};
+        for (int c = 0; c < 2; c++) {
+            for (int i = 0; i < 3; i++) {
+                const int n = 3 * c + i;
+                N[n] = L[i] * (2 * L[i] - 1) * Lz[c];
+                dxi[n] = (4 * L[i] - 1) * dLx[i] * Lz[c]; deta[n] = (4 * L[i] - 1) * dLe[i] * Lz[c];
+                dzeta[n] = L[i] * (2 * L[i] - 1) * dLz[c];
+            }
+            for (int m = 0; m < 3; m++) {
+                const int n = edge[c][m], a = ea[m], b = eb[m];
+                N[n] = 4 * L[a] * L[b] * Lz[c];
+                dxi[n] = 4 * (dLx[a] * L[b] + L[a] * dLx[b]) * Lz[c];
+                deta[n] = 4 * (dLe[a] * L[b] + L[a] * dLe[b]) * Lz[c];
+                dzeta[n] = 4 * L[a] * L[b] * dLz[c];
+            }
+        }
+        for (int i = 0; i < 3; i++) {
+            const int n = vert[i];
+            N[n] = L[i] * L0; dxi[n] = dLx[i] * L0; deta[n] = dLe[i] * L0; dzeta[n] = L[i] * dL0;
+        }
+        return;
+    }
     if (nn == 8) { /* SOLID.py:1768-1818 */
         const double sx[8] = {-1, 1, 1, -1, -1, 1, 1, -1}, sy[8] = {-1, -1, 1, 1, -1, -1, 1, 1},
                      sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
@@ -1365,7 +1473,7 @@ static int solid_grad(int nn, const double *xyz, const double *dxi, const double
  * SOLID.py:543-567 (K), :569-597 (M), :599-631 (body_load), :322-374 (K_G). */
 int fso_solid(int nn, int reduced, const double *xyz, const double *C, double rho, const double *b,
               const double *sigma, double *Ke, double *Me, double *fe, double *KGe) {
-    double pts[8][3], w[8];
+    double pts[27][3], w[27];
     int ng = solid_rule(nn, reduced, pts, w), nd = 3 * nn, status = 0;
     if (ng < 0) return -1;
     if (Ke) memset(Ke, 0, sizeof(double) * nd * nd);
@@ -1373,11 +1481,11 @@ int fso_solid(int nn, int reduced, const double *xyz, const double *C, double rh
     if (fe) memset(fe, 0, sizeof(double) * nd);
     if (KGe) memset(KGe, 0, sizeof(double) * nd * nd);
     for (int q = 0; q < ng; q++) {
-        double N[8], dxi[8], deta[8], dzeta[8], g[8][3], gT[8][3], det;
+        double N[20], dxi[20], deta[20], dzeta[20], g[20][3], gT[20][3], det;
         solid_shape(nn, pts[q][0], pts[q][1], pts[q][2], N, dxi, deta, dzeta);
         status |= solid_grad(nn, xyz, dxi, deta, dzeta, &det, g, gT);
         if (Ke) {
-            double B[6][24];
+            double B[6][60];
             memset(B, 0, sizeof B);
             for (int i = 0; i < nn; i++) {
                 B[0][3 * i] = g[i][0]; B[1][3 * i + 1] = g[i][1]; B[2][3 * i + 2] = g[i][2];

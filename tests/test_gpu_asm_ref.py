@@ -62,7 +62,7 @@ def _same_matrix(A, g, tag, n):
     return err
 
 
-@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex"])
+@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex", "q2"])
 def test_reference_assembler_golden(case):
     g = golden("asm_ref")
     mesh, asm = build(case, g)
@@ -97,7 +97,7 @@ def test_reference_assembler_golden(case):
         e = _same_matrix(KG, g, "tri_KG", n)
         print("  K_G(omega)", e)
         assert e < TOL
-    if case in ("somix", "hex"):
+    if case in ("somix", "hex", "q2"):
         body = g["somix_body"]
         F = asm.assemble_load_vector(SimpleNamespace(value=body)).cpu().numpy()
         e = _rel(F, g[pre + "F"])

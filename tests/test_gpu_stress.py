@@ -44,12 +44,12 @@ def _cmp(res, ref, tag, solid, worst):
         assert err < tol, (tag, k, err)
 
 
-@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex"])
+@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex", "q2"])
 def test_stress_recovery_golden(case):
     g, ref = golden("asm_ref"), golden("stress_ref")
     mesh, asm = build(case, g)
     pre = case + "_"
-    solid = case in ("somix", "hex")
+    solid = case in ("somix", "hex", "q2")
     sr = StressRecovery(asm, ref[pre + "u"])
     assert sr.n_nodes == mesh.node_count and sr.n_elements == mesh.conn.shape[0]
     worst = {}

@@ -134,6 +134,39 @@ def test_solids_vs_reference(oracle, nn):
         assert abs(g["M6"][0][0::3, 0::3].sum() / (props[0, 36] * vol) - 2.0) < 1e-12
 
 
+@pytest.mark.parametrize("nn", [10, 15, 20])
+def test_quadratic_solids_vs_reference(oracle, nn):
+    """TETRA10 / WEDGE15 / HEXA20 K, M, body_load, K_G (elements/SOLID.py:832-1059, 1600-1708, 1821-1946).
+    HEXA20 uses the reference's forward-difference derivatives (h = 1e-8): parity needs bit-identical
+    shape values, which the restatement reproduces (same operation order, libm pow)."""
+    g = golden("elem_solid2")
+    xyz, props = g[f"xyz{nn}"], g[f"props{nn}"]
+    pid = np.arange(xyz.shape[0], dtype=np.int32)
+    o = oracle.solid_batch(nn, xyz, pid, props, want_K=True, want_M=True, body=g["body"], sigma=g[f"sigma{nn}"])
+    assert not o["status"].any()
+    for k, ref in (("K", "K"), ("M", "M"), ("f", "F"), ("KG", "KG")):
+        err = _rel(o[k], g[f"{ref}{nn}"])
+        print(nn, k, err)
+        assert err < 1e-12
+
+
+def test_quadratic_solid_tables_bitwise():
+    """The host-built shape tables of the HIP library (fs_solid2_table) equal the reference's
+    shape_functions / shape_function_derivatives / integration_points bit for bit."""
+    import ctypes
+    from fem_shell_amd import _lib
+    lib = _lib.load()
+    g = golden("solid2_tables")
+    for nn in (10, 15, 20):
+        ng = ctypes.c_int32(0)
+        pts, w, v = np.zeros((27, 3)), np.zeros(27), np.zeros(27 * nn * 4)
+        assert lib.fs_solid2_table(nn, pts.ctypes.data, w.ctypes.data, v.ctypes.data, ctypes.byref(ng)) == 0
+        n = ng.value
+        assert np.array_equal(pts[:n], g[f"pts{nn}"]) and np.array_equal(w[:n], g[f"w{nn}"])
+        assert np.array_equal(v[:n * nn * 4].reshape(n, nn, 4), g[f"vals{nn}"])
+    assert lib.fs_solid2_table(8, None, None, None, None) != 0
+
+
 def test_mitc3_nonlinear_vs_reference(oracle):
     """MITC3 / MITC3Composite TL tangent and internal force after update_configuration
     (elements/MITC3.py:1144-1832, MITC3_composite.py:496-621), incl. the T()-from-current-coords quirk."""

@@ -219,6 +219,58 @@ def gen_elem_solid():
     print("elem_solid.npz")
 
 
+SOLID2_REF = {
+    10: np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (.5, 0, 0), (.5, .5, 0), (0, .5, 0), (0, 0, .5),
+                  (0, .5, .5), (.5, 0, .5)], float),   # edges 4: 0-1, 5: 1-2, 6: 0-2, 7: 0-3, 8: 2-3, 9: 1-3
+    15: np.array([(0, 0, -1), (1, 0, -1), (0, 1, -1), (0, 0, 1), (1, 0, 1), (0, 1, 1), (.5, 0, -1), (0, .5, -1),
+                  (0, 0, 0), (.5, .5, -1), (1, 0, 0), (0, 1, 0), (.5, 0, 1), (0, .5, 1), (.5, .5, 1)], float),
+    20: np.array([(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1),
+                  (0, -1, -1), (-1, 0, -1), (-1, -1, 0), (1, 0, -1), (1, -1, 0), (0, 1, -1), (1, 1, 0), (-1, 1, 0),
+                  (0, -1, 1), (-1, 0, 1), (1, 0, 1), (0, 1, 1)], float),
+}
+
+
+def gen_elem_solid2():
+    """TETRA10 / WEDGE15 / HEXA20 (elements/SOLID.py:832-1059, 1600-1708, 1821-1946): the shape tables at the
+    integration points (bit-for-bit pins of the host tables; HEXA20 derivatives are forward differences) and
+    K, M, body_load, geometric stiffness for isotropic, orthotropic and rotated-orthotropic C."""
+    from fem_shell.elements.SOLID import HEXA20, TETRA10, WEDGE15
+    cls = {10: TETRA10, 15: WEDGE15, 20: HEXA20}
+    rng = np.random.default_rng(17)
+    out, tabs = {}, {}
+    body = np.array([1.0, -2.0, 9.81])
+    for nn in (10, 15, 20):
+        el0 = cls[nn](SOLID2_REF[nn], tuple(range(nn)), IsotropicMaterial("m", 1.0, 0.3, 1.0))
+        pts, w = el0.integration_points
+        vals = np.empty((len(w), nn, 4))
+        for q, pt in enumerate(pts):
+            vals[q, :, 0] = el0.shape_functions(*pt)
+            d = el0.shape_function_derivatives(*pt)
+            vals[q, :, 1], vals[q, :, 2], vals[q, :, 3] = d
+        tabs.update({f"pts{nn}": pts, f"w{nn}": w, f"vals{nn}": vals})
+        n = 12
+        xyz, props, K, M, F, KG, sig = [], [], [], [], [], [], []
+        for t in range(n):
+            x = SOLID2_REF[nn].copy() if t == 0 else SOLID2_REF[nn] + 0.05 * rng.standard_normal((nn, 3))
+            x = x * rng.choice([1.0, 1e-2, 30.0]) + (rng.choice([0.0, 5.0]) * rng.standard_normal(3) if t else 0.0)
+            if t % 3 == 2:
+                mat = t300()
+                ori = np.linalg.qr(rng.standard_normal((3, 3)))[0] if t % 2 else None
+            else:
+                E, nu, rho = ISO[t % len(ISO)]
+                mat, ori = IsotropicMaterial("m", E, nu, rho), None
+            el = cls[nn](x, tuple(range(nn)), mat, orientation=ori)
+            sg = rng.standard_normal(6) * 1e6
+            xyz.append(x); props.append(np.concatenate([el.C.ravel(), [mat.rho]]))
+            K.append(el.K); M.append(el.M); F.append(el.body_load(body))
+            KG.append(el.compute_geometric_stiffness(sg)); sig.append(sg)
+        out.update({f"xyz{nn}": np.array(xyz), f"props{nn}": np.array(props), f"K{nn}": np.array(K),
+                    f"M{nn}": np.array(M), f"F{nn}": np.array(F), f"KG{nn}": np.array(KG), f"sigma{nn}": np.array(sig)})
+    np.savez_compressed(os.path.join(OUT, "elem_solid2.npz"), body=body, **out)
+    np.savez_compressed(os.path.join(OUT, "solid2_tables.npz"), **tabs)
+    print("elem_solid2.npz, solid2_tables.npz")
+
+
 def gen_elem_nl():
     rng = np.random.default_rng(5)
     N = 24
@@ -419,6 +471,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ALL = dict(elem_mitc4=gen_elem_mitc4, elem_nl=gen_elem_nl, elem_mitc3=gen_elem_mitc3,
                elem_solid=gen_elem_solid, laminate=gen_laminate, scordelis=lambda: gen_scordelis(16),
-               elem_nl3=gen_elem_nl3, prestress=gen_prestress)
+               elem_nl3=gen_elem_nl3, prestress=gen_prestress, elem_solid2=gen_elem_solid2)
     for name in (sys.argv[1:] or list(ALL)):      # python tools/gen_golden.py [fixture ...]
         ALL[name]()

@@ -224,6 +224,39 @@ def solid_cases(out, sout):
     stress_fields(asm, seeded_u(rng, coords, 3), "hex_", sout, shell=False)
 
 
+def quadratic_cases(out, sout):
+    """q2_: one TETRA10, two WEDGE15 and three HEXA20 in one SOLID model (mixed node counts; the HEXA20 share a
+    face each) -- K, M, load vector, stress recovery with pinv extrapolation (27 / 21 Gauss points)."""
+    from gen_golden import SOLID2_REF
+    rng = np.random.default_rng(47)
+    pts, rows, key = [], [], {}
+
+    def add(nn, shift):
+        row = []
+        for p in SOLID2_REF[nn]:
+            q = tuple(np.round(p + np.asarray(shift, float), 6))
+            if q not in key:
+                key[q] = len(pts); pts.append(q)
+            row.append(key[q])
+        rows.append(row + [-1] * (20 - nn))
+
+    for i in range(3):
+        add(20, (2 * i, 0, 0))
+    add(15, (7, -1, 0)); add(15, (7, -1, 2))
+    add(10, (9, 0, 0))
+    coords = np.array(pts, float) + 0.02 * rng.standard_normal((len(pts), 3))
+    conn = np.array(rows, dtype=np.int64)
+    iso = IsotropicMaterial("steel", 2.1e11, 0.3, 7800.0)
+    mesh = RefMesh(coords, conn)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SOLID, "material": iso}})
+    out.update(q2_coords=coords, q2_conn=conn)
+    asm_common(asm, "q2_", out)
+    out["q2_dofs_list"] = np.concatenate(asm._dofs_list)
+    body = np.array([1.0, -2.0, -9.81])
+    out["q2_F"] = asm.assemble_load_vector(SimpleNamespace(value=body)).array
+    stress_fields(asm, seeded_u(rng, coords, 3), "q2_", sout, shell=False)
+
+
 if __name__ == "__main__":
     out, sout = {}, {}
     import contextlib
@@ -231,6 +264,7 @@ if __name__ == "__main__":
     with contextlib.redirect_stdout(io.StringIO()):      # the reference prints progress lines
         shell_cases(out, sout)
         solid_cases(out, sout)
+        quadratic_cases(out, sout)
     np.savez_compressed(os.path.join(OUT, "asm_ref.npz"), **out)
     np.savez_compressed(os.path.join(OUT, "stress_ref.npz"), **sout)
     print("asm_ref.npz", len(out), "arrays;", "stress_ref.npz", len(sout), "arrays")
