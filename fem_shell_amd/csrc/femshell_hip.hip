@@ -827,6 +827,90 @@ __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__
     for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
 }
 
+// Tiled-layout mass kernel (FS_LAYOUT_SYMBLK_T16): one wave per 16-element tile, lane = (element, task lane)
+// as in mitc4_k_kernel, the same three task rounds and the same LDS-staged whole-line stores -- the mass
+// blocks are cheap (8 kflop per element), the kernel is bound by the 2 880 B per element it writes, and the
+// thread-per-pair form above spends most of its time on scattered 16-byte pieces.  Same arithmetic per
+// block as mitc4_m_kernel (bitwise identical values).
+__global__ __launch_bounds__(64) void mitc4_m_tiled_kernel(const double *__restrict__ xyz,
+                                                           const int32_t *__restrict__ prop_id,
+                                                           const fs_shell_prop *__restrict__ props,
+                                                           int64_t E, double *__restrict__ out) {
+    __shared__ double lds[32 * STG_SLOT];
+    const int lane = threadIdx.x;
+    const int Q = lane >> 2, g = lane & 3;
+    const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
+    const int64_t e = (e_raw < E) ? e_raw : (E - 1);
+    double x[4][3];
+    {
+        const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
+        for (int t = 0; t < 6; t++) {
+            const double2 v = p[t];
+            (&x[0][0])[2 * t] = v.x;
+            (&x[0][0])[2 * t + 1] = v.y;
+        }
+    }
+    QuadGeom geo;
+    quad_geometry(x, geo);
+    const fs_shell_prop *pr = props + prop_id[e];
+    const double mt = pr->m_t, mr = pr->m_r;
+    double det[4];
+    for (int q = 0; q < 4; q++) {
+        const double xi = (q == 1 || q == 2) ? kGP : -kGP, eta = (q >= 2) ? kGP : -kGP;
+        double dxi[4], deta[4], ia, ib, ic, id;
+        dshape(xi, eta, dxi, deta);
+        det[q] = jacobian(geo, dxi, deta, ia, ib, ic, id);
+    }
+    const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    for (int round = 0; round < 3; round++) {
+        int ti, tj;
+        if (round == 0) { ti = g; tj = g; }
+        else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
+        else { ti = g & 1; tj = (g & 1) + 2; }
+        const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
+        const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
+        double ct = 0.0, cr = 0.0;
+        for (int q = 0; q < 4; q++) {
+            const double xi = (q == 1 || q == 2) ? kGP : -kGP, eta = (q >= 2) ? kGP : -kGP;
+            const double Ni = 0.25 * (1.0 + sxi * xi) * (1.0 + syi * eta);
+            const double Nj = 0.25 * (1.0 + sxj * xi) * (1.0 + syj * eta);
+            ct = ct + Ni * Nj * mt * 1.0 * det[q];
+            cr = cr + Ni * Nj * mr * 1.0 * det[q];
+        }
+        double G[6][6];
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) G[a][b] = 0.0;
+        for (int p3 = 0; p3 < 3; p3++)
+            for (int q = 0; q < 3; q++) {
+                double st = 0.0, sr = 0.0;
+                for (int k = 0; k < 3; k++) {
+                    st = FMA(R[k][p3] * ct, R[k][q], st);
+                    sr = FMA(R[k][p3] * cr, R[k][q], sr);
+                }
+                G[p3][q] = st;
+                G[3 + p3][3 + q] = sr;
+            }
+        const int npass = (round == 2) ? 1 : 2;
+        for (int h = 0; h < npass; h++) {
+            const bool mine = (round == 2) ? (g < 2) : ((lane >> 5) == h);
+            const int slot = (round == 2) ? ((g << 4) + Q) : ((g << 3) + (Q & 7));
+            if (mine) {
+                double2 *sp = reinterpret_cast<double2 *>(lds + slot * STG_SLOT);
+                for (int t = 0; t < 18; t++) sp[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
+            }
+            __syncthreads();
+            double2 *gp = reinterpret_cast<double2 *>(out + ((int64_t)blockIdx.x * 160 + round * 64 + h * 32) * 36) + lane;
+            const double2 *sp2 = reinterpret_cast<const double2 *>(lds);
+            for (int i = 0; i < 9; i++) {
+                const int c = i * 64 + lane;
+                const int bl = (c * 3641) >> 16;        // c / 18 for c < 576
+                gp[i * 64] = sp2[c + bl];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // MITC3+ (elements/MITC3.py, MITC3_composite.py).  One thread per (element, node pair i<=j):
 // each thread rebuilds the (cheap) triangle geometry, evaluates the shape data of functions
@@ -2025,8 +2109,11 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
     }
     if (want & FS_WANT_M) {
         if (!Me) return fail(FS_EINVAL, "fs_shell_quad_batch: Me is null");
-        hipLaunchKernelGGL(mitc4_m_kernel, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz,
-                           prop_id, props, E, Me, tiled);
+        if (tiled)
+            hipLaunchKernelGGL(mitc4_m_tiled_kernel, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, s, xyz, prop_id, props, E, Me);
+        else
+            hipLaunchKernelGGL(mitc4_m_kernel, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz,
+                               prop_id, props, E, Me, tiled);
         FS_LAUNCH_CHECK("mitc4_m_kernel");
     }
     return FS_OK;
