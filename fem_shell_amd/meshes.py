@@ -194,3 +194,33 @@ def twisted_beam(length, width, twist_deg, nx, ny, triangular=False):
     mesh.coords[:, 1] = y * np.cos(phi)
     mesh.coords[:, 2] = y * np.sin(phi)
     return mesh
+
+
+def sphere_patch(radius, theta_min_deg, theta_max_deg, phi_max_deg, n, triangular=False):
+    """test_ko2017_performance.py:1558-1604 (_build_sphere_patch): structured in (theta, phi); the
+    hemisphere with an 18 degree cut-out is theta in [18, 90], phi in [0, 90]."""
+    th = np.linspace(np.radians(theta_min_deg), np.radians(theta_max_deg), n + 1)
+    ph = np.linspace(0.0, np.radians(phi_max_deg), n + 1)
+    TH, PH = np.meshgrid(th, ph, indexing="ij")           # node (i, j) -> row j (theta), column i (phi)
+    coords = np.stack([radius * np.sin(TH) * np.cos(PH), radius * np.sin(TH) * np.sin(PH), radius * np.cos(TH)], -1)
+    return ArrayMesh(coords.reshape(-1, 3), structured_conn(n, n, triangular))
+
+
+def tapered_tube(n_around, n_span, length=60.0, r_root=2.5, r_tip=0.4, n_sets_around=24, n_sets_span=8):
+    """Blade-like closed shell for config C3: a tapered, slightly twisted and flattened tube of
+    n_around x n_span quads (closed in the circumferential direction), split into n_sets_around x n_sets_span
+    element sets.  The real blade geometry cannot be regenerated here (no gmsh / turbine YAML)."""
+    s = np.linspace(0.0, 1.0, n_span + 1)
+    a = np.arange(n_around) * (2.0 * np.pi / n_around)
+    S, A = np.meshgrid(s, a, indexing="ij")
+    r = r_root + (r_tip - r_root) * S
+    tw = np.radians(15.0) * S
+    xc, yc = r * np.cos(A), 0.45 * r * np.sin(A)                       # flattened section
+    coords = np.stack([xc * np.cos(tw) - yc * np.sin(tw), xc * np.sin(tw) + yc * np.cos(tw), length * S], -1).reshape(-1, 3)
+    ids = np.arange((n_span + 1) * n_around, dtype=np.int64).reshape(n_span + 1, n_around)
+    nxt = np.roll(ids, -1, axis=1)
+    conn = np.stack([ids[:-1], nxt[:-1], nxt[1:], ids[1:]], -1).reshape(-1, 4)
+    ia = np.tile(np.arange(n_around) * n_sets_around // n_around, n_span)
+    js = np.repeat(np.arange(n_span) * n_sets_span // n_span, n_around)
+    set_id = (js * n_sets_around + ia).astype(np.int32)
+    return ArrayMesh(coords, conn, set_id, [f"set_{k}" for k in range(n_sets_around * n_sets_span)])
