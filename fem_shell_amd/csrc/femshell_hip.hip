@@ -777,6 +777,277 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// Tiled-layout form of mitc4_nl_kernel (FS_LAYOUT_SYMBLK_T16).  The per-element form above walks its
+// ten 288-byte blocks with per-lane strided 8-byte accesses (5.1 ms per 1.25 M elements for K_T + f_int);
+// here a wave owns a 16-element tile like mitc4_k_kernel:
+//   * lane = (element, Gauss point): the Gauss-point work (H, Green-Lagrange strain, B_L + B_NL, K_L + K_sigma
+//     contributions, membrane force, membrane core S) is split over the four lanes of an element and summed
+//     with DPP quad reductions; the 10 x 3 x 3 tangent corrections go to LDS;
+//   * the tile's 160 blocks stream through the LDS staging area in the order mitc4_k_kernel wrote them (whole
+//     128-byte lines in, whole lines out); the lane owning a node-pair task adds R^T sym(dL) R to the
+//     translational sub-block and accumulates K u for its two nodes in LDS (one writer per node and step).
+// Same formulas as mitc4_nl_kernel; sums over Gauss points and over blocks associate differently (eps level).
+// ------------------------------------------------------------------------------------------
+constexpr int NLT_STG = 0;                          // staging, 32 slots
+constexpr int NLT_DL = NLT_STG + 32 * STG_SLOT;     // dL[p][k][l][Q]: 90 x 16
+constexpr int NLT_F = NLT_DL + 90 * 16;             // f[node][a][Q]: 24 x 16
+constexpr int NLT_LDS = NLT_F + 24 * 16;
+
+__global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__restrict__ xyz,
+                                                            const int32_t *__restrict__ prop_id,
+                                                            const fs_shell_prop *__restrict__ props,
+                                                            const double *__restrict__ ue, int64_t E,
+                                                            double *__restrict__ kt, int want_kt,
+                                                            double *__restrict__ fe) {
+    __shared__ double lds[NLT_LDS];
+    const int lane = threadIdx.x;
+    const int Q = lane >> 2, g = lane & 3;
+    const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
+    const bool valid = e_raw < E;
+    const int64_t e = valid ? e_raw : (E - 1);
+    double x[4][3], u[4][6];
+    {
+        const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
+        for (int t = 0; t < 6; t++) { const double2 v = p[t]; (&x[0][0])[2 * t] = v.x; (&x[0][0])[2 * t + 1] = v.y; }
+        const double2 *q = reinterpret_cast<const double2 *>(ue + e * 24);
+        for (int t = 0; t < 12; t++) { const double2 v = q[t]; (&u[0][0])[2 * t] = v.x; (&u[0][0])[2 * t + 1] = v.y; }
+    }
+    const fs_shell_prop *pr = props + prop_id[e];
+    QuadGeom geo;
+    quad_geometry(x, geo);
+    const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
+    const bool nonlinear = pr->nonlinear != 0;
+    const int pidx[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+    double fnl[3] = {0.0, 0.0, 0.0};    // nonlinear part of f for node g (global axes)
+    {
+#pragma clang fp contract(fast)
+        if (want_kt)
+            for (int t = 0; t < 90; t++) if ((t & 3) == g) lds[NLT_DL + (t << 4) + Q] = 0.0;
+        for (int t = 0; t < 6; t++) lds[NLT_F + ((g * 6 + t) << 4) + Q] = 0.0;
+        if (nonlinear) {
+            const double h = pr->h;
+            double C[3][3];
+            for (int a = 0; a < 9; a++) (&C[0][0])[a] = pr->C_raw[a];
+            double ul[4][3], rl[4][3];
+            for (int i = 0; i < 4; i++)
+                for (int a = 0; a < 3; a++) {
+                    ul[i][a] = R[a][0] * u[i][0] + R[a][1] * u[i][1] + R[a][2] * u[i][2];
+                    rl[i][a] = R[a][0] * u[i][3] + R[a][1] * u[i][4] + R[a][2] * u[i][5];
+                }
+            double Sm00, Sm01, Sm11;   // membrane stress at the centre (MITC4.py:1227-1240; MITC4_composite.py:499-508)
+            {
+                double dxi[4], deta[4], ia, ib, ic, id;
+                dshape(0.0, 0.0, dxi, deta);
+                jacobian(geo, dxi, deta, ia, ib, ic, id);
+                double eps[3] = {0, 0, 0}, kap[3] = {0, 0, 0};
+                for (int i = 0; i < 4; i++) {
+                    const double nx = ia * dxi[i] + ib * deta[i], ny = ic * dxi[i] + id * deta[i];
+                    eps[0] += nx * ul[i][0]; eps[1] += ny * ul[i][1]; eps[2] += ny * ul[i][0] + nx * ul[i][1];
+                    kap[0] += nx * rl[i][1]; kap[1] += -ny * rl[i][0]; kap[2] += ny * rl[i][1] - nx * rl[i][0];
+                }
+                double sig[3];
+                if (pr->flags & FS_PROP_LAMINATE) {
+                    for (int a = 0; a < 3; a++)
+                        sig[a] = ((pr->A[a * 3] * eps[0] + pr->A[a * 3 + 1] * eps[1] + pr->A[a * 3 + 2] * eps[2]) +
+                                  (pr->B[a * 3] * kap[0] + pr->B[a * 3 + 1] * kap[1] + pr->B[a * 3 + 2] * kap[2])) / h;
+                } else {
+                    for (int a = 0; a < 3; a++) sig[a] = C[a][0] * eps[0] + C[a][1] * eps[1] + C[a][2] * eps[2];
+                }
+                Sm00 = sig[0] * h; Sm11 = sig[1] * h; Sm01 = sig[2] * h;
+            }
+            // ---- Gauss point g of this lane ----
+            const double xi = (g == 1 || g == 2) ? kGP : -kGP, eta = (g >= 2) ? kGP : -kGP;
+            double dxi[4], deta[4], ia, ib, ic, id;
+            dshape(xi, eta, dxi, deta);
+            const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
+            double nx[4], ny[4];
+            for (int i = 0; i < 4; i++) { nx[i] = ia * dxi[i] + ib * deta[i]; ny[i] = ic * dxi[i] + id * deta[i]; }
+            double H[3][2];   // GLOBAL displacement components, local derivatives (MITC4.py:1092-1107)
+            for (int c = 0; c < 3; c++) {
+                H[c][0] = dots4(u[0][c], u[1][c], u[2][c], u[3][c], nx[0], nx[1], nx[2], nx[3]);
+                H[c][1] = dots4(u[0][c], u[1][c], u[2][c], u[3][c], ny[0], ny[1], ny[2], ny[3]);
+            }
+            const double E00 = 0.5 * (2.0 * H[0][0] + (H[0][0] * H[0][0] + H[1][0] * H[1][0] + H[2][0] * H[2][0]));
+            const double E11 = 0.5 * (2.0 * H[1][1] + (H[0][1] * H[0][1] + H[1][1] * H[1][1] + H[2][1] * H[2][1]));
+            const double E01 = 0.5 * ((H[0][1] + H[1][0]) + (H[0][0] * H[0][1] + H[1][0] * H[1][1] + H[2][0] * H[2][1]));
+            const double eg[3] = {E00, E11, 2.0 * E01};
+            double sg[3];
+            for (int a = 0; a < 3; a++) sg[a] = C[a][0] * eg[0] + C[a][1] * eg[1] + C[a][2] * eg[2];
+            const double wh = detJ * h;
+            double Bt[4][3][3], BL[4][3][3], CBt[4][3][3], CBL[4][3][3], fm[4][3];
+            for (int i = 0; i < 4; i++) {
+                for (int k = 0; k < 3; k++) {
+                    BL[i][0][k] = (k == 0) ? nx[i] : 0.0;
+                    BL[i][1][k] = (k == 1) ? ny[i] : 0.0;
+                    BL[i][2][k] = (k == 0) ? ny[i] : ((k == 1) ? nx[i] : 0.0);
+                    Bt[i][0][k] = BL[i][0][k] + H[k][0] * nx[i];
+                    Bt[i][1][k] = BL[i][1][k] + H[k][1] * ny[i];
+                    Bt[i][2][k] = BL[i][2][k] + (H[k][0] * ny[i] + H[k][1] * nx[i]);
+                }
+                for (int a = 0; a < 3; a++)
+                    for (int k = 0; k < 3; k++) {
+                        CBt[i][a][k] = wh * (C[a][0] * Bt[i][0][k] + C[a][1] * Bt[i][1][k] + C[a][2] * Bt[i][2][k]);
+                        CBL[i][a][k] = wh * (C[a][0] * BL[i][0][k] + C[a][1] * BL[i][1][k] + C[a][2] * BL[i][2][k]);
+                    }
+                for (int k = 0; k < 3; k++)
+                    fm[i][k] = quad_sum(wh * (Bt[i][0][k] * sg[0] + Bt[i][1][k] * sg[1] + Bt[i][2][k] * sg[2]));
+            }
+            if (want_kt) {   // K_L + K_sigma, translational sub-blocks of the pairs i <= j (local axes) -> LDS
+                for (int i = 0; i < 4; i++)
+                    for (int j = i; j < 4; j++) {
+                        const int p = pidx[i][j];
+                        const double ks = detJ * (nx[i] * (Sm00 * nx[j] + Sm01 * ny[j]) + ny[i] * (Sm01 * nx[j] + Sm11 * ny[j]));
+                        for (int k = 0; k < 3; k++)
+                            for (int l = 0; l < 3; l++) {
+                                double v = Bt[i][0][k] * CBt[j][0][l] + Bt[i][1][k] * CBt[j][1][l] + Bt[i][2][k] * CBt[j][2][l];
+                                v -= BL[i][0][k] * CBL[j][0][l] + BL[i][1][k] * CBL[j][1][l] + BL[i][2][k] * CBL[j][2][l];
+                                if (k == l) v += ks;
+                                v = quad_sum(v);
+                                const int t = p * 9 + k * 3 + l;
+                                if ((t & 3) == g) lds[NLT_DL + (t << 4) + Q] = v;
+                            }
+                    }
+            }
+            if (fe) {   // f_loc = f_memb - K_m u_loc, K_m u_loc = Y^T S (Y u_loc); lane g keeps node g
+                double W[3][5], Sf[5][5];
+                membrane_W(geo, xi, eta, detJ, ia, ib, ic, id, W);
+                for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = 0.0;
+                for (int t = 0; t < 5; t++)
+                    for (int a = 0; a < 3; a++) {
+                        const double cw = detJ * (pr->A[a * 3] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
+                        for (int v = 0; v < 5; v++) Sf[v][t] += W[a][v] * cw;
+                    }
+                for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = quad_sum((&Sf[0][0])[t]);
+                double gt[6][3];
+                {
+#pragma clang fp contract(off)
+                    double t3[3];
+                    for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
+                    gt[0][0] = dot3(t3, geo.e1); gt[0][1] = dot3(t3, geo.e2); gt[0][2] = dot3(t3, geo.e3);
+                    for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
+                    gt[1][0] = dot3(t3, geo.e1); gt[1][1] = dot3(t3, geo.e2); gt[1][2] = dot3(t3, geo.e3);
+                    for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
+                    gt[2][0] = dot3(t3, geo.e1); gt[2][1] = dot3(t3, geo.e2); gt[2][2] = dot3(t3, geo.e3);
+                    for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
+                    gt[3][0] = dot3(t3, geo.e1); gt[3][1] = dot3(t3, geo.e2); gt[3][2] = dot3(t3, geo.e3);
+                    for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
+                    gt[4][0] = dot3(t3, geo.e1); gt[4][1] = dot3(t3, geo.e2); gt[4][2] = dot3(t3, geo.e3);
+                    for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
+                    gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
+                }
+                double z[5] = {0, 0, 0, 0, 0}, Yg[5][3];
+                for (int i = 0; i < 4; i++) {
+                    double w[6];
+                    tying_weights(i, w);
+                    for (int k = 0; k < 3; k++) {
+                        double y[5];
+                        for (int t = 0; t < 4; t++) y[t] = w[t] * gt[t][k];
+                        y[4] = w[4] * gt[4][k] + w[5] * gt[5][k];
+                        for (int t = 0; t < 5; t++) {
+                            z[t] += y[t] * ul[i][k];
+                            if (i == g) Yg[t][k] = y[t];
+                        }
+                    }
+                }
+                double Sz[5];
+                for (int t = 0; t < 5; t++) Sz[t] = Sf[t][0] * z[0] + Sf[t][1] * z[1] + Sf[t][2] * z[2] + Sf[t][3] * z[3] + Sf[t][4] * z[4];
+                double fl[3];
+                for (int k = 0; k < 3; k++) {
+                    double v = 0.0;
+                    for (int i = 0; i < 4; i++) v = (i == g) ? fm[i][k] : v;
+                    for (int t = 0; t < 5; t++) v -= Yg[t][k] * Sz[t];
+                    fl[k] = v;
+                }
+                for (int a = 0; a < 3; a++) fnl[a] = R[0][a] * fl[0] + R[1][a] * fl[1] + R[2][a] * fl[2];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stream the tile: K u (linear blocks) and K_T = K + R^T sym(dL) R ----
+    for (int round = 0; round < 3; round++) {
+#pragma clang fp contract(fast)
+        int ti, tj;
+        if (round == 0) { ti = g; tj = g; }
+        else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
+        else { ti = g & 1; tj = (g & 1) + 2; }
+        const int p = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
+        const int npass = (round == 2) ? 1 : 2;
+        for (int h = 0; h < npass; h++) {
+            double2 *gp = reinterpret_cast<double2 *>(kt + ((int64_t)blockIdx.x * 160 + round * 64 + h * 32) * 36) + lane;
+            double2 *st2 = reinterpret_cast<double2 *>(lds + NLT_STG);
+            for (int i = 0; i < 9; i++) {
+                const int c = i * 64 + lane;
+                const int bl = (c * 3641) >> 16;        // c / 18 for c < 576
+                st2[c + bl] = gp[i * 64];
+            }
+            __syncthreads();
+            const bool mine = (round == 2) ? (g < 2) : ((lane >> 5) == h);
+            const int slot = (round == 2) ? ((g << 4) + Q) : ((g << 3) + (Q & 7));
+            double G[6][6];
+            double *sp = lds + NLT_STG + slot * STG_SLOT;
+            if (mine) {
+                for (int t = 0; t < 36; t++) (&G[0][0])[t] = sp[t];
+                if (want_kt && nonlinear) {
+                    double Xs[3][3];
+                    for (int k = 0; k < 3; k++)
+                        for (int l = 0; l < 3; l++) Xs[k][l] = lds[NLT_DL + ((p * 9 + k * 3 + l) << 4) + Q];
+                    if (ti == tj)
+                        for (int k = 0; k < 3; k++)
+                            for (int l = k + 1; l < 3; l++) { const double m = 0.5 * (Xs[k][l] + Xs[l][k]); Xs[k][l] = m; Xs[l][k] = m; }
+                    double Yt[3][3];
+                    for (int a = 0; a < 3; a++)
+                        for (int l = 0; l < 3; l++) Yt[a][l] = R[0][a] * Xs[0][l] + R[1][a] * Xs[1][l] + R[2][a] * Xs[2][l];
+                    double T[3][3];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) T[a][b] = G[a][b] + (Yt[a][0] * R[0][b] + Yt[a][1] * R[1][b] + Yt[a][2] * R[2][b]);
+                    if (ti == tj)
+                        for (int a = 0; a < 3; a++)
+                            for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (T[a][b] + T[b][a]); T[a][b] = m; T[b][a] = m; }
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) sp[a * 6 + b] = T[a][b];
+                }
+            }
+            if (fe) {   // f_i += G u_j (step 0), f_j += G^T u_i (step 1, off-diagonal tasks); one writer per node
+                for (int step = 0; step < 2; step++) {
+                    // round 1: lanes 0..2 give node ti first, lane 3 (pair 0-3) gives node tj = 3 first
+                    const bool first = (round == 1 && g == 3) ? (step == 1) : (step == 0);
+                    if (mine && !(ti == tj && step == 1)) {
+                        const int node = first ? ti : tj, other = first ? tj : ti;
+                        double uo[6];
+                        for (int b = 0; b < 6; b++) {
+                            double v = 0.0;
+                            for (int n = 0; n < 4; n++) v = (n == other) ? u[n][b] : v;
+                            uo[b] = v;
+                        }
+                        for (int a = 0; a < 6; a++) {
+                            double v = lds[NLT_F + ((node * 6 + a) << 4) + Q];
+                            for (int b = 0; b < 6; b++) v += (first ? G[a][b] : G[b][a]) * uo[b];
+                            lds[NLT_F + ((node * 6 + a) << 4) + Q] = v;
+                        }
+                    }
+                    __syncthreads();
+                }
+            } else {
+                __syncthreads();
+            }
+            if (want_kt)
+                for (int i = 0; i < 9; i++) {
+                    const int c = i * 64 + lane;
+                    const int bl = (c * 3641) >> 16;
+                    gp[i * 64] = st2[c + bl];
+                }
+            __syncthreads();
+        }
+    }
+    if (fe && valid) {
+        for (int a = 0; a < 6; a++) {
+            const double v = lds[NLT_F + ((g * 6 + a) << 4) + Q] + ((a < 3) ? fnl[a] : 0.0);
+            fe[e * 24 + 6 * g + a] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // MITC4 consistent mass (MITC4.py:1038-1061), FS_LAYOUT_SYMBLK: one thread per (element, pair)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__ xyz,
@@ -2096,8 +2367,12 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
         if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
         else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
         FS_LAUNCH_CHECK("mitc4_k_kernel");
-        hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
-                           E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled);
+        if (tiled)
+            hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E, KTe,
+                               (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+        else
+            hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
+                               E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled);
         FS_LAUNCH_CHECK("mitc4_nl_kernel");
     }
     if (want & FS_WANT_K) {
