@@ -130,6 +130,41 @@ def hex8_leg(torch, steps=5):
             "k_tflops": E * 47000.0 / (k_ms * 1e-3) / 1e12, "flop_per_element": 47000.0}
 
 
+def newton_leg(torch, steps=10):
+    """configs[3]: geometric-nonlinear MITC4+ cantilever, tangent K_T and f_int re-assembled every Newton
+    iteration (400 x 40 strip, E = 1.2e6, nu = 0, t = 0.1, u_k = k * 1e-3 * smooth field), and the
+    same re-assembly on a 1.25 M-element plate.  Timed on its own, outside `value`."""
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    mat = fsa.IsotropicMaterial("cant", 1.2e6, 0.0, 1.0)
+    out = {}
+    for tag, nx, ny in (("c4_400x40", 400, 40), ("plate_400x3125", STRIP_NX, STRIP_NY)):
+        mesh = meshes.flat_patch(0.0, 10.0, 0.0, 1.0 * ny / 40, nx, ny)
+        asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat,
+                                                "thickness": 0.1, "nonlinear": True}})
+        xs = torch.from_numpy(mesh.coords[:, 0]).to(asm.device)
+        field = torch.zeros((mesh.node_count, 6), dtype=torch.float64, device=asm.device)
+        field[:, 2] = xs ** 2 / 100.0
+        field[:, 4] = -2.0 * xs / 100.0
+        field = field.reshape(-1)
+        asm.assemble_tangent_and_forces(field * 1e-3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(1, steps + 1):
+            asm.assemble_tangent_and_forces(field * (k * 1e-3))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        E = mesh.element_count
+        out[tag] = {"elements": E, "ms_per_reassembly": ms, "reassemblies_per_s": 1e3 / ms,
+                    "elements_per_s": E / (ms * 1e-3)}
+        del asm
+    out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate: gather u_e, element K kernel, TL tangent / " \
+                  "internal-force kernel, CSR assembly, vector scatter"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +288,7 @@ def main():
             nt = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(nt)
             line["hex8"] = hex8_leg(torch)
+            line["newton"] = newton_leg(torch)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
