@@ -130,6 +130,41 @@ def hex8_leg(torch, steps=5):
             "k_tflops": E * 47000.0 / (k_ms * 1e-3) / 1e12, "flop_per_element": 47000.0}
 
 
+def c2_leg(torch, steps=20):
+    """configs[1]: pinched hemisphere with an 18 degree cut-out, 256 x 256, MITC4+ (65 536 quads) and MITC3+
+    (131 072 triangles) on one GPU.  Step = element K kernel + CSR assembly, as in `value`."""
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    mat = fsa.IsotropicMaterial("Ko2017_Sphere", 6.825e7, 0.3, 1.0)
+    out = {}
+    for tag, tri in (("mitc4_256x256", False), ("mitc3_256x256", True)):
+        mesh = meshes.sphere_patch(10.0, 18.0, 90.0, 90.0, 256, triangular=tri)
+        asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.04}})
+        for _ in range(3):
+            asm.assemble_stiffness_matrix(recompute=True)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        k_ms = a_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ev[0].record()
+            asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
+            ev[1].record()
+            K = asm.assemble_stiffness_matrix(recompute=False)
+            ev[2].record()
+            torch.cuda.synchronize()
+            k_ms += ev[0].elapsed_time(ev[1]) / steps
+            a_ms += ev[1].elapsed_time(ev[2]) / steps
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        E = mesh.element_count
+        out[tag] = {"elements": E, "nnz": int(K.nnz), "element_kernel_ms": k_ms, "assembly_ms": a_ms,
+                    "ms_per_step_wall": wall, "elements_per_s": E / ((k_ms + a_ms) * 1e-3)}
+        del asm
+    return out
+
+
 def newton_leg(torch, steps=10):
     """configs[3]: geometric-nonlinear MITC4+ cantilever, tangent K_T and f_int re-assembled every Newton
     iteration (400 x 40 strip, E = 1.2e6, nu = 0, t = 0.1, u_k = k * 1e-3 * smooth field), and the
@@ -289,6 +324,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(nt)
             line["hex8"] = hex8_leg(torch)
             line["newton"] = newton_leg(torch)
+            line["c2_hemisphere"] = c2_leg(torch)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
