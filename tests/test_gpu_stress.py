@@ -97,3 +97,51 @@ def test_module_helpers():
     assert np.abs(compute_max_shear_stress(s[0], s[1], s[3], s[2], s[4], s[5]) - (mir[:, 2] - mir[:, 0]) / 2).max() / sc < 1e-9
     a, b, th = compute_principal_stresses(s[0], s[1], s[3])
     assert np.allclose(a + b, s[0] + s[1], rtol=1e-12)
+
+
+def test_stress_vs_oracle_larger_mesh():
+    """A 40 x 23 jittered laminate plate (8 property sets) and a 12 x 6 x 4 HEXA8 block: GPU StressRecovery vs the
+    CPU restatement oracle/stress.py (itself pinned to the reference fixtures in tests/test_oracle_stress.py)."""
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    from fem_shell_amd.properties import solid_C
+    from oracle import stress as S
+    from tests import util
+    rng = np.random.default_rng(9)
+    mesh = meshes.jittered_plate(40, 23, n_sets=8)
+    props = util.standard_props()
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
+                                            "properties": {f"band_{i}": props[i] for i in range(8)}}})
+    u = rng.standard_normal(asm.dofs_count) * 1e-6
+    sr = StressRecovery(asm, u)
+    data = [(asm._prop_table["A"][p].reshape(3, 3), float(asm._prop_table["h"][p])) for p in asm._prop_id]
+    for nodal, weighted in ((False, False), (True, False), (True, True)):
+        ref = S.recover(mesh.coords, mesh.conn, u, "shell", data, 1, 3, False, nodal, weighted)
+        got = (sr.compute_nodal_stresses(StressLocation.TOP, StressType.TOTAL, "area_weighted" if weighted else "average")
+               if nodal else sr.compute_element_stresses(StressLocation.TOP, StressType.TOTAL))
+        scale = np.abs(ref).max()
+        assert np.abs(got.sigma_xx - ref[:, 0]).max() < 1e-12 * scale and np.abs(got.sigma_yy - ref[:, 1]).max() < 1e-12 * scale
+        assert np.abs(got.von_mises - S.invariants(ref, False)["von_mises"]).max() < 1e-12 * scale
+    # solids
+    nx, ny, nz = 12, 6, 4
+    ids = np.arange((nx + 1) * (ny + 1) * (nz + 1)).reshape(nz + 1, ny + 1, nx + 1)
+    Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
+    coords = np.stack([X, Y, Z], -1).reshape(-1, 3) + 0.05 * rng.standard_normal((ids.size, 3))
+    n = lambda dz, dy, dx: ids[dz:nz + dz, dy:ny + dy, dx:nx + dx]
+    conn = np.stack([n(0, 0, 0), n(0, 0, 1), n(0, 1, 1), n(0, 1, 0), n(1, 0, 0), n(1, 0, 1), n(1, 1, 1), n(1, 1, 0)], -1).reshape(-1, 8)
+    mat = util.t300()
+    asm = MeshAssembler(meshes.ArrayMesh(coords, conn), {"elements": {"element_family": ElementFamily.SOLID, "material": mat}})
+    u = rng.standard_normal(asm.dofs_count) * 1e-4
+    sr = StressRecovery(asm, u)
+    C = [solid_C(mat, None)] * conn.shape[0]
+    for nodal, weighted in ((False, False), (True, True)):
+        ref = S.recover(coords, conn, u, "solid", C, 0, 3, False, nodal, weighted)
+        got = sr.compute_nodal_stresses(smoothing="area_weighted") if nodal else sr.compute_element_stresses()
+        scale = np.abs(ref).max()
+        for k, col in (("sigma_xx", 0), ("sigma_yy", 1), ("sigma_zz", 2), ("sigma_xy", 3), ("tau_yz", 4), ("tau_zx", 5)):
+            assert np.abs(getattr(got, k) - ref[:, col]).max() < 1e-12 * scale, k
+        eps = S.recover(coords, conn, u, "solid", C, 0, 3, True, nodal, weighted)
+        ge = sr.compute_nodal_strains(smoothing="area_weighted") if nodal else sr.compute_element_strains()
+        assert np.abs(ge.gamma_yz - eps[:, 4]).max() < 1e-12 * np.abs(eps).max()
