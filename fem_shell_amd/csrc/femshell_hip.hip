@@ -21,7 +21,6 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -515,458 +514,6 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
             const int p = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
             double2 *dst = reinterpret_cast<double2 *>(out + (e * 10 + p) * 36);
             for (int t = 0; t < 18; t++) dst[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Two-wave form of the tiled stiffness kernel.  mitc4_k_kernel keeps a whole 6x6 block (L, then G) per lane and
-// ends at 256 VGPR + 30 AGPR and 34 KB LDS per wave: ONE wave per SIMD, whose dependent fp64 FMA chains leave the
-// VALU 48 % idle (profiles/r01_fp64_fma_ilp.txt).  Here a 16-element tile is worked by a 128-thread workgroup:
-//   wave 0: geometry, membrane core S and coupling cores U (stage 1), then the TOP halves (rows u, v, w of node
-//           i) of the 10 node-pair blocks;
-//   wave 1: geometry, edge-tied shear and bubble data, Kbb^-1 (stage 1), then the BOTTOM halves (thx, thy, thz);
-// both work on ONE LDS image, so the LDS per wave halves and a half block needs half the registers -> two waves
-// per SIMD.  Every entry is produced by the same operation sequence as in mitc4_k_kernel (bitwise identical
-// output, tests/test_gpu_mitc4.py).
-// ------------------------------------------------------------------------------------------
-constexpr int K2_INV = LDS_WAVE_T16;       // i00, i01, i11 [3][16]
-constexpr int K2_LDS = K2_INV + 3 * 16;
-
-__global__ __launch_bounds__(128) void mitc4_k2_kernel(const double *__restrict__ xyz,
-                                                       const int32_t *__restrict__ prop_id,
-                                                       const fs_shell_prop *__restrict__ props,
-                                                       int64_t E, double *__restrict__ out,
-                                                       int32_t *__restrict__ status) {
-    __shared__ double lds[K2_LDS];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int Q = lane >> 2, g = lane & 3;
-    const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
-    const bool valid = e_raw < E;
-    const int64_t e = valid ? e_raw : (E - 1);
-
-    double x[4][3];
-    {
-        const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
-        for (int t = 0; t < 6; t++) {
-            const double2 v = p[t];
-            (&x[0][0])[2 * t] = v.x;
-            (&x[0][0])[2 * t + 1] = v.y;
-        }
-    }
-    const fs_shell_prop *pr = props + prop_id[e];
-    const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
-    const bool any_coupled = __any(coupled);
-
-    QuadGeom geo;
-    quad_geometry(x, geo);
-
-    // ---------------- stage 1: Gauss point g ----------------
-    const double xi = (g == 1 || g == 2) ? kGP : -kGP;
-    const double eta = (g >= 2) ? kGP : -kGP;
-    double dxi[4], deta[4];
-    dshape(xi, eta, dxi, deta);
-    double ia, ib, ic, id;
-    const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
-    int st = geo.status | ((detJ > 0.0) ? 0 : FS_ST_BAD_JAC);
-
-    // tangent vectors at the 5 tying points (MITC4.py:589-612 evaluated at A,B,C,D,E; the zero
-    // shape-derivative terms are dropped, which is exact), projected on the frame (:287-296).
-    // gt[0..3] = g_r(A), g_r(B), g_s(C), g_s(D); gt[4], gt[5] = g_r(E), g_s(E)
-    double gt[6][3];
-    {
-        double t3[3];
-        for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
-        gt[0][0] = dot3(t3, geo.e1); gt[0][1] = dot3(t3, geo.e2); gt[0][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
-        gt[1][0] = dot3(t3, geo.e1); gt[1][1] = dot3(t3, geo.e2); gt[1][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
-        gt[2][0] = dot3(t3, geo.e1); gt[2][1] = dot3(t3, geo.e2); gt[2][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
-        gt[3][0] = dot3(t3, geo.e1); gt[3][1] = dot3(t3, geo.e2); gt[3][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
-        gt[4][0] = dot3(t3, geo.e1); gt[4][1] = dot3(t3, geo.e2); gt[4][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
-        gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
-    }
-
-    const int qoff = ((Q >> 2) << 4) + (Q & 3);
-    double S[15];         // upper triangle of the 5x5 membrane core, row-major (t <= u)   (wave 0)
-    for (int n = 0; n < 15; n++) S[n] = 0.0;
-    double i00 = 0.0, i01 = 0.0, i11 = 0.0;
-    {
-#pragma clang fp contract(fast)
-        // shape-function derivatives in local axes (MITC4.py:642-657)
-        double dNx[4], dNy[4];
-        for (int i = 0; i < 4; i++) {
-            dNx[i] = ia * dxi[i] + ib * deta[i];
-            dNy[i] = ic * dxi[i] + id * deta[i];
-        }
-        if (w == 0) {
-            for (int i = 0; i < 4; i++) {
-                lds[lds_slot(C_DN + 0, g, i, 0) + qoff] = dNx[i];
-                lds[lds_slot(C_DN + 1, g, i, 0) + qoff] = dNy[i];
-            }
-            // ---- MITC4+ membrane (MITC4.py:351-392): W = T_eps * blend (3x5) ----
-            const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
-            const double r = xi, s = eta;
-            double bl[3][5];
-            bl[0][0] = 0.5 * (1.0 - 2.0 * aA + s + 2.0 * aA * s * s);
-            bl[0][1] = 0.5 * (1.0 - 2.0 * aB - s + 2.0 * aB * s * s);
-            bl[0][2] = aC * (-1.0 + s * s);
-            bl[0][3] = aD * (-1.0 + s * s);
-            bl[0][4] = aE * (-1.0 + s * s);
-            bl[1][0] = aA * (-1.0 + r * r);
-            bl[1][1] = aB * (-1.0 + r * r);
-            bl[1][2] = 0.5 * (1.0 - 2.0 * aC + r + 2.0 * aC * r * r);
-            bl[1][3] = 0.5 * (1.0 - 2.0 * aD - r + 2.0 * aD * r * r);
-            bl[1][4] = aE * (-1.0 + r * r);
-            bl[2][0] = 2.0 * (0.25 * (r + 4.0 * aA * r * s));
-            bl[2][1] = 2.0 * (0.25 * (-r + 4.0 * aB * r * s));
-            bl[2][2] = 2.0 * (0.25 * (s + 4.0 * aC * r * s));
-            bl[2][3] = 2.0 * (0.25 * (-s + 4.0 * aD * r * s));
-            bl[2][4] = 2.0 * (1.0 + aE * r * s);
-            double Te[3][3];
-            if (__builtin_fabs(detJ) < 1e-12) {  // MITC4.py:331-332
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) Te[a][b] = (a == b) ? 1.0 : 0.0;
-            } else {  // MITC4.py:334-347
-                Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
-                Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
-                Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
-            }
-            double W[3][5];
-            for (int a = 0; a < 3; a++)
-                for (int t = 0; t < 5; t++) W[a][t] = Te[a][0] * bl[0][t] + Te[a][1] * bl[1][t] + Te[a][2] * bl[2][t];
-            // S partial = detJ W^T Cm W
-            {
-                double CW[3][5];
-                for (int a = 0; a < 3; a++)
-                    for (int t = 0; t < 5; t++)
-                        CW[a][t] = detJ * (pr->A[a * 3 + 0] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
-                int n = 0;
-                for (int t = 0; t < 5; t++)
-                    for (int u = t; u < 5; u++) S[n++] = W[0][t] * CW[0][u] + W[1][t] * CW[1][u] + W[2][t] * CW[2][u];
-            }
-            // coupling cores U_j = detJ W^T (Bl Bk_j)  (MITC4_composite.py:210-248, nodal-only form)
-            if (any_coupled) {
-                double Bl[3][3];
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? detJ * pr->B[a * 3 + b] : 0.0;
-                for (int j = 0; j < 4; j++) {
-                    double LK[3][2];
-                    for (int a = 0; a < 3; a++) {
-                        LK[a][0] = -(Bl[a][1] * dNy[j] + Bl[a][2] * dNx[j]);
-                        LK[a][1] = Bl[a][0] * dNx[j] + Bl[a][2] * dNy[j];
-                    }
-                    for (int t = 0; t < 5; t++)
-                        for (int c = 0; c < 2; c++) {
-                            const double u = quad_sum(W[0][t] * LK[0][c] + W[1][t] * LK[1][c] + W[2][t] * LK[2][c]);
-                            if (j == g) lds[LDS_U + ((2 * t + c) << 6) + (j << 2) + qoff] = u;
-                        }
-                }
-            }
-            for (int n = 0; n < 15; n++) S[n] = quad_sum(S[n]);
-            st |= __builtin_amdgcn_update_dpp(0, st, 0xB1, 0xF, 0xF, true);
-            st |= __builtin_amdgcn_update_dpp(0, st, 0x4E, 0xF, 0xF, true);
-            if (status && valid && g == 0) status[e] = st;
-        } else {
-            double kbb00, kbb01, kbb11;
-            // ---- MITC4 edge-tied shear (MITC4.py:792-878) ----
-            const auto &xl = geo.xl;
-            double Ax, Bx, Cx, Ay, By, Cy;
-            double ex[4], ey[4];  // edge deltas: 0: 41, 1: 21, 2: 32, 3: 34
-            {
-    #pragma clang fp contract(off)
-                ex[0] = xl[3][0] - xl[0][0]; ey[0] = xl[3][1] - xl[0][1];
-                ex[1] = xl[1][0] - xl[0][0]; ey[1] = xl[1][1] - xl[0][1];
-                ex[2] = xl[2][0] - xl[1][0]; ey[2] = xl[2][1] - xl[1][1];
-                ex[3] = xl[2][0] - xl[3][0]; ey[3] = xl[2][1] - xl[3][1];
-                Ax = ((-xl[0][0] + xl[1][0]) + xl[2][0]) - xl[3][0];
-                Bx = ((xl[0][0] - xl[1][0]) + xl[2][0]) - xl[3][0];
-                Cx = ((-xl[0][0] - xl[1][0]) + xl[2][0]) + xl[3][0];
-                Ay = ((-xl[0][1] + xl[1][1]) + xl[2][1]) - xl[3][1];
-                By = ((xl[0][1] - xl[1][1]) + xl[2][1]) - xl[3][1];
-                Cy = ((-xl[0][1] - xl[1][1]) + xl[2][1]) + xl[3][1];
-            }
-            // Rot = [[sin b, -sin a], [-cos b, cos a]], a = atan2(Ay,Ax), b = pi/2 - atan2(Cx,Cy)
-            const double nA = __builtin_sqrt(Ax * Ax + Ay * Ay), nC = __builtin_sqrt(Cx * Cx + Cy * Cy);
-            const double rnA = recip(nA), rnC = recip(nC);
-            const double sa = divr(Ay, nA, rnA), ca = divr(Ax, nA, rnA), sb = divr(Cy, nC, rnC), cb = divr(Cx, nC, rnC);
-            double r1, r2;
-            {
-    #pragma clang fp contract(off)
-                const double p0 = Cx + xi * Bx, p1 = Cy + xi * By;
-                r1 = __builtin_sqrt(FMA(p1, p1, p0 * p0));
-                const double q0 = Ax + eta * Bx, q1 = Ay + eta * By;
-                r2 = __builtin_sqrt(FMA(q1, q1, q0 * q0));
-            }
-            const double d8 = 8.0 * detJ, rd8 = recip(d8);
-            const double f1 = divr(r1, d8, rd8), f2 = divr(r2, d8, rd8);
-            // node -> (edge of row 0 [eta-edges 21/34], weight), (edge of row 1 [xi-edges 41/32], weight)
-            const double me = 1.0 - eta, pe = 1.0 + eta, mx = 1.0 - xi, px = 1.0 + xi;
-            const int e0[4] = {1, 1, 3, 3}, e1[4] = {0, 2, 2, 0};
-            const double w0[4] = {me, me, pe, pe}, w1[4] = {mx, px, px, mx};
-            const double h0[4] = {-0.5, 0.5, 0.5, -0.5};  // G row of eta-edges: w coefficient
-            const double h1[4] = {-0.5, -0.5, 0.5, 0.5};  // G row of xi-edges: w coefficient
-            // ---- bubble enrichment (MITC4.py:214-222, 880-907): partial Knb, Kbb of this GP ----
-            const double Cb00 = pr->D[0], Cb01 = pr->D[1], Cb02 = pr->D[2];
-            const double Cb10 = pr->D[3], Cb11 = pr->D[4], Cb12 = pr->D[5];
-            const double Cb20 = pr->D[6], Cb21 = pr->D[7], Cb22 = pr->D[8];
-            const double Cs00 = pr->Cs[0], Cs01 = pr->Cs[1], Cs10 = pr->Cs[2], Cs11 = pr->Cs[3];
-            const double Nb = (1.0 - xi * xi) * (1.0 - eta * eta);
-            const double dNbxi = -2.0 * xi * (1.0 - eta * eta), dNbeta = -2.0 * eta * (1.0 - xi * xi);
-            const double bx = ia * dNbxi + ib * dNbeta, by = ic * dNbxi + id * dNbeta;
-            // Bkb = [[0,bx],[-by,0],[-bx,by]] ; Cb*Bkb (3x2)
-            const double q00 = -Cb01 * by - Cb02 * bx, q01 = Cb00 * bx + Cb02 * by;
-            const double q10 = -Cb11 * by - Cb12 * bx, q11 = Cb10 * bx + Cb12 * by;
-            const double q20 = -Cb21 * by - Cb22 * bx, q21 = Cb20 * bx + Cb22 * by;
-            // Bsb = [[0,Nb],[-Nb,0]] ; Cs*Bsb (2x2)
-            const double s00 = -Cs01 * Nb, s01 = Cs00 * Nb, s10 = -Cs11 * Nb, s11 = Cs10 * Nb;
-            for (int i = 0; i < 4; i++) {
-                const double a0 = w0[i] * f1, a1 = w1[i] * f2;
-                const double v0[3] = {a0 * h0[i], a0 * (-ey[e0[i]] * 0.25), a0 * (ex[e0[i]] * 0.25)};
-                const double v1[3] = {a1 * h1[i], a1 * (-ey[e1[i]] * 0.25), a1 * (ex[e1[i]] * 0.25)};
-                // Bk_i columns: thx = (0,-dNy,-dNx) ; thy = (dNx,0,dNy) ; w = 0
-                const double kx0 = -dNy[i] * q10 - dNx[i] * q20, kx1 = -dNy[i] * q11 - dNx[i] * q21;
-                const double ky0 = dNx[i] * q00 + dNy[i] * q20, ky1 = dNx[i] * q01 + dNy[i] * q21;
-                for (int k = 0; k < 3; k++) {
-                    const double b0 = sb * v0[k] - sa * v1[k];
-                    const double b1 = -cb * v0[k] + ca * v1[k];
-                    lds[lds_slot(C_BS + k, g, i, 0) + qoff] = b0;
-                    lds[lds_slot(C_BS + 3 + k, g, i, 0) + qoff] = b1;
-                    double n0 = b0 * s00 + b1 * s10;
-                    double n1 = b0 * s01 + b1 * s11;
-                    if (k == 1) { n0 += kx0; n1 += kx1; }
-                    if (k == 2) { n0 += ky0; n1 += ky1; }
-                    // reduce over the 4 Gauss points of the quad; lane g publishes the rows of node g
-                    n0 = quad_sum(detJ * n0);
-                    n1 = quad_sum(detJ * n1);
-                    if (i == g) {
-                        lds[LDS_KNB + ((2 * k) << 6) + (i << 2) + qoff] = n0;
-                        lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 2) + qoff] = n1;
-                    }
-                }
-            }
-            lds[LDS_DET + Q * 4 + g] = detJ;
-            // Kbb = Bkb^T Cb Bkb + Bsb^T Cs Bsb
-            kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
-            kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
-            kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
-            kbb00 = quad_sum(kbb00); kbb01 = quad_sum(kbb01); kbb11 = quad_sum(kbb11);
-            // Kbb^-1 (MITC4.py:994-998; singular -> no condensation)
-            const double kdet = kbb00 * kbb11 - kbb01 * kbb01;
-            const bool cond_ok = (kdet != 0.0) && (kdet == kdet);
-            const double rkdet = recip(kdet);
-            i00 = cond_ok ? divr(kbb11, kdet, rkdet) : 0.0; i01 = cond_ok ? divr(-kbb01, kdet, rkdet) : 0.0;
-            i11 = cond_ok ? divr(kbb00, kdet, rkdet) : 0.0;
-            if (g == 0) {
-                lds[K2_INV + (0 << 4) + Q] = i00; lds[K2_INV + (1 << 4) + Q] = i01; lds[K2_INV + (2 << 4) + Q] = i11;
-            }
-        }
-    }
-    __syncthreads();
-    if (w == 0) { i00 = lds[K2_INV + (0 << 4) + Q]; i01 = lds[K2_INV + (1 << 4) + Q]; i11 = lds[K2_INV + (2 << 4) + Q]; }
-
-    // ---------------- stage 2: half blocks ----------------
-    const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
-    const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
-    const double kd = pr->k_drill;
-    const double RS[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
-    double SfS[5][5];
-    {
-        int n = 0;
-        for (int t = 0; t < 5; t++)
-            for (int u = t; u < 5; u++) { SfS[t][u] = S[n]; SfS[u][t] = S[n]; n++; }
-    }
-    const auto &gtS = gt;
-
-    for (int round = 0; round < 3; round++) {
-#pragma clang fp contract(fast)
-        int ti, tj;
-        if (round == 0) { ti = g; tj = g; }
-        else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
-        else { ti = g & 1; tj = (g & 1) + 2; }
-        const int oi = (ti << 2) + qoff, oj = (tj << 2) + qoff;
-        const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
-        const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
-
-        double L[3][6];      // rows 3w .. 3w+2 of the local block
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 6; b++) L[a][b] = 0.0;
-        double Yj[5][3];
-        {
-            double wj[6];
-            tying_weights(tj, wj);
-            for (int k = 0; k < 3; k++) {
-                for (int t = 0; t < 4; t++) Yj[t][k] = wj[t] * gtS[t][k];
-                Yj[4][k] = wj[4] * gtS[4][k] + wj[5] * gtS[5][k];
-            }
-        }
-        if (w == 0) {
-            // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j ; coupling: L[uvw_i][th_j] += Y_i^T U_j
-            double Yi[5][3], wi[6];
-            tying_weights(ti, wi);
-            for (int k = 0; k < 3; k++) {
-                for (int t = 0; t < 4; t++) Yi[t][k] = wi[t] * gtS[t][k];
-                Yi[4][k] = wi[4] * gtS[4][k] + wi[5] * gtS[5][k];
-            }
-            for (int b = 0; b < 3; b++) {
-                double SY[5];
-                for (int t = 0; t < 5; t++) {
-                    double v = SfS[t][0] * Yj[0][b];
-                    for (int u = 1; u < 5; u++) v = FMA(SfS[t][u], Yj[u][b], v);
-                    SY[t] = v;
-                }
-                for (int a = 0; a < 3; a++) {
-                    double v = Yi[0][a] * SY[0];
-                    for (int t = 1; t < 5; t++) v = FMA(Yi[t][a], SY[t], v);
-                    L[a][b] = v;
-                }
-            }
-            if (any_coupled) {
-                for (int c = 0; c < 2; c++) {
-                    double Uj[5];
-                    for (int t = 0; t < 5; t++) Uj[t] = lds[LDS_U + ((2 * t + c) << 6) + oj];
-                    for (int a = 0; a < 3; a++) {
-                        double v = L[a][3 + c];
-                        for (int t = 0; t < 5; t++) v = FMA(Yi[t][a], Uj[t], v);
-                        L[a][3 + c] = v;
-                    }
-                }
-            }
-        } else if (any_coupled) {
-            // coupling: L[th_i][uvw_j] += U_i^T Y_j
-            for (int c = 0; c < 2; c++) {
-                double Ui[5];
-                for (int t = 0; t < 5; t++) Ui[t] = lds[LDS_U + ((2 * t + c) << 6) + oi];
-                for (int a = 0; a < 3; a++) {
-                    double w2 = L[c][a];
-                    for (int t = 0; t < 5; t++) w2 = FMA(Ui[t], Yj[t][a], w2);
-                    L[c][a] = w2;
-                }
-            }
-        }
-
-        for (int gg = 0; gg < 4; gg++) {
-            const double wd = lds[LDS_DET + Q * 4 + gg];
-            const int gi = (((ti + gg) & 3) << 2) + qoff, gj = (((tj + gg) & 3) << 2) + qoff;
-            double bsj[2][3];
-            const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + gi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + gi];
-            const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + gj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + gj];
-            for (int c = 0; c < 6; c++) (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + gj];
-            const double wdxi = wd * dxi_, wdyi = wd * dyi_;
-            double CS[2][3];
-            for (int rr = 0; rr < 2; rr++)
-                for (int b = 0; b < 3; b++) CS[rr][b] = FMA(Cs[rr][0], bsj[0][b], Cs[rr][1] * bsj[1][b]);
-            const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
-            const double Ni = 0.25 * (1.0 + sxi * xg) * (1.0 + syi * yg);
-            const double Nj = 0.25 * (1.0 + sxj * xg) * (1.0 + syj * yg);
-            const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
-            if (w == 0) {
-                // shear row w ; drilling rows u, v
-                const double bs00 = wd * lds[(((C_BS + 0) * 4 + gg) << 6) + gi], bs10 = wd * lds[(((C_BS + 3) * 4 + gg) << 6) + gi];
-                for (int b = 0; b < 3; b++) L[2][2 + b] = FMA(bs00, CS[0][b], FMA(bs10, CS[1][b], L[2][2 + b]));
-                const double bd0 = -0.5 * wdyi * kd, bd1 = 0.5 * wdxi * kd;
-                L[0][0] = FMA(bd0, bdj[0], L[0][0]); L[0][1] = FMA(bd0, bdj[1], L[0][1]); L[0][5] = FMA(bd0, bdj[2], L[0][5]);
-                L[1][0] = FMA(bd1, bdj[0], L[1][0]); L[1][1] = FMA(bd1, bdj[1], L[1][1]); L[1][5] = FMA(bd1, bdj[2], L[1][5]);
-            } else {
-                // bending rows thx, thy ; shear rows thx, thy ; drilling row thz   (local rows 0, 1, 2 of this half)
-                double CK[3][2];
-                for (int rr = 0; rr < 3; rr++) {
-                    CK[rr][0] = -FMA(Cb[rr][1], dyj, Cb[rr][2] * dxj);
-                    CK[rr][1] = FMA(Cb[rr][0], dxj, Cb[rr][2] * dyj);
-                }
-                for (int c = 0; c < 2; c++) {
-                    L[0][3 + c] = FMA(-wdyi, CK[1][c], FMA(-wdxi, CK[2][c], L[0][3 + c]));
-                    L[1][3 + c] = FMA(wdxi, CK[0][c], FMA(wdyi, CK[2][c], L[1][3 + c]));
-                }
-                const double bs01 = wd * lds[(((C_BS + 1) * 4 + gg) << 6) + gi], bs02 = wd * lds[(((C_BS + 2) * 4 + gg) << 6) + gi];
-                const double bs11 = wd * lds[(((C_BS + 4) * 4 + gg) << 6) + gi], bs12 = wd * lds[(((C_BS + 5) * 4 + gg) << 6) + gi];
-                for (int b = 0; b < 3; b++) {
-                    L[0][2 + b] = FMA(bs01, CS[0][b], FMA(bs11, CS[1][b], L[0][2 + b]));
-                    L[1][2 + b] = FMA(bs02, CS[0][b], FMA(bs12, CS[1][b], L[1][2 + b]));
-                }
-                const double bd2 = -Ni * (wd * kd);
-                L[2][0] = FMA(bd2, bdj[0], L[2][0]); L[2][1] = FMA(bd2, bdj[1], L[2][1]); L[2][5] = FMA(bd2, bdj[2], L[2][5]);
-            }
-        }
-        // bubble condensation: L[w,thx,thy][w,thx,thy] -= (Knb_i Kbb^-1) Knb_j^T
-        {
-            double kj[3][2];
-            for (int k = 0; k < 3; k++) {
-                kj[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oj]; kj[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oj];
-            }
-            if (w == 0) {
-                const double k0 = lds[LDS_KNB + (0 << 6) + oi], k1 = lds[LDS_KNB + (1 << 6) + oi];
-                const double h0 = k0 * i00 + k1 * i01, h1 = k0 * i01 + k1 * i11;
-                for (int b = 0; b < 3; b++) L[2][2 + b] = FMA(-h0, kj[b][0], FMA(-h1, kj[b][1], L[2][2 + b]));
-            } else {
-                for (int a = 1; a < 3; a++) {
-                    const double k0 = lds[LDS_KNB + ((2 * a) << 6) + oi], k1 = lds[LDS_KNB + ((2 * a + 1) << 6) + oi];
-                    const double h0 = k0 * i00 + k1 * i01, h1 = k0 * i01 + k1 * i11;
-                    for (int b = 0; b < 3; b++) L[a - 1][2 + b] = FMA(-h0, kj[b][0], FMA(-h1, kj[b][1], L[a - 1][2 + b]));
-                }
-            }
-        }
-        // rotation of this half to global axes: G[3w + p][.] = R^T L[.] R, 3x3 block-wise
-        double G[3][6];
-        for (int bb = 0; bb < 2; bb++) {
-            double Y[3][3];
-            for (int p = 0; p < 3; p++)
-                for (int q = 0; q < 3; q++)
-                    Y[p][q] = FMA(RS[2][p], L[2][3 * bb + q], FMA(RS[1][p], L[1][3 * bb + q], RS[0][p] * L[0][3 * bb + q]));
-            for (int p = 0; p < 3; p++)
-                for (int q = 0; q < 3; q++)
-                    G[p][3 * bb + q] = FMA(Y[p][2], RS[2][q], FMA(Y[p][1], RS[1][q], Y[p][0] * RS[0][q]));
-        }
-        if (round == 0) {   // diagonal block: K = 0.5 (K + K^T); the off-diagonal 3x3 lives in the other wave
-            // (static register indices in both branches: a runtime column offset would put G in scratch)
-            if (w == 0) {
-                for (int a = 0; a < 3; a++)
-                    for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (G[a][b] + G[b][a]); G[a][b] = m; G[b][a] = m; }
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) lds[LDS_STG + ((a * 3 + b) << 7) + tid] = G[a][3 + b];
-            } else {
-                for (int a = 0; a < 3; a++)
-                    for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (G[a][3 + b] + G[b][3 + a]); G[a][3 + b] = m; G[b][3 + a] = m; }
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) lds[LDS_STG + ((a * 3 + b) << 7) + tid] = G[a][b];
-            }
-            __syncthreads();
-            double X2[3][3];      // the other half's off-diagonal 3x3, transposed
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) X2[a][b] = lds[LDS_STG + ((b * 3 + a) << 7) + (tid ^ 64)];
-            if (w == 0) {
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) G[a][3 + b] = 0.5 * (G[a][3 + b] + X2[a][b]);
-            } else {
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) G[a][b] = 0.5 * (X2[a][b] + G[a][b]);
-            }
-            __syncthreads();
-        }
-        // ---- FS_LAYOUT_SYMBLK_T16 output through the shared staging area (see mitc4_k_kernel): whole lines;
-        // storing each wave's 144-byte halves on its own (no barriers) was measured 1.4x SLOWER
-        const int npass = (round == 2) ? 1 : 2;
-        for (int h = 0; h < npass; h++) {
-            const bool mine = (round == 2) ? (g < 2) : ((lane >> 5) == h);
-            const int slot = (round == 2) ? ((g << 4) + Q) : ((g << 3) + (Q & 7));
-            if (mine) {
-                double2 *sp = reinterpret_cast<double2 *>(lds + LDS_STG + slot * STG_SLOT + 18 * w);
-                for (int t = 0; t < 9; t++) sp[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
-            }
-            __syncthreads();
-            double2 *gp = reinterpret_cast<double2 *>(out + ((int64_t)blockIdx.x * 160 + round * 64 + h * 32) * 36);
-            const double2 *sp2 = reinterpret_cast<const double2 *>(lds + LDS_STG);
-            for (int i = 0; i < 5; i++) {
-                const int c = i * 128 + tid;            // 16-byte chunk of the pass's 32 blocks
-                if (c < 576) {
-                    const int bl = (c * 3641) >> 16;    // c / 18
-                    gp[c] = sp2[c + bl];                // staging slots are 19 chunks apart
-                }
-            }
-            __syncthreads();
         }
     }
 }
@@ -2784,12 +2331,6 @@ inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
     return (unsigned)g;
 }
 
-// experiment switch: FEMSHELL_K2=1 selects the two-wave stiffness kernel for the tiled layout
-bool use_k2() {
-    static const bool v = [] { const char *e = getenv("FEMSHELL_K2"); return e && e[0] == '1'; }();
-    return v;
-}
-
 }  // namespace
 
 int fs_fail_(int code, const char *what, int hip_error) { return fail(code, what, (hipError_t)hip_error); }
@@ -2823,8 +2364,7 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
         if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_quad_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_quad_batch: fe is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
-        if (tiled && use_k2()) hipLaunchKernelGGL(mitc4_k2_kernel, dim3(grid), dim3(128), 0, s, xyz, prop_id, props, E, KTe, status);
-        else if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
         else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
         FS_LAUNCH_CHECK("mitc4_k_kernel");
         if (tiled)
@@ -2838,8 +2378,7 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_quad_batch: Ke is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
-        if (tiled && use_k2()) hipLaunchKernelGGL(mitc4_k2_kernel, dim3(grid), dim3(128), 0, s, xyz, prop_id, props, E, Ke, status);
-        else if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
+        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
         else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
         FS_LAUNCH_CHECK("mitc4_k_kernel");
     }
