@@ -2125,6 +2125,48 @@ __global__ __launch_bounds__(256) void csr_numeric_desc2_kernel(const double *__
     *reinterpret_cast<double2 *>(data + dsc.dst + (int64_t)k * dsc.stride + l) = v;
 }
 
+// d = 3 (solids): one thread per (block, row k): three entries per thread instead of one -- a third of the threads,
+// descriptor reads and address arithmetic of csr_numeric_desc_kernel<3>; same sums in the same element order.
+__global__ __launch_bounds__(256) void csr_numeric_desc3_row_kernel(const double *__restrict__ vals,
+                                                                    const fs_blk_desc *__restrict__ desc,
+                                                                    const int64_t *__restrict__ contrib,
+                                                                    int64_t nblk, double *__restrict__ data) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * 3) return;
+    const int64_t b = t / 3;
+    const int k = (int)(t - b * 3);
+    const fs_blk_desc dsc = desc[b];
+    double v0, v1, v2;
+    if (dsc.cnt <= 4) {
+        double x[4][3];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int64_t cc = dsc.c[c];
+            const double *src = vals + (cc >> 1) * 9;
+            const bool tr = cc & 1;
+            x[c][0] = (c < dsc.cnt) ? src[tr ? k : 3 * k] : 0.0;
+            x[c][1] = (c < dsc.cnt) ? src[tr ? 3 + k : 3 * k + 1] : 0.0;
+            x[c][2] = (c < dsc.cnt) ? src[tr ? 6 + k : 3 * k + 2] : 0.0;
+        }
+        v0 = ((x[0][0] + x[1][0]) + x[2][0]) + x[3][0];   // element order == reference insertion order
+        v1 = ((x[0][1] + x[1][1]) + x[2][1]) + x[3][1];
+        v2 = ((x[0][2] + x[1][2]) + x[2][2]) + x[3][2];
+    } else {
+        v0 = v1 = v2 = 0.0;
+        const int64_t lo = dsc.c[0];
+        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
+            const int64_t cc = contrib[q];
+            const double *src = vals + (cc >> 1) * 9;
+            const bool tr = cc & 1;
+            v0 = v0 + src[tr ? k : 3 * k];
+            v1 = v1 + src[tr ? 3 + k : 3 * k + 1];
+            v2 = v2 + src[tr ? 6 + k : 3 * k + 2];
+        }
+    }
+    double *dst = data + dsc.dst + (int64_t)k * dsc.stride;
+    dst[0] = v0; dst[1] = v1; dst[2] = v2;
+}
+
 // LDS-staged descriptor assembly (d = 6): workgroup = 14 node-pair blocks x 18 lanes.
 //   * the 14 descriptors are fetched once per workgroup (42 lanes x 16 B) instead of by every lane;
 //   * every contribution is fetched as ONE coalesced 16-byte load per lane (the 288-byte source
@@ -2655,7 +2697,7 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
         hipLaunchKernelGGL(csr_numeric_desc6_lds_kernel, dim3(8 * grid_for(nblk, 14 * 8, INT32_MAX / 8)), dim3(256), 0, s,
                            vals, desc, contrib, nblk, data);
     } else if (d == 3) {
-        hipLaunchKernelGGL(csr_numeric_desc_kernel<3>, dim3(grid_for(nblk * 9, 256, INT32_MAX)), dim3(256), 0, s,
+        hipLaunchKernelGGL(csr_numeric_desc3_row_kernel, dim3(grid_for(nblk * 3, 256, INT32_MAX)), dim3(256), 0, s,
                            vals, desc, contrib, nblk, data);
     } else {
         return fail(FS_EINVAL, "fs_csr_numeric_desc: d must be 3 or 6");
