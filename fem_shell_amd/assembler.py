@@ -116,6 +116,7 @@ class MeshAssembler:
             elem_ids = np.arange(conn.shape[0], dtype=np.int64)
             thickness = None
             set_lookup = None
+            self._node_ids = None          # node id == node index
             if getattr(mesh, "set_id", None) is not None:
                 set_lookup = (mesh.set_id, mesh.set_names)
             return coords, conn, elem_ids, thickness, set_lookup
@@ -126,9 +127,11 @@ class MeshAssembler:
         coords = np.full((mesh.node_count, 3), np.nan)
         elem_ids = np.empty(E, dtype=np.int64)
         thickness = np.full(E, np.nan)
+        self._node_ids = np.full(mesh.node_count, -1, dtype=np.int64)      # node index -> node id
         for i, el in enumerate(mesh.elements):
             idx = [n2i[n] for n in el.node_ids]
             conn[i, :len(idx)] = idx
+            self._node_ids[idx] = list(el.node_ids)
             coords[idx] = np.asarray(el.node_coords, dtype=float)
             elem_ids[i] = el.id
             if getattr(el, "thickness", None) is not None:
@@ -167,7 +170,8 @@ class MeshAssembler:
                         r = add(laminate_row(p.laminate, nonlinear) if isinstance(p, CompositeShellProperty)
                                 else iso_row(p.material, p.thickness, kappa, nonlinear), p)
                         for el in self.mesh.element_sets[name].elements:
-                            pid[pos[int(el.id)]] = r
+                            if int(el.id) in pos:          # skipped (unsupported) elements have no row
+                                pid[pos[int(el.id)]] = r
         rest = pid < 0
         if rest.any():
             if m.get("laminate") is not None:
@@ -200,6 +204,23 @@ class MeshAssembler:
         self._family = fam
         self.dofs_per_node, self.spatial_dim = self._FAMILY_PROPERTIES[fam]
         coords, conn, elem_ids, thickness, set_lookup = self._extract()
+        # Elements whose node count the family's factory does not know are skipped, like the reference
+        # (ElementFactory returns False on the KeyError and the loop `continue`s: elements.py:258-259,
+        # core/assembler.py:163-164).  PYRAMID13 is known to the reference but not built here: loud error.
+        self._mesh_pos = None              # position in mesh.elements of every kept element (None: all kept)
+        counts = (conn >= 0).sum(axis=1)
+        known = (3, 4) if fam == ElementFamily.SHELL else (4, 5, 6, 8, 10, 15, 20)
+        if fam == ElementFamily.SOLID and (counts == 13).any():
+            raise NotImplementedError("SOLID elements with 13 nodes (PYRAMID13) are not on the GPU path")
+        keep = np.isin(counts, known)
+        if not keep.all():
+            self._mesh_pos = np.flatnonzero(keep)
+            conn, elem_ids = conn[keep], elem_ids[keep]
+            width = int((conn >= 0).sum(axis=1).max()) if conn.shape[0] else 0
+            conn = np.ascontiguousarray(conn[:, :width])
+            thickness = None if thickness is None else thickness[keep]
+            if set_lookup is not None:
+                set_lookup = (set_lookup[0][keep], set_lookup[1])
         E = conn.shape[0]
         self._coords, self._conn, self._elem_ids = coords, conn, elem_ids
         self._elem_pos = {int(e): i for i, e in enumerate(elem_ids)} if E < 2_000_000 else _RangePos(E)
@@ -337,12 +358,15 @@ class MeshAssembler:
 
     @property
     def _node_dofs_map(self):
+        """node ID -> its DOFs `node_index * dofs_per_node + k` (core/assembler.py:166-182), for the nodes some
+        element touches."""
         d = self.dofs_per_node
         used = np.unique(self._conn[self._conn >= 0])
-        return {int(n): tuple(range(int(n) * d, int(n) * d + d)) for n in used}
+        ids = used if self._node_ids is None else self._node_ids[used]
+        return {int(i): tuple(range(int(n) * d, int(n) * d + d)) for i, n in zip(ids, used)}
 
     def _make_element(self, pos):
-        view = self.mesh.elements[pos]
+        view = self.mesh.elements[pos if self._mesh_pos is None else int(self._mesh_pos[pos])]
         prop = self._prop_objects[int(self._prop_id[pos])]
         extra = {k: v for k, v in self.model.items()
                  if k not in ("properties", "material", "thickness", "laminate", "element_family")}

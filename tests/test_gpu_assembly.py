@@ -278,3 +278,58 @@ def test_assembled_solids(case, oracle):
                                                           want_K=False, body=body)["f"][0]).max() < 1e-9
     with pytest.raises(ValueError):
         asm.assemble_geometric_stiffness()
+
+
+def test_reference_mesh_protocol_duck_typed():
+    """The mesh protocol the reference assembler touches (core/assembler.py:72,107,113-119,160-187,220): a mesh of
+    plain objects with arbitrary node ids / element ids, `node_id_to_index`, `element_sets[name].elements`, one
+    element the SHELL factory does not know (5 nodes: skipped like the reference) and the deprecated per-element
+    thickness -- against the same mesh given as ArrayMesh."""
+    import warnings
+    from types import SimpleNamespace
+    from fem_shell_amd.assembler import MeshAssembler
+    base = meshes.cylindrical_patch(25.0, 25.0, 40.0, 5, 4)
+    coords, conn = base.coords, meshes.mixed_conn(5, 4)
+    nid = 100 + 3 * np.arange(coords.shape[0])                       # node ids != node indices
+    perm = np.random.default_rng(1).permutation(coords.shape[0])     # index of node id k is perm-defined
+    index_of = {int(nid[k]): int(perm[k]) for k in range(coords.shape[0])}
+    coords_by_index = np.empty_like(coords)
+    coords_by_index[perm] = coords
+    elements = []
+    for e, row in enumerate(conn):
+        nodes = [int(k) for k in row if k >= 0]
+        elements.append(SimpleNamespace(id=1000 + 7 * e, node_ids=tuple(int(nid[k]) for k in nodes), node_count=len(nodes),
+                                        node_coords=coords[nodes], thickness=None))
+    odd = SimpleNamespace(id=5, node_ids=tuple(int(nid[k]) for k in range(5)), node_count=5, node_coords=coords[:5],
+                          thickness=None)                             # no 5-node shell: ElementFactory -> False
+    elements.insert(3, odd)
+    sets = {"a": SimpleNamespace(elements=elements[:10]), "b": SimpleNamespace(elements=elements[10:])}
+    mesh = SimpleNamespace(elements=elements, node_id_to_index=index_of, node_count=coords.shape[0], element_sets=sets)
+    props = util.standard_props()
+    model = {"elements": {"element_family": ElementFamily.SHELL, "properties": {"a": props[0], "b": props[4]}}}
+    asm = MeshAssembler(mesh, model)
+    # the same mesh as arrays: node index = perm, elements without the odd one
+    conn_idx = np.where(conn >= 0, perm[np.maximum(conn, 0)], -1)
+    set_id = np.array([0 if k < 9 else 1 for k in range(conn.shape[0])], dtype=np.int32)   # "a" lost the odd element
+    ref = MeshAssembler(meshes.ArrayMesh(coords_by_index, conn_idx, set_id, ["a", "b"]), model)
+    K, Kr = asm.assemble_stiffness_matrix(), ref.assemble_stiffness_matrix()
+    assert np.array_equal(K.indptr.cpu().numpy(), Kr.indptr.cpu().numpy())
+    assert np.array_equal(K.indices.cpu().numpy(), Kr.indices.cpu().numpy())
+    assert bool((K.data == Kr.data).all()) and bool((asm.assemble_mass_matrix().data == ref.assemble_mass_matrix().data).all())
+    assert len(asm._element_map) == conn.shape[0] and 5 not in asm._element_map       # odd element skipped
+    assert sorted(asm._element_map.keys())[0] == 1000 and asm._is_mixed_mesh
+    el = asm._element_map[1000 + 7 * 4]
+    assert el.node_ids == list(elements[5].node_ids) or tuple(el.node_ids) == elements[5].node_ids
+    nd = asm._node_dofs_map
+    k = 17
+    assert nd[int(nid[k])] == tuple(range(int(perm[k]) * 6, int(perm[k]) * 6 + 6))     # keyed by node ID
+    assert asm.dofs_count == coords.shape[0] * 6
+    # deprecated per-element thickness (core/assembler.py:144-158)
+    for el_ in elements:
+        el_.thickness = 0.02
+    mat = fsa.IsotropicMaterial("m", 2.1e11, 0.3, 7800.0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        asm2 = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.5}})
+    assert any(issubclass(x.category, DeprecationWarning) for x in w)
+    assert float(asm2._prop_table["h"][0]) == 0.02
