@@ -241,13 +241,16 @@ def main():
                           "properties": {names[i]: lams[i] for i in range(16)}}}
     if world > 1:
         from fem_shell_amd.dist import DistributedAssembler
-        asm = DistributedAssembler(mesh, model, strip=(rank, world, STRIP_NX, STRIP_NY))
+        asm = DistributedAssembler(mesh, model, strip=(rank, world, STRIP_NX, STRIP_NY),
+                                   overlap=os.environ.get("FEMSHELL_DIST_OVERLAP", "1") != "0")
     else:
         asm = MeshAssembler(mesh, model)
     E = mesh.element_count
     coupled_frac = float(np.mean((asm._prop_table["flags"][asm._prop_id] & 1) != 0))
 
     def barrier():
+        if world > 1:
+            asm.finish()               # the last step's interface exchange (side stream) joins here
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

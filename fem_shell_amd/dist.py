@@ -177,7 +177,10 @@ class DistributedAssembler:
     `mesh` is the rank's local ArrayMesh; `l2g` its global node ids.  For the bench's x-strip
     partition pass strip=(rank, world, nx, ny) and l2g is derived."""
 
-    def __init__(self, mesh, model, l2g=None, strip=None):
+    def __init__(self, mesh, model, l2g=None, strip=None, overlap=False):
+        """overlap=True runs pack -> send/recv -> add on a side stream: the caller's stream goes straight on
+        (e.g. to the next element kernel, which does not touch the CSR values) and joins again at the next
+        assemble_* call or at finish().  The returned matrix is complete only after finish()."""
         from . import _lib, batch
         from .assembler import MeshAssembler
         if l2g is None:
@@ -204,6 +207,9 @@ class DistributedAssembler:
         self._lib, self._libmod = _lib.load(), _lib
         self._prop_table, self._prop_id = self.local._prop_table, self.local._prop_id
         self.owned_rows = np.repeat(self.dplan.owned, 6)
+        self.overlap = bool(overlap)
+        self._comm = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._pending = None
 
     def refresh_element_matrices(self, **kw):
         return self.local.refresh_element_matrices(**kw)
@@ -211,7 +217,25 @@ class DistributedAssembler:
     def check_status(self):
         return self.local.check_status()
 
+    def finish(self):
+        """Make the current stream wait for an exchange still running on the side stream."""
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
+
     def _exchange(self, A):
+        if not self.overlap:
+            return self._exchange_on_current_stream(A)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(ready)
+            self._exchange_on_current_stream(A)
+            self._pending = torch.cuda.Event()
+            self._pending.record(self._comm)
+        return A
+
+    def _exchange_on_current_stream(self, A):
         L, lib = self._libmod, self._lib
         s = L.stream_ptr()
         for q, idx in self._send.items():
@@ -237,7 +261,9 @@ class DistributedAssembler:
     def assemble_stiffness_matrix(self, recompute=False):
         """Owned rows of the returned CSR (see `owned_rows`) hold the globally assembled values;
         column j of the local matrix is global DOF 6*nodes_g[j//6] + j%6."""
+        self.finish()
         return self._exchange(self.local.assemble_stiffness_matrix(recompute=recompute))
 
     def assemble_mass_matrix(self, recompute=False):
+        self.finish()
         return self._exchange(self.local.assemble_mass_matrix(recompute=recompute))

@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, nx, ny, q):
+def _worker(rank, world, port, nx, ny, q, overlap=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -32,8 +32,12 @@ def _worker(rank, world, port, nx, ny, q):
         loc = meshes.jittered_plate(nx, ny, n_sets=8, x_offset_cells=rank * nx)
         # the strip must use the GLOBAL band of each element
         loc.set_id = g.set_id.reshape(ny, nx * world)[:, rank * nx:(rank + 1) * nx].reshape(-1).copy()
-        da = DistributedAssembler(loc, model, strip=(rank, world, nx, ny))
+        da = DistributedAssembler(loc, model, strip=(rank, world, nx, ny), overlap=overlap)
         A = da.assemble_stiffness_matrix(recompute=True)
+        if overlap:       # a second step while the first exchange may still be in flight, then join
+            da.refresh_element_matrices(want_K=True, want_M=False, check=False)
+            A = da.assemble_stiffness_matrix(recompute=False)
+            da.finish()
         ip, ix, data = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy()
         X = da.dplan.nodes_g
         worst = 0.0
@@ -51,11 +55,12 @@ def _worker(rank, world, port, nx, ny, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_one_gpu(overlap):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 9, 7, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 9, 7, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
