@@ -1,0 +1,134 @@
+/*
+ * Plain-C host for libfemshell_hip.so: proves that include/femshell_hip.h is a C header and that the hot
+ * path (MITC4+ element matrices -> device symbolic phase -> CSR assembly -> lumped mass) runs from a
+ * process that contains neither Python nor torch -- the way a cgo / JNI / ctypes binding would drive it.
+ * Test infrastructure (tests/test_gpu_cabi.py writes the input file and checks the output file against the
+ * oracle); built by fem_shell_amd/csrc/Makefile with gcc, linked against libamdhip64 for hipMalloc/hipMemcpy.
+ *
+ *   usage: cabi_driver in.bin out.bin
+ *   in :  int64 E, n_nodes, n_props; f64 xyz[E][4][3]; i32 prop_id[E]; fs_shell_prop props[n_props];
+ *         i64 conn[E][4]
+ *   out:  int64 nblk, nnz, ndof; i64 indptr[ndof+1]; i32 indices[nnz]; f64 K[nnz]; f64 M[nnz];
+ *         f64 lumped[ndof]; i32 status[E]
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "femshell_hip.h"
+
+#define HIPCHK(x)                                                                          \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_));     \
+            return 2;                                                                      \
+        }                                                                                  \
+    } while (0)
+#define FSCHK(x)                                                                           \
+    do {                                                                                   \
+        int r_ = (x);                                                                      \
+        if (r_ != FS_OK) {                                                                 \
+            fprintf(stderr, "%s:%d: %d %s\n", __FILE__, __LINE__, r_, fs_last_error());    \
+            return 3;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+static void *rd(FILE *f, size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (!p || fread(p, 1, n, f) != n) {
+        fprintf(stderr, "short read (%zu bytes)\n", n);
+        exit(4);
+    }
+    return p;
+}
+
+static int to_dev(void **d, const void *h, size_t n) {
+    HIPCHK(hipMalloc(d, n ? n : 1));
+    if (h) HIPCHK(hipMemcpy(*d, h, n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int wr_dev(FILE *f, const void *d, size_t n) {
+    void *h = malloc(n ? n : 1);
+    HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    fwrite(h, 1, n, f);
+    free(h);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc != 3) return 1;
+    char name[128];
+    int cus = 0;
+    FSCHK(fs_device_info(0, name, (int)sizeof name, &cus));
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) return 1;
+    int64_t hdr[3];
+    if (fread(hdr, 8, 3, in) != 3) return 4;
+    const int64_t E = hdr[0], N = hdr[1], P = hdr[2], ndof = 6 * N;
+    if (sizeof(fs_shell_prop) != 368 || sizeof(fs_blk_desc) != 48) return 5;
+    double *xyz = rd(in, (size_t)E * 96);
+    int32_t *pid = rd(in, (size_t)E * 4);
+    fs_shell_prop *props = rd(in, (size_t)P * sizeof(fs_shell_prop));
+    int64_t *conn = rd(in, (size_t)E * 32);
+    fclose(in);
+
+    hipStream_t s;
+    HIPCHK(hipStreamCreate(&s));
+    void *d_xyz, *d_pid, *d_props, *d_conn, *d_Ke, *d_Me, *d_st;
+    const size_t tile_bytes = (size_t)((E + 15) / 16) * 160 * 36 * 8;
+    if (to_dev(&d_xyz, xyz, (size_t)E * 96) || to_dev(&d_pid, pid, (size_t)E * 4) ||
+        to_dev(&d_props, props, (size_t)P * sizeof(fs_shell_prop)) || to_dev(&d_conn, conn, (size_t)E * 32) ||
+        to_dev(&d_Ke, NULL, tile_bytes) || to_dev(&d_Me, NULL, tile_bytes) || to_dev(&d_st, NULL, (size_t)E * 4))
+        return 2;
+    HIPCHK(hipMemsetAsync(d_st, 0, (size_t)E * 4, s));
+
+    /* element matrices (the body of MeshAssembler._precompute_elements) */
+    FSCHK(fs_shell_quad_batch(d_xyz, d_pid, d_props, (int32_t)P, NULL, E, FS_WANT_K | FS_WANT_M, FS_LAYOUT_SYMBLK_T16,
+                              d_Ke, d_Me, NULL, NULL, d_st, s));
+
+    /* symbolic phase (_compute_sparsity_pattern) */
+    fs_symbolic *h = NULL;
+    int64_t nblk = 0, ncontrib = 0;
+    FSCHK(fs_csr_symbolic_begin(d_conn, NULL, NULL, E, 4, FS_LAYOUT_SYMBLK_T16, E * 16, N, NULL, 0, &h, &nblk, &ncontrib, s));
+    const int64_t nnz = nblk * 36;
+    void *d_nbr_ptr, *d_nbr, *d_blk_row, *d_blk_ptr, *d_contrib, *d_desc, *d_indptr, *d_indices, *d_K, *d_M, *d_lump;
+    if (to_dev(&d_nbr_ptr, NULL, (size_t)(N + 1) * 8) || to_dev(&d_nbr, NULL, (size_t)nblk * 4) ||
+        to_dev(&d_blk_row, NULL, (size_t)nblk * 4) || to_dev(&d_blk_ptr, NULL, (size_t)(nblk + 1) * 8) ||
+        to_dev(&d_contrib, NULL, (size_t)ncontrib * 8) || to_dev(&d_desc, NULL, (size_t)nblk * sizeof(fs_blk_desc)) ||
+        to_dev(&d_indptr, NULL, (size_t)(ndof + 1) * 8) || to_dev(&d_indices, NULL, (size_t)nnz * 4) ||
+        to_dev(&d_K, NULL, (size_t)nnz * 8) || to_dev(&d_M, NULL, (size_t)nnz * 8) || to_dev(&d_lump, NULL, (size_t)ndof * 8))
+        return 2;
+    FSCHK(fs_csr_symbolic_finish(h, 6, d_nbr_ptr, d_nbr, d_blk_row, d_blk_ptr, d_contrib, d_desc, s));
+    FSCHK(fs_csr_pattern_blk(d_nbr_ptr, d_blk_row, d_nbr, N, nblk, 6, d_indptr, d_indices, s));
+
+    /* numeric phase (assemble_stiffness_matrix / assemble_mass_matrix) + lumping */
+    FSCHK(fs_csr_numeric_desc(d_Ke, d_desc, d_contrib, nblk, 6, d_K, s));
+    FSCHK(fs_csr_numeric_desc(d_Me, d_desc, d_contrib, nblk, 6, d_M, s));
+    FSCHK(fs_csr_row_sums(d_indptr, d_M, ndof, d_lump, s));
+    HIPCHK(hipStreamSynchronize(s));
+
+    /* error behaviour: bad arguments come back as codes + message, never as a crash */
+    if (fs_shell_quad_batch(NULL, d_pid, d_props, (int32_t)P, NULL, E, FS_WANT_K, FS_LAYOUT_SYMBLK, d_Ke, NULL, NULL,
+                            NULL, NULL, s) != FS_EINVAL || !strstr(fs_last_error(), "null input"))
+        return 6;
+    if (fs_shell_quad_batch(d_xyz, d_pid, d_props, (int32_t)P, NULL, E, FS_WANT_K, FS_LAYOUT_DENSE, d_Ke, NULL, NULL,
+                            NULL, NULL, s) != FS_EINVAL)
+        return 6;
+
+    FILE *out = fopen(argv[2], "wb");
+    if (!out) return 1;
+    int64_t oh[3] = {nblk, nnz, ndof};
+    fwrite(oh, 8, 3, out);
+    if (wr_dev(out, d_indptr, (size_t)(ndof + 1) * 8) || wr_dev(out, d_indices, (size_t)nnz * 4) ||
+        wr_dev(out, d_K, (size_t)nnz * 8) || wr_dev(out, d_M, (size_t)nnz * 8) || wr_dev(out, d_lump, (size_t)ndof * 8) ||
+        wr_dev(out, d_st, (size_t)E * 4))
+        return 2;
+    fclose(out);
+    printf("cabi_driver ok: %s (%d CUs), E=%lld nblk=%lld nnz=%lld\n", name, cus, (long long)E, (long long)nblk,
+           (long long)nnz);
+    return 0;
+}

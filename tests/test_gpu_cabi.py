@@ -1,0 +1,53 @@
+"""GPU: the C ABI driven by a plain-C host (tests/cabi/driver.c: no Python, no torch in that process; gcc-built
+against include/femshell_hip.h) -- element matrices, device symbolic phase, CSR assembly of K and M, lumped mass --
+checked against the oracle.  This is the calling sequence a cgo / JNI / ctypes binding of the reference would use
+(INTEGRATION.md)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fem_shell_amd import meshes
+from fem_shell_amd.properties import build_prop_table
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DRIVER = os.path.join(HERE, "cabi", "cabi_driver")
+
+
+def test_c_host_drives_the_whole_path(tmp_path):
+    assert os.path.exists(DRIVER), "tests/cabi/cabi_driver missing: run __graft_entry__.build()"
+    mesh = meshes.jittered_plate(37, 23, n_sets=8)                    # 851 elements: ragged last tile
+    props = build_prop_table(util.standard_props()[:8])
+    E, N = mesh.element_count, mesh.node_count
+    xyz = np.ascontiguousarray(mesh.coords[mesh.conn], dtype=np.float64)
+    pid = np.ascontiguousarray(mesh.set_id, dtype=np.int32)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        np.array([E, N, props.shape[0]], dtype=np.int64).tofile(f)
+        xyz.tofile(f); pid.tofile(f); f.write(props.tobytes()); mesh.conn.astype(np.int64).tofile(f)
+    r = subprocess.run([DRIVER, str(fin), str(fout)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "cabi_driver ok" in r.stdout
+    with open(fout, "rb") as f:
+        nblk, nnz, ndof = (int(v) for v in np.fromfile(f, np.int64, 3))
+        indptr = np.fromfile(f, np.int64, ndof + 1)
+        indices = np.fromfile(f, np.int32, nnz)
+        K = np.fromfile(f, np.float64, nnz)
+        M = np.fromfile(f, np.float64, nnz)
+        lumped = np.fromfile(f, np.float64, ndof)
+        status = np.fromfile(f, np.int32, E)
+    assert ndof == 6 * N and nnz == 36 * nblk and not status.any()
+    Ke, st = O.mitc4_K_batch(xyz, pid, props)
+    Me, _ = O.mitc4_M_batch(xyz, pid, props)
+    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(E, -1)
+    ip, ix, kd = O.csr_assemble(dofs, ndof, Ke)
+    _, _, md = O.csr_assemble(dofs, ndof, Me)
+    assert np.array_equal(indptr, ip) and np.array_equal(indices, ix)          # pattern: bit for bit
+    assert np.abs(K - kd).max() <= 1e-12 * np.abs(kd).max()
+    assert np.abs(M - md).max() <= 1e-13 * np.abs(md).max()
+    rs = np.add.reduceat(md, ip[:-1])
+    assert np.abs(lumped - rs).max() <= 1e-13 * np.abs(rs).max()

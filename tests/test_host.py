@@ -27,6 +27,15 @@ def test_header_symbols_exported():
     assert ctypes.sizeof(ctypes.c_double) * 45 + 8 == fsa.properties.PROP_DTYPE.itemsize == 368
 
 
+def test_header_is_plain_c():
+    """include/femshell_hip.h must be usable from C (cgo / JNI / ctypes bindings): C99, pedantic, no C++."""
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "femshell_hip.h")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_laminate_rows_bitwise():
     g = golden("laminate")
     m = fsa.OrthotropicMaterial("T300/5208", **T300)
