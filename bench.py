@@ -165,6 +165,48 @@ def c2_leg(torch, steps=20):
     return out
 
 
+def c5_full_leg(torch, steps=5):
+    """configs[4]'s shell plate at its FULL size on ONE GPU: 3200 x 3125 = 10 M MITC4+ laminate elements, 60 M dofs,
+    nnz 3.24e9 (about 110 GB of device memory).  Step = element K kernel + CSR assembly, as in `value`; skipped
+    when less than 140 GB are free."""
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    if free < 140e9:
+        return {"skipped": f"{free / 1e9:.0f} GB of device memory free"}
+    lams = c5_laminates()
+    mesh = meshes.jittered_plate(3200, 3125, cell=1e-3, seed=11, n_sets=16)
+    t0 = time.perf_counter()
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
+                                            "properties": {mesh.set_names[i]: lams[i] for i in range(16)}}})
+    torch.cuda.synchronize()
+    setup = time.perf_counter() - t0
+    asm.assemble_stiffness_matrix(recompute=True)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    k_ms = a_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev[0].record()
+        asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
+        ev[1].record()
+        K = asm.assemble_stiffness_matrix(recompute=False)
+        ev[2].record()
+        torch.cuda.synchronize()
+        k_ms += ev[0].elapsed_time(ev[1]) / steps
+        a_ms += ev[1].elapsed_time(ev[2]) / steps
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    E = mesh.element_count
+    out = {"elements": E, "nnz": int(K.nnz), "element_kernel_ms": k_ms, "assembly_ms": a_ms, "ms_per_step_wall": wall,
+           "elements_per_s": E / (wall * 1e-3), "assembler_setup_s": setup,
+           "device_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del asm, K
+    torch.cuda.empty_cache()
+    return out
+
+
 def newton_leg(torch, steps=10):
     """configs[3]: geometric-nonlinear MITC4+ cantilever, tangent K_T and f_int re-assembled every Newton
     iteration (400 x 40 strip, E = 1.2e6, nu = 0, t = 0.1, u_k = k * 1e-3 * smooth field), and the
@@ -328,6 +370,8 @@ def main():
             line["hex8"] = hex8_leg(torch)
             line["newton"] = newton_leg(torch)
             line["c2_hemisphere"] = c2_leg(torch)
+            del asm, K
+            line["c5_full_one_gpu"] = c5_full_leg(torch)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -201,3 +201,59 @@ def test_c5_strip_full_size(oracle):
     assert err < 1e-12 and sym < 1e-12 and rb < 1e-9
     again = asm.assemble_stiffness_matrix(recompute=True)
     assert bool((again.data == K.data).all())                                      # no atomics: bitwise repeatable
+
+
+def test_c5_plate_10m_one_gpu(oracle):
+    """configs[4] at its FULL size on one GPU: 3200 x 3125 = 10 M MITC4+ laminate elements, 60 M dofs,
+    nnz = 3 240 683 136 > 2^31 (int64 indptr / value offsets, 1e8 node-pair blocks).  Checked through the closed-form
+    nnz, sampled CSR rows against the oracle (first, last and random nodes), block symmetry K_IJ == K_JI^T of the
+    sampled rows and a bitwise comparison of sampled rows with the same plate assembled from its first 200 element
+    rows (rows whose elements all lie inside that piece must not depend on the rest of the mesh)."""
+    import bench
+    from fem_shell_amd.assembler import MeshAssembler
+    NX, NY = 3200, 3125
+    free = torch.cuda.mem_get_info()[0]
+    if free < 120e9:
+        pytest.skip(f"needs ~100 GB of device memory, {free / 1e9:.0f} GB free")
+    lams = bench.c5_laminates()
+    mesh = meshes.jittered_plate(NX, NY, cell=1e-3, seed=11, n_sets=16)
+    model = {"elements": {"element_family": ElementFamily.SHELL,
+                          "properties": {mesh.set_names[i]: lams[i] for i in range(16)}}}
+    asm = MeshAssembler(mesh, model)
+    K = asm.assemble_stiffness_matrix()
+    nnz = 36 * (3 * NX + 1) * (3 * NY + 1)
+    assert nnz == 3_240_683_136 and K.nnz == nnz and int(K.indptr[-1]) == nnz and K.data.numel() == nnz
+    rng = np.random.default_rng(5)
+    N = mesh.node_count
+    nodes = np.unique(np.concatenate([[0, N - 1, N - NX - 3], rng.choice(N, 29, replace=False)]))
+    err = _sample_rows(asm, mesh, K, oracle, "K", nodes)
+    print("C5 10M: sampled rows vs oracle", err)
+    assert err < 1e-12
+    ip = K.indptr.cpu().numpy()
+
+    def block_row(A, ipx, I):
+        lo, hi = int(ipx[6 * I]), int(ipx[6 * I + 6])
+        m = int(ipx[6 * I + 1]) - lo
+        return A.indices[lo:lo + m].cpu().numpy()[::6] // 6, A.data[lo:hi].cpu().numpy().reshape(6, m)
+
+    for I in nodes[:8]:                                         # K_IJ == K_JI^T, bit for bit (symmetrised blocks)
+        cols, rowI = block_row(K, ip, int(I))
+        for c, J in enumerate(cols):
+            colsJ, rowJ = block_row(K, ip, int(J))
+            cj = int(np.searchsorted(colsJ, I))
+            assert np.array_equal(rowI[:, 6 * c:6 * c + 6], rowJ[:, 6 * cj:6 * cj + 6].T)
+    # the first 200 element rows as a mesh of their own: same node numbering (row-major), so rows of nodes
+    # below the cut are identical bit for bit
+    del K
+    torch.cuda.empty_cache()
+    sub_rows = 200
+    sub = meshes.ArrayMesh(mesh.coords[:(NX + 1) * (sub_rows + 1)], mesh.conn[:NX * sub_rows],
+                           mesh.set_id[:NX * sub_rows], mesh.set_names)
+    Ks = MeshAssembler(sub, model).assemble_stiffness_matrix()
+    K = asm.assemble_stiffness_matrix(recompute=True)
+    ips = Ks.indptr.cpu().numpy()
+    low = np.concatenate([[0, 17, (NX + 1) * (sub_rows - 1) + 5], rng.choice((NX + 1) * sub_rows, 13, replace=False)])
+    for I in low:
+        c1, r1 = block_row(K, ip, int(I))
+        c2, r2 = block_row(Ks, ips, int(I))
+        assert np.array_equal(c1, c2) and np.array_equal(r1, r2)
