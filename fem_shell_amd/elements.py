@@ -87,9 +87,21 @@ class ShellElement(FemElement):
         if len(displacements) != n:
             raise ValueError(f"Expected {n} DOFs, got {len(displacements)}")
         self._current_displacements = np.array(displacements, dtype=float)
+        self._current_coords = self._initial_coords + self._current_displacements.reshape(self._NN, 6)[:, :3]
 
     def reset_configuration(self):
         self._current_displacements = np.zeros(6 * self._NN)
+        self._current_coords = self._initial_coords.copy()
+
+    # constitutive matrices as the kernels receive them (elements/MITC4.py:671-695, MITC4_composite.py:172-182)
+    def Cm(self) -> np.ndarray:
+        return np.array(self._prop_row()["A"], dtype=float).reshape(3, 3)
+
+    def Cb(self) -> np.ndarray:
+        return np.array(self._prop_row()["D"], dtype=float).reshape(3, 3)
+
+    def Cs(self) -> np.ndarray:
+        return np.array(self._prop_row()["Cs"], dtype=float).reshape(2, 2)
 
     def _run_nl(self, want_KT, want_F):
         import torch
@@ -143,6 +155,7 @@ class MITC4(ShellElement):
         if self._initial_coords.shape != (4, 3):
             raise ValueError("MITC4 needs 4 nodes with 3 coordinates each")
         self._current_displacements = np.zeros(24)
+        self._current_coords = self._initial_coords.copy()
         self._kappa_arg = shear_correction_factor
 
     def _prop_row(self):
@@ -204,6 +217,7 @@ class MITC3(ShellElement):
             raise ValueError("MITC3 needs 3 nodes with 3 coordinates each")
         self._kappa_arg = shear_correction_factor
         self._current_displacements = np.zeros(18)
+        self._current_coords = self._initial_coords.copy()
         # MITC3.py:375-418 raises at construction for a degenerate triangle
         v12, v13 = self._initial_coords[1] - self._initial_coords[0], self._initial_coords[2] - self._initial_coords[0]
         if np.linalg.norm(np.cross(v12, v13)) < 1e-12:
