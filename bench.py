@@ -233,9 +233,17 @@ def newton_leg(torch, steps=10):
             asm.assemble_tangent_and_forces(field * (k * 1e-3))
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+        step = asm.capture_tangent_and_forces()          # the same re-assembly replayed as one HIP graph
+        step(field * 1e-3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(1, steps + 1):
+            step(field * (k * 1e-3))
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - t0) / steps * 1e3
         E = mesh.element_count
         out[tag] = {"elements": E, "ms_per_reassembly": ms, "reassemblies_per_s": 1e3 / ms,
-                    "elements_per_s": E / (ms * 1e-3)}
+                    "elements_per_s": E / (ms * 1e-3), "ms_per_reassembly_hip_graph": gms}
         del asm
     out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate: gather u_e, element K kernel, TL tangent / " \
                   "internal-force kernel, CSR assembly, vector scatter"

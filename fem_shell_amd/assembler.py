@@ -472,6 +472,28 @@ class MeshAssembler:
         out = self._nl_pass(u, True, True)
         return self._assemble(out["KT"]), self._scatter_vector(out["f_int"])
 
+    def capture_tangent_and_forces(self):
+        """One HIP graph for a whole Newton re-assembly (gather u_e -> element kernels -> CSR assembly -> vector
+        scatter): small meshes are launch-bound (five launches of a few microseconds each), the graph replays them
+        with one submission.  Returns step(u) -> (K_T, f_int); every call overwrites the SAME output buffers."""
+        u_static = torch.zeros(self.dofs_count, dtype=torch.float64, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # warm-up outside the capture: lazy plans, allocator pools
+            self.assemble_tangent_and_forces(u_static)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            K, f = self.assemble_tangent_and_forces(u_static)
+
+        def step(u):
+            u_static.copy_(torch.as_tensor(u, dtype=torch.float64, device=self.device))
+            graph.replay()
+            return K, f
+
+        step.graph = graph
+        return step
+
     def assemble_load_vector(self, load_condition):
         """core/assembler.py:338-384: fe = element.body_load(load_condition.value), scatter-added in
         element order.  Shells have no body_load in the reference (AttributeError)."""

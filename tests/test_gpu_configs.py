@@ -183,6 +183,14 @@ def test_c4_nl_cantilever_newton(oracle):
             print("C4 iterate", k, "f_int err", err, "element force", fscale, "|K||u|", terms)
             assert err <= 1e-12 * terms and err <= 1e-10 * fscale
     print("C4 ok: 10 re-assemblies of K_T and f_int,", mesh.conn.shape[0], "elements")
+    # the same re-assembly captured in one HIP graph: bitwise the same K_T and f_int, replay after replay
+    step = asm.capture_tangent_and_forces()
+    for k in (3, 7, 3):
+        uk = torch.from_numpy((k * 1e-3 * shape).reshape(-1)).to(asm.device)
+        Kd, fd = asm.assemble_tangent_and_forces(uk)
+        Kg, fg = step(uk)
+        torch.cuda.synchronize()
+        assert bool((Kg.data == Kd.data).all()) and bool((fg == fd).all())
 
 
 def test_c5_strip_full_size(oracle):
