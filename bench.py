@@ -165,6 +165,46 @@ def c2_leg(torch, steps=20):
     return out
 
 
+def measured_peaks(torch):
+    """The box's own ceilings, measured in this run: fp64 FMA issue rate with one and with four waves
+    per SIMD (8 independent chains per lane), HBM write-only (memset), read+write (copy) and read-only (sum)."""
+    from fem_shell_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty(8192 * 64, dtype=torch.float64, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    res = {}
+    iters = 20000
+    for tag, waves in (("fp64_fma_1_wave_per_simd_TFLOPs", 1024), ("fp64_fma_4_waves_per_simd_TFLOPs", 4096)):
+        _lib.check(lib.fs_bench_fp64_fma(waves, 10, _lib.ptr(out), _lib.stream_ptr()), "fs_bench_fp64_fma")
+        torch.cuda.synchronize()
+        ev[0].record()
+        _lib.check(lib.fs_bench_fp64_fma(waves, iters, _lib.ptr(out), _lib.stream_ptr()), "fs_bench_fp64_fma")
+        ev[1].record()
+        torch.cuda.synchronize()
+        res[tag] = 2.0 * 64 * 64 * iters * waves / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12
+    n = 1 << 29                                    # 4 GiB of doubles: far beyond the 256 MB Infinity Cache
+    a = torch.empty(n, dtype=torch.float64, device=dev)
+    b = torch.empty(n, dtype=torch.float64, device=dev)
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) * 1e-3 / reps
+
+    res["hbm_write_GBs"] = 8.0 * n / timed(lambda: a.zero_()) / 1e9
+    res["hbm_copy_GBs"] = 16.0 * n / timed(lambda: b.copy_(a)) / 1e9
+    res["hbm_read_GBs"] = 8.0 * n / timed(lambda: a.sum()) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return res
+
+
 def c5_full_leg(torch, steps=5):
     """configs[4]'s shell plate at its FULL size on ONE GPU: 3200 x 3125 = 10 M MITC4+ laminate elements, 60 M dofs,
     nnz 3.24e9 (about 110 GB of device memory).  Step = element K kernel + CSR assembly, as in `value`; skipped
@@ -375,6 +415,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             nt = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(nt)
+            mp = measured_peaks(torch)
+            line["measured_peaks"] = mp
+            k_obj["frac_of_measured_peak"] = k_obj["achieved"] / mp["fp64_fma_4_waves_per_simd_TFLOPs"]
+            k_obj["frac_of_measured_one_wave_per_simd"] = k_obj["achieved"] / mp["fp64_fma_1_wave_per_simd_TFLOPs"]
+            a_obj["frac_of_measured_peak"] = a_obj["achieved"] / mp["hbm_copy_GBs"]
             line["hex8"] = hex8_leg(torch)
             line["newton"] = newton_leg(torch)
             line["c2_hemisphere"] = c2_leg(torch)

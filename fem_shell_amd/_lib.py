@@ -49,6 +49,7 @@ SIGNATURES = {
     "fs_halo_pack": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "fs_bench_fp64_fma": (ctypes.c_int, [_i32, _i32, _vp, _vp]),
     "fs_shell_stress_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _u32, _i32,
                                              _vp, _vp, _vp]),
     "fs_solid_stress_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp,

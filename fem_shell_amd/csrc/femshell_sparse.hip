@@ -130,6 +130,22 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
     if (lane == 0) out[r] = s;
 }
 
+// Diagnostic: fp64 FMA issue rate, 8 independent dependent-chains per lane (bench.py measures the box's own fp64
+// ceiling with it, at one and at four waves per SIMD).
+__global__ __launch_bounds__(64) void fp64_fma_kernel(double *__restrict__ out, int iters, double a, double b) {
+    double acc[8];
+    for (int c = 0; c < 8; c++) acc[c] = (double)(threadIdx.x + c);
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc[c] = __builtin_fma(acc[c], a, b);
+    }
+    double s = 0.0;
+    for (int c = 0; c < 8; c++) s += acc[c];
+    out[(int64_t)blockIdx.x * 64 + threadIdx.x] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,6 +248,14 @@ int fs_csr_row_sums(const int64_t *indptr, const double *data, int64_t nrows, do
                        nrows, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FS_OK : fs_fail_(FS_EHIP, "row_sums_kernel", (int)e);
+}
+
+int fs_bench_fp64_fma(int32_t waves, int32_t iters, double *out, void *stream) {
+    if (waves <= 0 || iters <= 0 || !out) return fs_fail_(FS_EINVAL, "fs_bench_fp64_fma: bad arguments", 0);
+    hipLaunchKernelGGL(fp64_fma_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, out, (int)iters,
+                       1.0000001, 1e-9);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FS_OK : fs_fail_(FS_EHIP, "fp64_fma_kernel", (int)e);
 }
 
 }  // extern "C"

@@ -382,6 +382,11 @@ int fs_halo_add(const double *buf, const int64_t *idx, int64_t n, double *data, 
 /* u_e[e][a] = u[dofs[e][a]]  (gather for KT / f_int re-assembly) */
 int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream);
 
+/* Diagnostic, no counterpart in the reference: `waves` 64-lane workgroups each run iters * 64 fp64 FMAs per lane in
+ * 8 independent chains (2 * 64 * 64 * iters * waves flop per launch); out [waves * 64].  bench.py times it to report
+ * the box's own fp64 ceiling beside the vendor peak. */
+int fs_bench_fp64_fma(int32_t waves, int32_t iters, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
