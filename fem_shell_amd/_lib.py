@@ -11,6 +11,7 @@ FS_WANT_FBODY, FS_WANT_KG = 16, 32
 FS_LAYOUT_DENSE, FS_LAYOUT_SYMBLK, FS_LAYOUT_SYMBLK_T16 = 0, 1, 2
 FS_STRESS_MEMBRANE, FS_STRESS_BENDING = 1, 2
 FS_SOLID_STRESS_GP, FS_SOLID_STRESS_MEAN, FS_SOLID_STRESS_NODES = 0, 1, 2
+FS_INERTIAL_CENTRIFUGAL, FS_INERTIAL_CORIOLIS, FS_INERTIAL_EULER = 1, 2, 4
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_bench_fp64_fma": (ctypes.c_int, [_i32, _i32, _vp, _vp]),
+    "fs_inertial_forces": (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_double, _vp, _vp, _u32, _vp, _vp]),
     "fs_shell_stress_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _u32, _i32,
                                              _vp, _vp, _vp]),
     "fs_solid_stress_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp,

@@ -130,6 +130,38 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
     if (lane == 0) out[r] = s;
 }
 
+// Inertial (fictitious) nodal forces of a rotating frame (solvers/fsi/corotational.py:347-469), one thread per node:
+//   centrifugal  m w^2 (r - (r.a) a)      Coriolis  -2 m (w a) x v      Euler  -m (alpha a) x r
+// summed in that order like compute_all_inertial_forces (:511-552).  Products in the reference's order
+// (contraction is off for this translation unit's arithmetic: -ffp-contract=off).
+__global__ __launch_bounds__(256) void inertial_forces_kernel(const double *__restrict__ coords,
+                                                              const double *__restrict__ vel,
+                                                              const double *__restrict__ mass, int64_t N,
+                                                              double omega, double alpha, double ax, double ay,
+                                                              double az, double cx, double cy, double cz,
+                                                              unsigned parts, double *__restrict__ F) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double m = mass[n];
+    const double rx = coords[3 * n] - cx, ry = coords[3 * n + 1] - cy, rz = coords[3 * n + 2] - cz;
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+    if ((parts & 1u) && omega != 0.0) {
+        const double rd = (rx * ax + ry * ay) + rz * az;                 // r @ axis
+        const double w2 = omega * omega;
+        fx += (m * w2) * (rx - rd * ax); fy += (m * w2) * (ry - rd * ay); fz += (m * w2) * (rz - rd * az);
+    }
+    if ((parts & 2u) && omega != 0.0) {
+        const double wx = omega * ax, wy = omega * ay, wz = omega * az;
+        const double vx = vel[3 * n], vy = vel[3 * n + 1], vz = vel[3 * n + 2];
+        fx += (-2.0 * m) * (wy * vz - wz * vy); fy += (-2.0 * m) * (wz * vx - wx * vz); fz += (-2.0 * m) * (wx * vy - wy * vx);
+    }
+    if ((parts & 4u) && alpha != 0.0) {
+        const double bx = alpha * ax, by = alpha * ay, bz = alpha * az;
+        fx += (-m) * (by * rz - bz * ry); fy += (-m) * (bz * rx - bx * rz); fz += (-m) * (bx * ry - by * rx);
+    }
+    F[3 * n] = fx; F[3 * n + 1] = fy; F[3 * n + 2] = fz;
+}
+
 // Diagnostic: fp64 FMA issue rate, 8 independent dependent-chains per lane (bench.py measures the box's own fp64
 // ceiling with it, at one and at four waves per SIMD).
 __global__ __launch_bounds__(64) void fp64_fma_kernel(double *__restrict__ out, int iters, double a, double b) {
@@ -248,6 +280,20 @@ int fs_csr_row_sums(const int64_t *indptr, const double *data, int64_t nrows, do
                        nrows, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FS_OK : fs_fail_(FS_EHIP, "row_sums_kernel", (int)e);
+}
+
+int fs_inertial_forces(const double *coords, const double *vel, const double *mass, int64_t N, double omega,
+                       double alpha, const double *axis_host, const double *center_host, uint32_t parts, double *F,
+                       void *stream) {
+    if (N <= 0) return N == 0 ? FS_OK : fs_fail_(FS_EINVAL, "fs_inertial_forces: N < 0", 0);
+    if (!coords || !mass || !F || !axis_host) return fs_fail_(FS_EINVAL, "fs_inertial_forces: null argument", 0);
+    if ((parts & 2u) && !vel) return fs_fail_(FS_EINVAL, "fs_inertial_forces: Coriolis part needs velocities", 0);
+    const double c[3] = {center_host ? center_host[0] : 0.0, center_host ? center_host[1] : 0.0,
+                         center_host ? center_host[2] : 0.0};
+    hipLaunchKernelGGL(inertial_forces_kernel, dim3(grid_of(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, vel,
+                       mass, N, omega, alpha, axis_host[0], axis_host[1], axis_host[2], c[0], c[1], c[2], parts, F);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FS_OK : fs_fail_(FS_EHIP, "inertial_forces_kernel", (int)e);
 }
 
 int fs_bench_fp64_fma(int32_t waves, int32_t iters, double *out, void *stream) {

@@ -382,6 +382,20 @@ int fs_halo_add(const double *buf, const int64_t *idx, int64_t n, double *data, 
 /* u_e[e][a] = u[dofs[e][a]]  (gather for KT / f_int re-assembly) */
 int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream);
 
+/*
+ * Inertial nodal forces of a rotating frame: InertialForcesCalculator.compute_centrifugal_force / compute_coriolis_force
+ * / compute_euler_force / compute_all_inertial_forces (solvers/fsi/corotational.py:347-552), the rotor load that goes
+ * with the lumped mass of the assembled M.
+ *   coords [N][3], vel [N][3] (NULL unless FS_INERTIAL_CORIOLIS), mass [N]: device;  axis_host (unit vector),
+ *   center_host (NULL = origin): 3 doubles each in HOST memory;  parts: FS_INERTIAL_* bits;  F [N][3] = their sum.
+ */
+#define FS_INERTIAL_CENTRIFUGAL 1u
+#define FS_INERTIAL_CORIOLIS 2u
+#define FS_INERTIAL_EULER 4u
+int fs_inertial_forces(const double *coords, const double *vel, const double *mass, int64_t N, double omega,
+                       double alpha, const double *axis_host, const double *center_host, uint32_t parts, double *F,
+                       void *stream);
+
 /* Diagnostic, no counterpart in the reference: `waves` 64-lane workgroups each run iters * 64 fp64 FMAs per lane in
  * 8 independent chains (2 * 64 * 64 * iters * waves flop per launch); out [waves * 64].  bench.py times it to report
  * the box's own fp64 ceiling beside the vendor peak. */
