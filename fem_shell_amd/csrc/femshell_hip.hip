@@ -1428,6 +1428,243 @@ __global__ __launch_bounds__(256) void mitc3_k_kernel(const double *__restrict__
     for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
 }
 
+// ------------------------------------------------------------------------------------------
+// MITC3+ stiffness, wave-per-10-elements form (the shipped one; mitc3_k_kernel above is the simple thread-per-pair
+// statement of the same arithmetic, kept for reference and for the A/B test).
+//   stage 1  lane = (element q, function f = node 0..2 or bubble 3), 40 lanes: triangle geometry and the shape /
+//            tying data of f at the 3 Hammer points -> LDS, 23 doubles per (q, f); frame and area per element
+//   stage 2  lane = (element q, node pair p), 60 lanes: the pair's 6 x 6 block from the LDS image, Gauss point by
+//            Gauss point (only one point's data is live, so the wave fits two per SIMD), rotation, then the 60
+//            blocks of the wave -- 17 280 contiguous bytes of FS_LAYOUT_SYMBLK -- leave through an LDS staging area
+//            as whole-line stores (30 blocks per pass), like the tiled MITC4 kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int M3_EPW = 10;                       // elements per wave
+constexpr int M3_FN = 0;                         // fn[c < 23][q][f]
+constexpr int M3_GEO = M3_FN + 23 * 40;          // geo[c < 10][q]: area, R (9)
+constexpr int M3_STG = M3_GEO + 10 * M3_EPW;     // staging, 30 slots
+constexpr int M3_LDS = M3_STG + 30 * STG_SLOT;   // 2160 doubles = 17 280 B
+
+struct TriG { double fx, fy, gx0, gx1, gy0, gy1, h; };
+__device__ __forceinline__ TriG tri_g_load(const double *lds, int qf, int g) {
+    TriG F;
+    F.fx = lds[M3_FN + (0 + g) * 40 + qf]; F.fy = lds[M3_FN + (3 + g) * 40 + qf];
+    F.gx0 = lds[M3_FN + (6 + 2 * g) * 40 + qf]; F.gx1 = lds[M3_FN + (7 + 2 * g) * 40 + qf];
+    F.gy0 = lds[M3_FN + (12 + 2 * g) * 40 + qf]; F.gy1 = lds[M3_FN + (13 + 2 * g) * 40 + qf];
+    F.h = lds[M3_FN + (18 + g) * 40 + qf];
+    return F;
+}
+struct TriCSg { double w[2], x[5], y[5]; };
+__device__ __forceinline__ void tri_cs_g(const double *D, const double *Cs, const TriG &F, double dhx, double dhy,
+                                         bool nodal, TriCSg &c) {
+#pragma clang fp contract(fast)
+    const double fx = F.fx, fy = F.fy;
+    c.x[0] = -(D[1] * fy + D[2] * fx); c.x[1] = -(D[4] * fy + D[5] * fx); c.x[2] = -(D[7] * fy + D[8] * fx);
+    c.y[0] = D[0] * fx + D[2] * fy;    c.y[1] = D[3] * fx + D[5] * fy;    c.y[2] = D[6] * fx + D[8] * fy;
+    c.x[3] = Cs[0] * F.gx0 + Cs[1] * F.gx1; c.x[4] = Cs[2] * F.gx0 + Cs[3] * F.gx1;
+    c.y[3] = Cs[0] * F.gy0 + Cs[1] * F.gy1; c.y[4] = Cs[2] * F.gy0 + Cs[3] * F.gy1;
+    c.w[0] = nodal ? Cs[0] * dhx + Cs[1] * dhy : 0.0;
+    c.w[1] = nodal ? Cs[2] * dhx + Cs[3] * dhy : 0.0;
+}
+__device__ __forceinline__ double tri_dw(double dhx, double dhy, const double *c5) {
+#pragma clang fp contract(fast)
+    return dhx * c5[3] + dhy * c5[4];
+}
+__device__ __forceinline__ double tri_dx(const TriG &F, const double *c5) {
+#pragma clang fp contract(fast)
+    return -F.fy * c5[1] - F.fx * c5[2] + F.gx0 * c5[3] + F.gx1 * c5[4];
+}
+__device__ __forceinline__ double tri_dy(const TriG &F, const double *c5) {
+#pragma clang fp contract(fast)
+    return F.fx * c5[0] + F.fy * c5[2] + F.gy0 * c5[3] + F.gy1 * c5[4];
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mitc3_k_lds_kernel(const double *__restrict__ xyz,
+                                                         const int32_t *__restrict__ prop_id,
+                                                         const fs_shell_prop *__restrict__ props,
+                                                         int64_t E, double *__restrict__ out,
+                                                         int32_t *__restrict__ status) {
+    __shared__ double lds[M3_LDS];
+    const int lane = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * M3_EPW;
+    // ---------------- stage 1 ----------------
+    if (lane < 4 * M3_EPW) {
+        const int q = lane >> 2, f = lane & 3;
+        const int64_t e_raw = e0 + q;
+        const int64_t e = e_raw < E ? e_raw : E - 1;
+        double x[3][3];
+        for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+        TriGeom geo;
+        tri_geometry(x, geo);
+        TriFn F;
+        tri_fn(geo, f, F);
+        const int qf = lane;                                   // q * 4 + f
+        for (int g = 0; g < 3; g++) {
+            lds[M3_FN + (0 + g) * 40 + qf] = F.fx[g];
+            lds[M3_FN + (3 + g) * 40 + qf] = F.fy[g];
+            lds[M3_FN + (6 + 2 * g) * 40 + qf] = F.gx[g][0];
+            lds[M3_FN + (7 + 2 * g) * 40 + qf] = F.gx[g][1];
+            lds[M3_FN + (12 + 2 * g) * 40 + qf] = F.gy[g][0];
+            lds[M3_FN + (13 + 2 * g) * 40 + qf] = F.gy[g][1];
+            lds[M3_FN + (18 + g) * 40 + qf] = F.h[g];
+        }
+        lds[M3_FN + 21 * 40 + qf] = F.dhx;
+        lds[M3_FN + 22 * 40 + qf] = F.dhy;
+        if (f == 0) {
+            lds[M3_GEO + 0 * M3_EPW + q] = geo.area;
+            for (int k = 0; k < 3; k++) {
+                lds[M3_GEO + (1 + k) * M3_EPW + q] = geo.e1[k];
+                lds[M3_GEO + (4 + k) * M3_EPW + q] = geo.e2[k];
+                lds[M3_GEO + (7 + k) * M3_EPW + q] = geo.e3[k];
+            }
+            if (status && e_raw < E) status[e] = geo.status;
+        }
+    }
+    __syncthreads();
+    // ---------------- stage 2 ----------------
+    const int q = (lane * 43) >> 8;                            // lane / 6 for lane < 64
+    const int p = lane - q * 6;
+    const bool worker = lane < 6 * M3_EPW;
+    const int ti = (p < 3) ? 0 : ((p < 5) ? 1 : 2);
+    const int tj = (p < 3) ? p : ((p < 5) ? p - 2 : 2);
+    const int qq = worker ? q : 0;
+    const int64_t e_raw = e0 + qq;
+    const int64_t e = e_raw < E ? e_raw : E - 1;
+    double G[6][6];
+    {
+#pragma clang fp contract(fast)
+        const fs_shell_prop *pr = props + prop_id[e];
+        const int qi = qq * 4 + ti, qj = qq * 4 + tj, qb = qq * 4 + 3;
+        const double area = lds[M3_GEO + qq];
+        const double idhx = lds[M3_FN + 21 * 40 + qi], idhy = lds[M3_FN + 22 * 40 + qi];
+        const double jdhx = lds[M3_FN + 21 * 40 + qj], jdhy = lds[M3_FN + 22 * 40 + qj];
+        double D[9], Cs[4];
+        for (int c = 0; c < 9; c++) D[c] = pr->D[c];
+        for (int c = 0; c < 4; c++) Cs[c] = pr->Cs[c];
+        const double kd = pr->k_drill;
+        const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
+        double Kij[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        double Ni[3][2] = {{0, 0}, {0, 0}, {0, 0}}, Nj[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        double Kbb[2][2] = {{0, 0}, {0, 0}};
+        double dr[2][2] = {{0, 0}, {0, 0}}, drz[2] = {0, 0}, dzr[2] = {0, 0}, dzz = 0.0;
+        double cpl_ij[2][2] = {{0, 0}, {0, 0}}, cpl_ji[2][2] = {{0, 0}, {0, 0}};
+        const double bdi[2] = {-0.5 * idhy, 0.5 * idhx}, bdj[2] = {-0.5 * jdhy, 0.5 * jdhx};
+        const double wA = (1.0 / 3.0) * area;
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const TriG Fi = tri_g_load(lds, qi, g), Fj = tri_g_load(lds, qj, g), Fb = tri_g_load(lds, qb, g);
+            TriCSg cj, cb;
+            tri_cs_g(D, Cs, Fj, jdhx, jdhy, true, cj);
+            tri_cs_g(D, Cs, Fb, 0.0, 0.0, false, cb);
+            const double cjw[5] = {0.0, 0.0, 0.0, cj.w[0], cj.w[1]};
+            Kij[0][0] += wA * tri_dw(idhx, idhy, cjw);  Kij[0][1] += wA * tri_dw(idhx, idhy, cj.x);  Kij[0][2] += wA * tri_dw(idhx, idhy, cj.y);
+            Kij[1][0] += wA * (Fi.gx0 * cj.w[0] + Fi.gx1 * cj.w[1]);
+            Kij[1][1] += wA * tri_dx(Fi, cj.x);  Kij[1][2] += wA * tri_dx(Fi, cj.y);
+            Kij[2][0] += wA * (Fi.gy0 * cj.w[0] + Fi.gy1 * cj.w[1]);
+            Kij[2][1] += wA * tri_dy(Fi, cj.x);  Kij[2][2] += wA * tri_dy(Fi, cj.y);
+            Ni[0][0] += wA * tri_dw(idhx, idhy, cb.x);  Ni[0][1] += wA * tri_dw(idhx, idhy, cb.y);
+            Ni[1][0] += wA * tri_dx(Fi, cb.x);  Ni[1][1] += wA * tri_dx(Fi, cb.y);
+            Ni[2][0] += wA * tri_dy(Fi, cb.x);  Ni[2][1] += wA * tri_dy(Fi, cb.y);
+            Nj[0][0] += wA * tri_dw(jdhx, jdhy, cb.x);  Nj[0][1] += wA * tri_dw(jdhx, jdhy, cb.y);
+            Nj[1][0] += wA * tri_dx(Fj, cb.x);  Nj[1][1] += wA * tri_dx(Fj, cb.y);
+            Nj[2][0] += wA * tri_dy(Fj, cb.x);  Nj[2][1] += wA * tri_dy(Fj, cb.y);
+            Kbb[0][0] += wA * tri_dx(Fb, cb.x); Kbb[0][1] += wA * tri_dx(Fb, cb.y);
+            Kbb[1][0] += wA * tri_dy(Fb, cb.x); Kbb[1][1] += wA * tri_dy(Fb, cb.y);
+            const double wk = wA * kd;
+            dr[0][0] += wk * bdi[0] * bdj[0]; dr[0][1] += wk * bdi[0] * bdj[1];
+            dr[1][0] += wk * bdi[1] * bdj[0]; dr[1][1] += wk * bdi[1] * bdj[1];
+            drz[0] += wk * bdi[0] * (-Fj.h); drz[1] += wk * bdi[1] * (-Fj.h);
+            dzr[0] += wk * (-Fi.h) * bdj[0]; dzr[1] += wk * (-Fi.h) * bdj[1];
+            dzz += wk * Fi.h * Fj.h;
+            if (coupled) {  // MITC3_composite.py:204-240 (nodal-only form: the bubble block of K_qq is zero)
+                const double *B = pr->B;
+                {
+                    const double fx = Fj.fx, fy = Fj.fy;
+                    const double bx[3] = {-(B[1] * fy + B[2] * fx), -(B[4] * fy + B[5] * fx), -(B[7] * fy + B[8] * fx)};
+                    const double by[3] = {B[0] * fx + B[2] * fy, B[3] * fx + B[5] * fy, B[6] * fx + B[8] * fy};
+                    cpl_ij[0][0] += wA * (idhx * bx[0] + idhy * bx[2]); cpl_ij[0][1] += wA * (idhx * by[0] + idhy * by[2]);
+                    cpl_ij[1][0] += wA * (idhy * bx[1] + idhx * bx[2]); cpl_ij[1][1] += wA * (idhy * by[1] + idhx * by[2]);
+                }
+                {
+                    const double fx = Fi.fx, fy = Fi.fy;
+                    const double bx[3] = {-(B[1] * fy + B[2] * fx), -(B[4] * fy + B[5] * fx), -(B[7] * fy + B[8] * fx)};
+                    const double by[3] = {B[0] * fx + B[2] * fy, B[3] * fx + B[5] * fy, B[6] * fx + B[8] * fy};
+                    cpl_ji[0][0] += wA * (jdhx * bx[0] + jdhy * bx[2]); cpl_ji[0][1] += wA * (jdhx * by[0] + jdhy * by[2]);
+                    cpl_ji[1][0] += wA * (jdhy * bx[1] + jdhx * bx[2]); cpl_ji[1][1] += wA * (jdhy * by[1] + jdhx * by[2]);
+                }
+            }
+        }
+        // static condensation of the two bubble rotations (MITC3.py:958-1007)
+        const double det = Kbb[0][0] * Kbb[1][1] - Kbb[0][1] * Kbb[1][0];
+        const double i00 = Kbb[1][1] / det, i01 = -Kbb[0][1] / det, i10 = -Kbb[1][0] / det, i11 = Kbb[0][0] / det;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+                Kij[a][b] -= Ni[a][0] * (i00 * Nj[b][0] + i01 * Nj[b][1]) + Ni[a][1] * (i10 * Nj[b][0] + i11 * Nj[b][1]);
+        if (ti == tj) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (Kij[a][b] + Kij[b][a]); Kij[a][b] = m; Kij[b][a] = m; }
+        }
+        double L[6][6];
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) L[a][b] = 0.0;
+        {   // membrane CST (MITC3.py:1009-1022): area * Bm_i^T A Bm_j
+            const double *A = pr->A;
+            const double cu[3] = {A[0] * jdhx + A[2] * jdhy, A[3] * jdhx + A[5] * jdhy, A[6] * jdhx + A[8] * jdhy};
+            const double cv[3] = {A[1] * jdhy + A[2] * jdhx, A[4] * jdhy + A[5] * jdhx, A[7] * jdhy + A[8] * jdhx};
+            L[0][0] = area * (idhx * cu[0] + idhy * cu[2]) + dr[0][0]; L[0][1] = area * (idhx * cv[0] + idhy * cv[2]) + dr[0][1];
+            L[1][0] = area * (idhy * cu[1] + idhx * cu[2]) + dr[1][0]; L[1][1] = area * (idhy * cv[1] + idhx * cv[2]) + dr[1][1];
+        }
+        L[0][5] = drz[0]; L[1][5] = drz[1]; L[5][0] = dzr[0]; L[5][1] = dzr[1]; L[5][5] = dzz;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) L[2 + a][2 + b] = Kij[a][b];
+        if (coupled) {
+            L[0][3] = cpl_ij[0][0]; L[0][4] = cpl_ij[0][1]; L[1][3] = cpl_ij[1][0]; L[1][4] = cpl_ij[1][1];
+            L[3][0] = cpl_ji[0][0]; L[4][0] = cpl_ji[0][1]; L[3][1] = cpl_ji[1][0]; L[4][1] = cpl_ji[1][1];
+        }
+        double R[3][3];
+        for (int k = 0; k < 3; k++) {
+            R[0][k] = lds[M3_GEO + (1 + k) * M3_EPW + qq];
+            R[1][k] = lds[M3_GEO + (4 + k) * M3_EPW + qq];
+            R[2][k] = lds[M3_GEO + (7 + k) * M3_EPW + qq];
+        }
+        rotate_block6(L, R, G);
+        if (ti == tj) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a + 1; b < 6; b++) { const double m = 0.5 * (G[a][b] + G[b][a]); G[a][b] = m; G[b][a] = m; }
+        }
+    }
+    // ---------------- output: 60 blocks = 1080 contiguous 16-byte chunks, 30 blocks per pass ----------------
+    const int64_t nblk_total = E * 6;
+    const int64_t blk0 = e0 * 6;
+    for (int h = 0; h < 2; h++) {
+        if (worker && lane / 30 == h) {
+            double2 *sp = reinterpret_cast<double2 *>(lds + M3_STG + (lane - 30 * h) * STG_SLOT);
+            for (int t = 0; t < 18; t++) sp[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
+        }
+        __syncthreads();
+        const int64_t pass_blk0 = blk0 + 30 * h;
+        const int64_t left = nblk_total - pass_blk0;             // blocks that exist from here on
+        const int nvalid = left >= 30 ? 540 : (left > 0 ? (int)left * 18 : 0);
+        double2 *gp = reinterpret_cast<double2 *>(out + pass_blk0 * 36);
+        const double2 *sp2 = reinterpret_cast<const double2 *>(lds + M3_STG);
+        for (int i = 0; i < 9; i++) {
+            const int c = i * 64 + lane;
+            if (c < nvalid) {
+                const int bl = (c * 3641) >> 16;                 // c / 18 for c < 576
+                gp[c] = sp2[c + bl];                             // staging slots are 19 chunks apart
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // MITC3 consistent mass (MITC3.py:1105-1138): one thread per (element, pair)
 __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
@@ -2436,6 +2673,21 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
     return FS_OK;
 }
 
+// FEMSHELL_M3_SIMPLE=1 in the environment selects the thread-per-pair statement of the MITC3+ kernel (A/B tests)
+static bool m3_simple() {
+    static const bool v = [] { const char *e = getenv("FEMSHELL_M3_SIMPLE"); return e && e[0] == '1'; }();
+    return v;
+}
+#define M3_LAUNCH(dst)                                                                                              \
+    do {                                                                                                            \
+        if (m3_simple())                                                                                            \
+            hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id, \
+                               props, E, dst, status);                                                              \
+        else                                                                                                        \
+            hipLaunchKernelGGL(mitc3_k_lds_kernel, dim3((unsigned)((E + M3_EPW - 1) / M3_EPW)), dim3(64), 0, s, xyz,  \
+                               prop_id, props, E, dst, status);                                                     \
+    } while (0)
+
 int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
                        int32_t n_props, const double *u_e, int64_t E, uint32_t want, uint32_t layout,
                        double *Ke, double *Me, double *KTe, double *fe, int32_t *status, void *stream) {
@@ -2448,8 +2700,7 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
     if (want & (FS_WANT_KT | FS_WANT_FINT)) {
         if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_tri_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_tri_batch: fe is null");
-        hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, E, KTe, status);
+        M3_LAUNCH(KTe);
         FS_LAUNCH_CHECK("mitc3_k_kernel");
         hipLaunchKernelGGL(mitc3_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
                            E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
@@ -2457,8 +2708,7 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
     }
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_tri_batch: Ke is null");
-        hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, E, Ke, status);
+        M3_LAUNCH(Ke);
         FS_LAUNCH_CHECK("mitc3_k_kernel");
     }
     if (want & FS_WANT_M) {
