@@ -61,12 +61,12 @@ def c5_laminates():
 
 def cpu_baseline(n_threads):
     """Oracle (CPU restatement of the reference algorithm, oracle/) on a bounded sample of the same
-    workload: element K for a 200 x 250 piece of the strip on all host threads + element-order
+    workload: element K for a 400 x 1250 piece of the strip on all host threads + element-order
     CSR summation.  Reported baseline only."""
     import fem_shell_amd as fsa
     from fem_shell_amd import meshes
     from oracle import oracle as O
-    nx, ny = 200, 500
+    nx, ny = 400, 1250      # 500 000 elements: about 10 CPU-seconds of oracle work, 2.3 GB of dense element matrices
     mesh = meshes.jittered_plate(nx, ny, n_sets=16)
     table = fsa.build_prop_table(c5_laminates())
     pid = mesh.set_id.astype(np.int32)
