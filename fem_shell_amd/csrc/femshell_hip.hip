@@ -2389,15 +2389,27 @@ __global__ __launch_bounds__(256) void csr_numeric_desc3_row_kernel(const double
         v1 = ((x[0][1] + x[1][1]) + x[2][1]) + x[3][1];
         v2 = ((x[0][2] + x[1][2]) + x[2][2]) + x[3][2];
     } else {
+        // more than 4 contributions (the diagonal block of a node shared by up to 8 hexahedra): batches of 8 with
+        // all index loads, then all value loads, in flight together -- two dependent round trips per batch instead
+        // of two per contribution; the sum still runs in element order
         v0 = v1 = v2 = 0.0;
-        const int64_t lo = dsc.c[0];
-        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
-            const int64_t cc = contrib[q];
-            const double *src = vals + (cc >> 1) * 9;
-            const bool tr = cc & 1;
-            v0 = v0 + src[tr ? k : 3 * k];
-            v1 = v1 + src[tr ? 3 + k : 3 * k + 1];
-            v2 = v2 + src[tr ? 6 + k : 3 * k + 2];
+        const int64_t lo = dsc.c[0], hi = lo + dsc.cnt;
+        for (int64_t q0 = lo; q0 < hi; q0 += 8) {
+            int64_t cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cc[u] = (q0 + u < hi) ? contrib[q0 + u] : 0;
+            double y[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double *src = vals + (cc[u] >> 1) * 9;
+                const bool tr = cc[u] & 1, on = q0 + u < hi;
+                y[u][0] = on ? src[tr ? k : 3 * k] : 0.0;
+                y[u][1] = on ? src[tr ? 3 + k : 3 * k + 1] : 0.0;
+                y[u][2] = on ? src[tr ? 6 + k : 3 * k + 2] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (q0 + u < hi) { v0 = v0 + y[u][0]; v1 = v1 + y[u][1]; v2 = v2 + y[u][2]; }
         }
     }
     double *dst = data + dsc.dst + (int64_t)k * dsc.stride;
@@ -2459,14 +2471,25 @@ __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double
         v.x = ((x[0].x + x[1].x) + x[2].x) + x[3].x;  // element order == reference insertion order
         v.y = ((x[0].y + x[1].y) + x[2].y) + x[3].y;
     } else {
+        // more than 4 contributions (triangle meshes: 6 around an interior node): batches of 8 with all index
+        // loads, then all value loads, in flight together; the sum still runs in element order
         v = make_double2(0.0, 0.0);
-        const int64_t lo = dsc.c[0];
-        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
-            const int64_t cc = contrib[q];
-            const double *base = vals + (cc >> 1) * DD;
-            const double2 y = (cc & 1) ? make_double2(base[l * D + k], base[(l + 1) * D + k])
-                                       : *reinterpret_cast<const double2 *>(base + k * D + l);
-            v.x = v.x + y.x; v.y = v.y + y.y;
+        const int64_t lo = dsc.c[0], hi = lo + dsc.cnt;
+        for (int64_t q0 = lo; q0 < hi; q0 += 8) {
+            int64_t cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cc[u] = (q0 + u < hi) ? contrib[q0 + u] : 0;
+            double2 y[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double *base = vals + (cc[u] >> 1) * DD;
+                y[u] = (q0 + u >= hi) ? make_double2(0.0, 0.0)
+                       : ((cc[u] & 1) ? make_double2(base[l * D + k], base[(l + 1) * D + k])
+                                      : *reinterpret_cast<const double2 *>(base + k * D + l));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (q0 + u < hi) { v.x = v.x + y[u].x; v.y = v.y + y[u].y; }
         }
     }
     *reinterpret_cast<double2 *>(data + dsc.dst + (int64_t)k * dsc.stride + l) = v;
