@@ -55,12 +55,14 @@ def _worker(rank, world, port, nx, ny, q, overlap=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_one_gpu(overlap):
+@pytest.mark.parametrize("world,overlap", [(2, False), (2, True), (3, True)])
+def test_ranks_share_one_gpu(world, overlap):
+    """world = 3: the middle strip has a neighbour on either side (it ships rows to the lower rank and receives the
+    upper rank's)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 9, 7, q, overlap)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 9, 7, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -68,4 +70,4 @@ def test_two_ranks_one_gpu(overlap):
         p.join(30)
     for rank, n, err in res:
         assert err is None, err
-    assert sum(n for _, n, _ in res) == 6 * 19 * 8
+    assert sum(n for _, n, _ in res) == 6 * (9 * world + 1) * 8
