@@ -247,6 +247,57 @@ def c5_full_leg(torch, steps=5):
     return out
 
 
+def c3_leg(torch, steps=10):
+    """configs[2]: blade-like laminate shell (tapered closed tube, 512 x 128 quads, 192 property sets drawn from UD /
+    biax / triax / sandwich layups, ~10 % asymmetric -- the real blade cannot be regenerated here) with
+    its rotor loads: per step K (element kernel + assembly), M (element kernel + assembly), row-sum lumping and the
+    centrifugal nodal forces at 0.79 rad/s about z.  Timed on its own, outside `value`."""
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    from fem_shell_amd.inertial import InertialForcesCalculator
+    mesh = meshes.tapered_tube(128, 512)
+    rng = np.random.default_rng(7)
+    m = fsa.OrthotropicMaterial("T300/5208", (181e9, 10.3e9, 10.3e9), (7.17e9, 3.0e9, 7.17e9), (0.28, 0.28, 0.28), 1600.0)
+    core = fsa.OrthotropicMaterial("core", (0.13e9,) * 3, (0.05e9,) * 3, (0.3,) * 3, 100.0)
+    props = {}
+    for k, name in enumerate(mesh.set_names):
+        kind = rng.integers(0, 4)
+        if kind == 3:
+            lam = fsa.Laminate([fsa.Ply(m, 1e-3, 0.0), fsa.Ply(m, 1e-3, 45.0), fsa.Ply(core, 25e-3, 0.0),
+                                fsa.Ply(m, 1e-3, 45.0), fsa.Ply(m, 1e-3, 0.0)])
+        else:
+            ang = ([0.0] * int(rng.integers(4, 41)), [45.0, -45.0] * int(rng.integers(2, 21)),
+                   [0.0, 45.0, -45.0] * int(rng.integers(2, 14)))[kind]
+            lam = fsa.create_laminate_from_angles(m, 0.5e-3, ang + ([90.0] if k % 10 == 0 else []))
+        props[name] = fsa.CompositeShellProperty(lam)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "properties": props}})
+    calc = InertialForcesCalculator([0.0, 0.0, 1.0])
+    coords_d = torch.from_numpy(mesh.coords).to(asm.device)
+
+    def step():
+        K = asm.assemble_stiffness_matrix(recompute=True)
+        M = asm.assemble_mass_matrix(recompute=True)
+        lumped = M.lump_rows()
+        F = calc.compute_centrifugal_force(coords_d, lumped[0::6].contiguous(), 0.79)
+        return K, M, F
+
+    for _ in range(3):
+        K, M, F = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        K, M, F = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    E = mesh.element_count
+    return {"workload": f"tapered tube 128 x 512 = {E} MITC4+ laminate elements, {len(asm._prop_table)} property rows, "
+                        f"{int((asm._prop_table['flags'] & 1).sum())} with membrane-bending coupling",
+            "ms_per_step": ms, "elements_per_s": E / (ms * 1e-3), "nnz": int(K.nnz),
+            "what": "K and M (element kernels + CSR assembly), row-sum lumping, centrifugal nodal loads"}
+
+
 def newton_leg(torch, steps=10):
     """configs[3]: geometric-nonlinear MITC4+ cantilever, tangent K_T and f_int re-assembled every Newton
     iteration (400 x 40 strip, E = 1.2e6, nu = 0, t = 0.1, u_k = k * 1e-3 * smooth field), and the
@@ -423,6 +474,7 @@ def main():
             line["hex8"] = hex8_leg(torch)
             line["newton"] = newton_leg(torch)
             line["c2_hemisphere"] = c2_leg(torch)
+            line["c3_blade_like"] = c3_leg(torch)
             del asm, K
             line["c5_full_one_gpu"] = c5_full_leg(torch)
         else:
