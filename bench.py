@@ -247,6 +247,64 @@ def c5_full_leg(torch, steps=5):
     return out
 
 
+def c1_leg(torch, steps=50):
+    """configs[0]: Scordelis-Lo roof, MITC4+ 32 x 32 (1 024 elements, 6 534 dofs, nnz 338 724): the reference's own
+    CPU-runnable case.  GPU: element kernel + assembly per step (launch-bound at this size), device Dirichlet
+    reduction, SciPy solve on the host as in the reference's benchmark; CPU: the oracle on one core."""
+    import fem_shell_amd as fsa
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.bc import BoundaryConditionManager, DirichletCondition
+    from fem_shell_amd.elements import ElementFamily
+    from oracle import oracle as O
+    from scipy.sparse.linalg import spsolve
+    R, L, ang, t, rho, n = 25.0, 25.0, 40.0, 0.25, 360.0, 32
+    mesh = meshes.cylindrical_patch(R, L, ang, n, n)
+    mat = fsa.IsotropicMaterial("Ko2017_Scordelis", 4.32e8, 0.0, rho)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": t}})
+    for _ in range(5):
+        K = asm.assemble_stiffness_matrix(recompute=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        K = asm.assemble_stiffness_matrix(recompute=True)
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / steps * 1e3
+    # linear static solve (gravity lumped to the nodes, symmetry + diaphragm constraints of the benchmark)
+    F = np.zeros(mesh.node_count * 6)
+    for row in mesh.conn:
+        c = mesh.coords[row]
+        area = 0.5 * np.linalg.norm(np.cross(c[1] - c[0], c[2] - c[0])) + 0.5 * np.linalg.norm(np.cross(c[2] - c[0], c[3] - c[0]))
+        F[row * 6] -= area * t * rho / 4
+    fixed = []
+    for i, (x, y, z) in enumerate(mesh.coords):
+        if abs(z) < 1e-6:
+            fixed += [i * 6 + 2, i * 6 + 3, i * 6 + 4]
+        if abs(z - L) < 1e-6:
+            fixed += [i * 6 + 0, i * 6 + 1, i * 6 + 5]
+        if abs(y) < 1e-6 and x > 0.0:
+            fixed += [i * 6 + 1, i * 6 + 3, i * 6 + 5]
+    bcm = BoundaryConditionManager(K, F, dof_per_node=6)
+    bcm.apply_dirichlet([DirichletCondition(sorted(set(fixed)), 0.0)])
+    K_red, F_red, _ = bcm.reduced_system
+    u = bcm.expand_solution(spsolve(K_red.to_scipy().tocsc(), F_red.cpu().numpy())).cpu().numpy()
+    node = int(np.argmin(np.abs(mesh.coords - np.array([R * np.cos(np.radians(ang)), R * np.sin(np.radians(ang)), 0.0])).sum(axis=1)))
+    # CPU: oracle element K + element-order CSR summation, one core
+    xyz = mesh.coords[mesh.conn]
+    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
+    O.csr_assemble(dofs, mesh.node_count * 6, O.mitc4_K_batch(xyz, asm._prop_id, asm._prop_table)[0])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        Ke, _ = O.mitc4_K_batch(xyz, asm._prop_id, asm._prop_table)
+        O.csr_assemble(dofs, mesh.node_count * 6, Ke)
+    cpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+    return {"elements": mesh.element_count, "nnz": int(K.nnz), "gpu_ms_per_assembly": gpu_ms,
+            "cpu_oracle_ms_per_assembly_1_core": cpu_ms, "normalised_displacement": abs(u[node * 6]) / 3.0240e-1,
+            "paper_value_n16": 0.9973, "note": "normalised displacement on this 32 x 32 mesh; the reference's benchmark "
+            "pins the 16 x 16 value (0.9973, 5 % band); oracle time includes its symbolic pass; the reference's "
+            "per-object Python path runs at about 580 elements/s/core (BASELINE.md)"}
+
+
 def c3_leg(torch, steps=10):
     """configs[2]: blade-like laminate shell (tapered closed tube, 512 x 128 quads, 192 property sets drawn from UD /
     biax / triax / sandwich layups, ~10 % asymmetric -- the real blade cannot be regenerated here) with
@@ -473,6 +531,7 @@ def main():
             a_obj["frac_of_measured_peak"] = a_obj["achieved"] / mp["hbm_copy_GBs"]
             line["hex8"] = hex8_leg(torch)
             line["newton"] = newton_leg(torch)
+            line["c1_scordelis_lo"] = c1_leg(torch)
             line["c2_hemisphere"] = c2_leg(torch)
             line["c3_blade_like"] = c3_leg(torch)
             del asm, K
