@@ -90,6 +90,7 @@ class _LazyElementMap:
 class MeshAssembler:
     use_descriptors = True   # fs_csr_numeric_desc (False: fs_csr_numeric_blk, same result)
     use_symmetric = False    # fs_csr_numeric_sym: each source block read once (same result)
+    reuse_linear_blocks = True   # K_T / f_int re-assembly reads the cached linear blocks (tiled quad meshes)
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
@@ -433,12 +434,19 @@ class MeshAssembler:
         if self._family != ElementFamily.SHELL:
             raise NotImplementedError("K_T / f_int re-assembly is available for shell meshes (MITC4 / MITC3)")
         ues = self._element_displacements(u)
-        buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
+        # the linear blocks do not depend on u: the tiled quad path hands the ones of the last K evaluation back to the
+        # kernel instead of recomputing them every iterate (the reference reads its cached MITC4.K the same way)
+        cached = self.reuse_linear_blocks and self._layout == _lib.FS_LAYOUT_SYMBLK_T16 and self._K_blk is not None
+        buf = None
+        if want_KT or not cached:
+            buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
         fparts = []
         for g, ue in zip(self._groups, ues):
+            extra = {"K_lin": self._K_blk} if cached else {}
             out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
                                     want_K=False, status=False, validate=False, u_e=ue, want_KT=want_KT,
-                                    want_F=want_F, KT_out=self._group_view(buf, g), layout=self._layout)
+                                    want_F=want_F, KT_out=None if buf is None else self._group_view(buf, g),
+                                    layout=self._layout, **extra)
             if want_F:
                 fparts.append(out["f_int"].reshape(-1))
         f = None

@@ -45,8 +45,11 @@ def _out_buf(given, E, npair, dev, dd=36, layout=_lib.FS_LAYOUT_SYMBLK):
 
 def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
                status=True, validate=True, u_e=None, want_KT=False, want_F=False, K_out=None,
-               M_out=None, KT_out=None, layout=_lib.FS_LAYOUT_SYMBLK):
+               M_out=None, KT_out=None, layout=_lib.FS_LAYOUT_SYMBLK, K_lin=None):
     """MITC4+ element matrices for E quads.
+
+    K_lin: linear blocks K of the same elements from an earlier want_K call (tiled layout): KT / f_int then skip the
+    stiffness kernel (they do not depend on u_e; the reference reads its cached MITC4.K).
 
     xyz [E,4,3] f64 device, prop_id [E] i32 device, props_dev = to_device_props(table).
     Returns dict with 'K'/'M' (FS_LAYOUT_SYMBLK [E,10,36] -- or FS_LAYOUT_SYMBLK_T16 [ceil(E/16)*160,36]
@@ -73,13 +76,21 @@ def quad_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dens
             raise ValueError("KT / f_int need the element displacement vectors u_e [E,24]")
         u_e = u_e.contiguous()
         assert u_e.dtype == torch.float64 and u_e.shape == (E, 24) and u_e.is_cuda
-        KT = _out_buf(KT_out, E, NPAIR4, dev, layout=layout)   # also the FINT workspace
+        cached = K_lin is not None and not want_K and layout == _lib.FS_LAYOUT_SYMBLK_T16
+        if cached:
+            assert K_lin.dtype == torch.float64 and K_lin.is_cuda and K_lin.is_contiguous() and K_lin.numel() >= -(-E // 16) * 160 * 36
+        if want_KT or not cached:
+            KT = _out_buf(KT_out, E, NPAIR4, dev, layout=layout)   # also the FINT workspace without K_lin
         F = torch.empty((E, 24), dtype=torch.float64, device=dev) if want_F else None
         want |= (_lib.FS_WANT_KT if want_KT else 0) | (_lib.FS_WANT_FINT if want_F else 0)
+        if cached:
+            K = K_lin
     _lib.check(lib.fs_shell_quad_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
                                        n_props, _lib.ptr(u_e), E, want, layout,
                                        _lib.ptr(K), _lib.ptr(M), _lib.ptr(KT), _lib.ptr(F), _lib.ptr(st),
                                        _lib.stream_ptr()), "fs_shell_quad_batch")
+    if not want_K:
+        K = None
     if not want_KT:
         KT = None
     if dense:

@@ -797,8 +797,9 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
                                                             const int32_t *__restrict__ prop_id,
                                                             const fs_shell_prop *__restrict__ props,
                                                             const double *__restrict__ ue, int64_t E,
-                                                            double *__restrict__ kt, int want_kt,
+                                                            const double *k0, double *kt, int want_kt,
                                                             double *__restrict__ fe) {
+    // k0: the linear blocks K (read); kt: K_T (written when want_kt).  They may be the same buffer (in place).
     __shared__ double lds[NLT_LDS];
     const int lane = threadIdx.x;
     const int Q = lane >> 2, g = lane & 3;
@@ -973,12 +974,14 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
         const int p = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
         const int npass = (round == 2) ? 1 : 2;
         for (int h = 0; h < npass; h++) {
-            double2 *gp = reinterpret_cast<double2 *>(kt + ((int64_t)blockIdx.x * 160 + round * 64 + h * 32) * 36) + lane;
+            const int64_t toff = ((int64_t)blockIdx.x * 160 + round * 64 + h * 32) * 36;
+            const double2 *gin = reinterpret_cast<const double2 *>(k0 + toff) + lane;
+            double2 *gp = reinterpret_cast<double2 *>(kt + toff) + lane;
             double2 *st2 = reinterpret_cast<double2 *>(lds + NLT_STG);
             for (int i = 0; i < 9; i++) {
                 const int c = i * 64 + lane;
                 const int bl = (c * 3641) >> 16;        // c / 18 for c < 576
-                st2[c + bl] = gp[i * 64];
+                st2[c + bl] = gin[i * 64];
             }
             __syncthreads();
             const bool mine = (round == 2) ? (g < 2) : ((lane >> 5) == h);
@@ -2663,15 +2666,23 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
     const int tiled = layout == FS_LAYOUT_SYMBLK_T16;
     hipStream_t s = (hipStream_t)stream;
     if (want & (FS_WANT_KT | FS_WANT_FINT)) {
-        if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_quad_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
+        // the linear blocks K do not depend on u (the reference caches them: MITC4.K is a cached_property read by
+        // compute_tangent_stiffness / compute_internal_forces): with Ke given and FS_WANT_K clear, Ke is an INPUT
+        // (a previous FS_WANT_K result for the same elements, tiled layout) and the stiffness kernel is skipped
+        const bool k_cached = tiled && Ke && !(want & FS_WANT_K);
+        if (!u_e) return fail(FS_EINVAL, "fs_shell_quad_batch: KT/FINT need u_e");
+        if (!KTe && ((want & FS_WANT_KT) || !k_cached))
+            return fail(FS_EINVAL, "fs_shell_quad_batch: KT/FINT need the KTe buffer (workspace for FINT unless Ke holds the linear blocks)");
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_quad_batch: fe is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
-        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
-        else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
-        FS_LAUNCH_CHECK("mitc4_k_kernel");
+        if (!k_cached) {
+            if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+            else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+            FS_LAUNCH_CHECK("mitc4_k_kernel");
+        }
         if (tiled)
-            hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E, KTe,
-                               (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+            hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E,
+                               k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
         else
             hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
                                E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled);

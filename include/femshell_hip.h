@@ -94,6 +94,10 @@ int fs_device_info(int device, char *name, int len, int *cu_count);
  *   u_e     [E][24]    element displacement vectors (global axes) or NULL (KT/FINT only)
  *   Ke/Me/KTe          outputs in `layout` (NULL if not wanted); fe [E][24]
  *   status  [E]        FS_ST_* bits (may be NULL)
+ * KT / FINT need the linear blocks K of the same elements.  They do not depend on u_e (the reference reads its cached
+ * MITC4.K, a cached_property), so a caller that kept them passes them back: FS_LAYOUT_SYMBLK_T16, FS_WANT_K clear and
+ * Ke != NULL make Ke an INPUT and skip the stiffness kernel (KTe may then be NULL for FINT alone).  Otherwise the
+ * stiffness kernel runs first, into KTe.
  */
 int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
                         int32_t n_props, const double *u_e, int64_t E, uint32_t want,

@@ -183,6 +183,17 @@ def test_c4_nl_cantilever_newton(oracle):
             print("C4 iterate", k, "f_int err", err, "element force", fscale, "|K||u|", terms)
             assert err <= 1e-12 * terms and err <= 1e-10 * fscale
     print("C4 ok: 10 re-assemblies of K_T and f_int,", mesh.conn.shape[0], "elements")
+    # cached linear blocks (default) against recomputing them every iterate: bitwise the same K_T and f_int
+    uk = torch.from_numpy((5e-3 * shape).reshape(-1)).to(asm.device)
+    assert asm.reuse_linear_blocks
+    Kc, fc = asm.assemble_tangent_and_forces(uk)
+    fc_only = asm.assemble_internal_forces(uk)
+    Kc_only = asm.assemble_tangent_stiffness(uk)
+    asm.reuse_linear_blocks = False
+    Kr, fr = asm.assemble_tangent_and_forces(uk)
+    asm.reuse_linear_blocks = True
+    assert bool((Kc.data == Kr.data).all()) and bool((fc == fr).all())
+    assert bool((fc_only == fr).all()) and bool((Kc_only.data == Kr.data).all())
     # the same re-assembly captured in one HIP graph: bitwise the same K_T and f_int, replay after replay
     step = asm.capture_tangent_and_forces()
     for k in (3, 7, 3):
