@@ -436,13 +436,15 @@ class MeshAssembler:
         ues = self._element_displacements(u)
         # the linear blocks do not depend on u: the tiled quad path hands the ones of the last K evaluation back to the
         # kernel instead of recomputing them every iterate (the reference reads its cached MITC4.K the same way)
-        cached = self.reuse_linear_blocks and self._layout == _lib.FS_LAYOUT_SYMBLK_T16 and self._K_blk is not None
+        tiled = self._layout == _lib.FS_LAYOUT_SYMBLK_T16
+        can = self.reuse_linear_blocks and self._K_blk is not None
+        group_cached = [can and (tiled or g["nn"] == 3) for g in self._groups]   # element-major quads recompute
         buf = None
-        if want_KT or not cached:
+        if want_KT or not all(group_cached):
             buf = torch.empty((self._plan.n_src_blocks, self.dofs_per_node ** 2), dtype=torch.float64, device=self.device)
         fparts = []
-        for g, ue in zip(self._groups, ues):
-            extra = {"K_lin": self._K_blk} if cached else {}
+        for g, ue, cached in zip(self._groups, ues, group_cached):
+            extra = {"K_lin": self._group_view(self._K_blk, g)} if cached else {}
             out = batch.shell_batch(g["nn"], g["xyz_d"], g["pid_d"], self._props_d, len(self._prop_table),
                                     want_K=False, status=False, validate=False, u_e=ue, want_KT=want_KT,
                                     want_F=want_F, KT_out=None if buf is None else self._group_view(buf, g),

@@ -106,8 +106,8 @@ NPAIR3 = 6
 
 def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense=False,
               status=True, validate=True, K_out=None, M_out=None, u_e=None, want_KT=False,
-              want_F=False, KT_out=None):
-    """MITC3+ element matrices for E triangles (fs_shell_tri_batch).
+              want_F=False, KT_out=None, K_lin=None):
+    """MITC3+ element matrices for E triangles (fs_shell_tri_batch).  K_lin: cached linear blocks, see quad_batch.
 
     xyz [E,3,3] f64 device.  Returns dict with 'K'/'M'/'KT' (FS_LAYOUT_SYMBLK [E,6,36] or dense
     [E,18,18]), 'f_int' [E,18] and 'status'."""
@@ -131,7 +131,12 @@ def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense
             raise ValueError("KT / f_int need the element displacement vectors u_e [E,18]")
         u_e = u_e.contiguous()
         assert u_e.dtype == torch.float64 and u_e.shape == (E, 18) and u_e.is_cuda
-        KT = _out_buf(KT_out, E, NPAIR3, dev)   # also the FINT workspace
+        cached = K_lin is not None and not want_K
+        if cached:
+            assert K_lin.dtype == torch.float64 and K_lin.is_cuda and K_lin.is_contiguous() and K_lin.numel() == E * NPAIR3 * 36
+            K = K_lin
+        if want_KT or not cached:
+            KT = _out_buf(KT_out, E, NPAIR3, dev)   # also the FINT workspace without K_lin
         F = torch.empty((E, 18), dtype=torch.float64, device=dev) if want_F else None
         want |= (_lib.FS_WANT_KT if want_KT else 0) | (_lib.FS_WANT_FINT if want_F else 0)
     _lib.check(lib.fs_shell_tri_batch(_lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev),
@@ -140,6 +145,8 @@ def tri_batch(xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, dense
                                       _lib.stream_ptr()), "fs_shell_tri_batch")
     if not want_KT:
         KT = None
+    if not want_K:
+        K = None
     if dense:
         K = expand_blocks(K, 3, 6) if K is not None else None
         M = expand_blocks(M, 3, 6) if M is not None else None

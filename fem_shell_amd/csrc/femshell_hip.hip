@@ -1726,8 +1726,9 @@ __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__
                                                       const int32_t *__restrict__ prop_id,
                                                       const fs_shell_prop *__restrict__ props,
                                                       const double *__restrict__ ue, int64_t E,
-                                                      double *__restrict__ kt, int want_kt,
+                                                      const double *k0, double *kt, int want_kt,
                                                       double *__restrict__ fe) {
+    // k0: the linear blocks K (read); kt: K_T (written when want_kt); they may be the same buffer (in place)
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     double x[3][3], u[3][6];
@@ -1751,6 +1752,7 @@ __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__
         for (int k = 0; k < 3; k++) Rc[2][k] = n[k] / l;
         cross3(Rc[2], Rc[0], Rc[1]);
     }
+    const double *bin = k0 + e * 216;
     double *blk = kt + e * 216;
     const int pidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     {
@@ -1783,7 +1785,7 @@ __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__
         for (int c = 0; c < 18; c++) (&w[0][0])[c] = 0.0;
         for (int i = 0; i < 3; i++)
             for (int j = i; j < 3; j++) {
-                const double *B = blk + pidx[i][j] * 36;
+                const double *B = bin + pidx[i][j] * 36;
                 for (int a = 0; a < 6; a++)
                     for (int b = 0; b < 6; b++) {
                         const double v = B[a * 6 + b];
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__
                 for (int bb = 0; bb < 2; bb++) {
                     double X[3][3], Y[3][3];
                     for (int a = 0; a < 3; a++)
-                        for (int b = 0; b < 3; b++) X[a][b] = blk[p * 36 + (3 * ba + a) * 6 + 3 * bb + b];
+                        for (int b = 0; b < 3; b++) X[a][b] = bin[p * 36 + (3 * ba + a) * 6 + 3 * bb + b];
                     for (int a = 0; a < 3; a++)
                         for (int b = 0; b < 3; b++) Y[a][b] = P[0][a] * X[0][b] + P[1][a] * X[1][b] + P[2][a] * X[2][b];
                     for (int a = 0; a < 3; a++)
@@ -2732,12 +2734,18 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
         return fail(FS_EINVAL, "fs_shell_tri_batch: kernels emit FS_LAYOUT_SYMBLK; use fs_blk_expand for dense");
     hipStream_t s = (hipStream_t)stream;
     if (want & (FS_WANT_KT | FS_WANT_FINT)) {
-        if (!u_e || !KTe) return fail(FS_EINVAL, "fs_shell_tri_batch: KT/FINT need u_e and the KTe buffer (workspace for FINT)");
+        // as in fs_shell_quad_batch: Ke given with FS_WANT_K clear = the cached linear blocks (input)
+        const bool k_cached = Ke && !(want & FS_WANT_K);
+        if (!u_e) return fail(FS_EINVAL, "fs_shell_tri_batch: KT/FINT need u_e");
+        if (!KTe && ((want & FS_WANT_KT) || !k_cached))
+            return fail(FS_EINVAL, "fs_shell_tri_batch: KT/FINT need the KTe buffer (workspace for FINT unless Ke holds the linear blocks)");
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_tri_batch: fe is null");
-        M3_LAUNCH(KTe);
-        FS_LAUNCH_CHECK("mitc3_k_kernel");
+        if (!k_cached) {
+            M3_LAUNCH(KTe);
+            FS_LAUNCH_CHECK("mitc3_k_kernel");
+        }
         hipLaunchKernelGGL(mitc3_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
-                           E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+                           E, k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
         FS_LAUNCH_CHECK("mitc3_nl_kernel");
     }
     if (want & FS_WANT_K) {

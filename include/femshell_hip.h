@@ -112,7 +112,8 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
  * element.  With u_e [E][18]: FS_WANT_KT / FS_WANT_FINT = update_configuration(u_e) +
  * compute_tangent_stiffness() / compute_internal_forces() (MITC3.py:1144-1832, MITC3_composite.py:496-621;
  * the reference rebuilds T() from the CURRENT coordinates x + u, :471-494 -- kept); KTe is also the
- * FINT workspace, fe [E][18].
+ * FINT workspace, fe [E][18].  As for the quads, Ke != NULL with FS_WANT_K clear passes the cached linear blocks in
+ * (input) and skips the stiffness kernel.
  * status: FS_ST_NAN_FRAME where the reference raises ValueError("Degenerate triangle").
  */
 int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,

@@ -333,3 +333,27 @@ def test_reference_mesh_protocol_duck_typed():
         asm2 = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.5}})
     assert any(issubclass(x.category, DeprecationWarning) for x in w)
     assert float(asm2._prop_table["h"][0]) == 0.02
+
+
+@pytest.mark.parametrize("kind", ["tri", "mixed"])
+def test_newton_reassembly_cached_linear_blocks(kind):
+    """K_T / f_int re-assembly with the cached linear blocks (default) against recomputing them every call: bitwise
+    equal on a MITC3+ mesh and on a mixed MITC3+/MITC4+ mesh (quads in the element-major layout recompute, triangles
+    read the cache)."""
+    from fem_shell_amd.assembler import MeshAssembler
+    mat = fsa.IsotropicMaterial("cant", 1.2e6, 0.3, 1.0)
+    if kind == "tri":
+        mesh = meshes.cylindrical_patch(5.0, 4.0, 60.0, 9, 7, triangular=True)
+    else:
+        base = meshes.cylindrical_patch(5.0, 4.0, 60.0, 9, 7)
+        mesh = meshes.ArrayMesh(base.coords, meshes.mixed_conn(9, 7))
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.05,
+                                            "nonlinear": True}})
+    rng = np.random.default_rng(9)
+    u = 1e-3 * rng.standard_normal(asm.dofs_count)
+    Kc, fc = asm.assemble_tangent_and_forces(u)
+    f_only = asm.assemble_internal_forces(u)
+    asm.reuse_linear_blocks = False
+    Kr, fr = asm.assemble_tangent_and_forces(u)
+    assert bool((Kc.data == Kr.data).all()) and bool((fc == fr).all()) and bool((f_only == fr).all())
+    assert float(Kr.data.abs().max()) > 0.0 and float(fr.abs().max()) > 0.0
