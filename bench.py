@@ -394,8 +394,8 @@ def newton_leg(torch, steps=10):
         out[tag] = {"elements": E, "ms_per_reassembly": ms, "reassemblies_per_s": 1e3 / ms,
                     "elements_per_s": E / (ms * 1e-3), "ms_per_reassembly_hip_graph": gms}
         del asm
-    out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate: gather u_e, element K kernel, TL tangent / " \
-                  "internal-force kernel, CSR assembly, vector scatter"
+    out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate: gather u_e, TL tangent / internal-force kernel on " \
+                  "the cached linear blocks, CSR assembly, vector scatter"
     return out
 
 
