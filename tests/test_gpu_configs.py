@@ -3,7 +3,7 @@
   C2  pinched hemisphere (18 degree cut-out) 256 x 256, MITC4+ and MITC3+          (configs[1])
   C3  blade-like laminate tube 512 x 128, 192 property sets, K, M, lumped mass     (configs[2])
   C4  NL cantilever 400 x 40, K_T / f_int re-assembled over Newton iterates        (configs[3])
-  C5  one GPU's 400 x 3125 strip of the 10 M-element laminate plate               (configs[4])
+  C5  one GPU's 400 x 3125 strip, the whole 10 M-element plate and the 1 M-element HEXA8 block on one GPU   (configs[4])
 Properties: closed-form nnz, CSR rows of sampled nodes against the oracle's element matrices summed in element
 order (1e-12), symmetry (x.Ky == y.Kx), rigid translations in the null space of K, total mass from the assembled
 and the lumped M, bitwise repeatability, K_T(0) == K and f_int(0) == 0."""
@@ -276,3 +276,60 @@ def test_c5_plate_10m_one_gpu(oracle):
         c1, r1 = block_row(K, ip, int(I))
         c2, r2 = block_row(Ks, ips, int(I))
         assert np.array_equal(c1, c2) and np.array_equal(r1, r2)
+
+
+def test_c5_hexa8_block_full_size(oracle):
+    """configs[4]'s solid block at its FULL size on one GPU: 128 x 128 x 64 = 1 048 576 jittered HEXA8 (orthotropic C),
+    3.2 M dofs.  Closed-form nnz of the 27-point node graph, sampled block rows against the oracle (element order),
+    K_IJ == K_JI^T on the samples, total mass from M, bitwise repeatability."""
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.properties import solid_row
+    nx, ny, nz = 128, 128, 64
+    ids = np.arange((nx + 1) * (ny + 1) * (nz + 1), dtype=np.int64).reshape(nz + 1, ny + 1, nx + 1)
+    Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
+    coords = np.stack([X, Y, Z], -1).reshape(-1, 3) * 1e-3
+    coords += (meshes.hash_uniform(np.arange(coords.size), 5).reshape(-1, 3) - 0.5) * 1e-4
+    n = lambda dz, dy, dx: ids[dz:nz + dz, dy:ny + dy, dx:nx + dx]
+    conn = np.stack([n(0, 0, 0), n(0, 0, 1), n(0, 1, 1), n(0, 1, 0), n(1, 0, 0), n(1, 0, 1), n(1, 1, 1), n(1, 1, 0)],
+                    -1).reshape(-1, 8)
+    mat = util.t300()
+    asm = MeshAssembler(meshes.ArrayMesh(coords, conn), {"elements": {"element_family": ElementFamily.SOLID, "material": mat}})
+    K = asm.assemble_stiffness_matrix()
+    per_axis = lambda m: 3 * (m + 1) - 2                   # sum over the nodes of an axis of their neighbours on it
+    assert K.nnz == 9 * per_axis(nx) * per_axis(ny) * per_axis(nz)
+    props = solid_row(mat, None)[None]
+    rng = np.random.default_rng(8)
+    N = coords.shape[0]
+    nodes = np.unique(np.concatenate([[0, N - 1], rng.choice(N, 14, replace=False)]))
+    ip = K.indptr.cpu().numpy()
+    touch = np.flatnonzero(np.isin(conn, nodes).any(axis=1))
+    Ke = oracle.solid_batch(8, coords[conn[touch]], np.zeros(touch.size, np.int32), props)["K"]
+    worst = scale = 0.0
+    for I in nodes:
+        lo, hi = int(ip[3 * I]), int(ip[3 * I + 3])
+        m = int(ip[3 * I + 1]) - lo
+        cols = K.indices[lo:lo + m].cpu().numpy()[::3] // 3
+        got = K.data[lo:hi].cpu().numpy().reshape(3, m)
+        ref = np.zeros((3, m))
+        for k, e in enumerate(touch):                       # element order
+            loc = np.flatnonzero(conn[e] == I)
+            if loc.size:
+                i = int(loc[0])
+                for j in range(8):
+                    c = int(np.searchsorted(cols, conn[e, j]))
+                    ref[:, 3 * c:3 * c + 3] += Ke[k][3 * i:3 * i + 3, 3 * j:3 * j + 3]
+        worst, scale = max(worst, np.abs(got - ref).max()), max(scale, np.abs(ref).max())
+        for c, J in enumerate(cols[:6]):                    # K_IJ == K_JI^T
+            lo2 = int(ip[3 * J]); m2 = int(ip[3 * J + 1]) - lo2
+            cols2 = K.indices[lo2:lo2 + m2].cpu().numpy()[::3] // 3
+            blk2 = K.data[lo2:int(ip[3 * J + 3])].cpu().numpy().reshape(3, m2)
+            cj = int(np.searchsorted(cols2, I))
+            assert np.abs(got[:, 3 * c:3 * c + 3] - blk2[:, 3 * cj:3 * cj + 3].T).max() <= 1e-12 * np.abs(ref).max()
+    print("C5 HEXA8 block: sampled rows vs oracle", worst / scale, "nnz", K.nnz)
+    assert worst <= 1e-12 * scale
+    again = asm.assemble_stiffness_matrix(recompute=True)
+    assert bool((again.data == K.data).all())
+    M = asm.assemble_mass_matrix()
+    vol = nx * ny * nz * 1e-9
+    total = float(M.data.sum()) / 3.0                        # each direction carries the whole mass
+    assert abs(total / (mat.rho * vol) - 1.0) < 1e-3         # jitter changes the volume of boundary cells only
