@@ -45,6 +45,17 @@ def timeit(dd, n=20):
 
 
 print(f"block order: {timeit(desc.contiguous()):.3f} ms")
+# order by the source block of the first contribution inside windows: adjacent lanes then read adjacent source blocks
+c0 = desc[:, 2] >> 1
+for W in (126, 1008, 8064, 64512):
+    key = (torch.arange(nblk, device=desc.device) // W) * (1 << 40) + c0
+    perm = torch.argsort(key, stable=True)
+    dd = desc[perm].contiguous()
+    ms = timeit(dd)
+    data.zero_()
+    run(dd)
+    torch.cuda.synchronize()
+    print(f"sorted by first source block, window {W:6d}: {ms:.3f} ms  bitwise_equal={torch.equal(data, ref)}", flush=True)
 idx = torch.arange(nblk, device=desc.device)
 for W in [int(a) for a in sys.argv[1:]] or [28, 56, 126, 252, 1008, 4032]:
     key = (idx // W) * 8 + cnt.clamp(max=7)
