@@ -207,7 +207,7 @@ def measured_peaks(torch):
 
 def c5_full_leg(torch, steps=5):
     """configs[4]'s shell plate at its FULL size on ONE GPU: 3200 x 3125 = 10 M MITC4+ laminate elements, 60 M dofs,
-    nnz 3.24e9 (about 110 GB of device memory).  Step = element K kernel + CSR assembly, as in `value`; skipped
+    nnz 3.24e9 (about 103 GB of device memory).  Step = element K kernel + CSR assembly, as in `value`; skipped
     when less than 140 GB are free."""
     from fem_shell_amd import meshes
     from fem_shell_amd.assembler import MeshAssembler

@@ -266,7 +266,9 @@ class MeshAssembler:
         self._plan_d = p.to_device(dev)
         self._desc_d = self._plan_d["desc"]
         self._sdesc_d = None     # symmetric descriptors: built on first use (use_symmetric)
-        self.refresh_element_matrices()
+        # K of every element now (this is also the geometry check of the reference's constructor loop); M on first use
+        # (assemble_mass_matrix / _me_array): the reference evaluates both up front, here that would only cost memory
+        self.refresh_element_matrices(want_K=True, want_M=False)
 
     def _group_view(self, buf, g):
         dd = self.dofs_per_node ** 2
@@ -342,9 +344,14 @@ class MeshAssembler:
         return out
 
     _ke_array = property(lambda self: self._dense(self._K_blk, True))
-    _me_array = property(lambda self: self._dense(self._M_blk, True))
+    def _mass_blocks(self):
+        if self._M_blk is None:
+            self.refresh_element_matrices(want_K=False, want_M=True)
+        return self._M_blk
+
+    _me_array = property(lambda self: self._dense(self._mass_blocks(), True))
     _ke_list = property(lambda self: self._dense(self._K_blk, False))
-    _me_list = property(lambda self: self._dense(self._M_blk, False))
+    _me_list = property(lambda self: self._dense(self._mass_blocks(), False))
 
     @property
     def _dofs_list(self):
