@@ -62,3 +62,20 @@ def test_mitc3_degenerate_and_empty(oracle):
     assert out["status"][0] == 1 and out["status"][1] == 0
     out = _run(np.zeros((0, 3, 3)), np.zeros(0, np.int32), table)
     assert out["K"].shape == (0, 18, 18)
+
+
+def test_wave_kernel_equals_thread_per_pair_kernel(tmp_path):
+    """mitc3_k_lds_kernel (shipped) against the thread-per-pair statement of the same arithmetic (FEMSHELL_M3_SIMPLE=1,
+    read once per process: two child processes) over 32 batch sizes with ragged last waves; 1e-13 relative."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "exp", "m3_fuzz.py")
+    a, b = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    env = dict(os.environ, FEMSHELL_M3_SIMPLE="1")
+    subprocess.run([sys.executable, script, a], check=True, cwd=root, env=env, timeout=120, capture_output=True)
+    env.pop("FEMSHELL_M3_SIMPLE")
+    subprocess.run([sys.executable, script, b], check=True, cwd=root, env=env, timeout=120, capture_output=True)
+    r = subprocess.run([sys.executable, script, "--cmp", a, b], cwd=root, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
