@@ -204,3 +204,34 @@ def test_sym_descriptors_cover_every_block_once():
     t = sym["dst_t"] >= 0
     lookup = {int(d): int(s) for d, s in zip(full["dst"], full["stride"])}
     assert all(lookup[int(d)] == int(st) for d, st in zip(sym["dst_t"][t], sym["stride_t"][t]))
+
+
+def test_csr_matrix_exports(monkeypatch):
+    """CsrMatrix.to_scipy / to_petsc (the hand-over to the unchanged solver layers): petsc4py is absent
+    here, so to_petsc must raise ImportError; with a stand-in PETSc module it must call createAIJWithArrays with
+    PETSc.IntType index arrays and the values."""
+    import sys
+    import types
+    import torch
+    from fem_shell_amd.assembler import CsrMatrix
+    A = CsrMatrix(torch.tensor([0, 2, 3], dtype=torch.int64), torch.tensor([0, 1, 1], dtype=torch.int32),
+                  torch.tensor([4.0, 1.0, 3.0], dtype=torch.float64), (2, 2))
+    S = A.to_scipy()
+    assert S.shape == (2, 2) and S.nnz == 3 and np.array_equal(S.toarray(), [[4.0, 1.0], [0.0, 3.0]]) and A.nnz == 3
+    monkeypatch.setitem(sys.modules, "petsc4py", None)
+    with pytest.raises(ImportError):
+        A.to_petsc()
+    calls = {}
+
+    class Mat:
+        def createAIJWithArrays(self, size, csr, comm=None):
+            calls["size"], calls["csr"], calls["comm"] = size, csr, comm
+            return self
+
+    fake = types.ModuleType("petsc4py")
+    fake.PETSc = types.SimpleNamespace(IntType=np.int32, Mat=Mat)
+    monkeypatch.setitem(sys.modules, "petsc4py", fake)
+    out = A.to_petsc(comm="world")
+    ip, ix, data = calls["csr"]
+    assert isinstance(out, Mat) and calls["size"] == (2, 2) and calls["comm"] == "world"
+    assert ip.dtype == np.int32 and ix.dtype == np.int32 and np.array_equal(ip, [0, 2, 3]) and np.array_equal(data, [4.0, 1.0, 3.0])
