@@ -135,6 +135,12 @@ class DistributedPlan:
             self.send_idx[q] = self._value_index(pr, pr, X, P, m, kk, ll)
         for q, pr in recv_pairs.items():
             self.recv_idx[q] = self._value_index(pr, pr, X, P, m, kk, ll)
+        # --- vector exchange (f_int, load vectors): d values per interface node, nodes in ascending global id
+        ar = np.arange(d, dtype=np.int64)
+        self.vsend_idx = {q: (np.searchsorted(X, np.unique(pr.reshape(-1, 2)[:, 0]))[:, None] * d + ar).reshape(-1)
+                          for q, pr in send_pairs.items()}
+        self.vrecv_idx = {q: (np.searchsorted(X, np.unique(pr[:, 0]))[:, None] * d + ar).reshape(-1)
+                          for q, pr in recv_pairs.items()}
 
     @staticmethod
     def _value_index(pairs, _unused, X, P, m, kk, ll):
@@ -171,6 +177,17 @@ class DistributedPlan:
         return out
 
 
+    def exchange_vector_host(self, f: np.ndarray) -> np.ndarray:
+        """NumPy stand-in of the vector exchange: rows this rank does not own go to their owner, which adds them in
+        ascending neighbour-rank order."""
+        send = {q: f[idx] for q, idx in self.vsend_idx.items()}
+        recv = _exchange(send, self.neighbors, dtype=torch.float64)
+        out = f.copy()
+        for q in sorted(recv):
+            out[self.vrecv_idx[q]] = out[self.vrecv_idx[q]] + recv[q]
+        return out
+
+
 class DistributedAssembler:
     """MeshAssembler over this rank's element block + RCCL interface exchange.
 
@@ -204,6 +221,10 @@ class DistributedAssembler:
         self._recv = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.recv_idx.items()}
         self._sbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._send.items()}
         self._rbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._recv.items()}
+        self._vsend = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.vsend_idx.items()}
+        self._vrecv = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.vrecv_idx.items()}
+        self._vsbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._vsend.items()}
+        self._vrbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._vrecv.items()}
         self._lib, self._libmod = _lib.load(), _lib
         self._prop_table, self._prop_id = self.local._prop_table, self.local._prop_id
         self.owned_rows = np.repeat(self.dplan.owned, 6)
@@ -236,27 +257,31 @@ class DistributedAssembler:
         return A
 
     def _exchange_on_current_stream(self, A):
+        self._halo(A.data, self._send, self._recv, self._sbuf, self._rbuf)
+        return A
+
+    def _halo(self, data, send, recv, sbuf, rbuf):
+        """pack -> grouped send / recv -> add, on the current stream (matrix values or vectors)."""
         L, lib = self._libmod, self._lib
         s = L.stream_ptr()
-        for q, idx in self._send.items():
-            L.check(lib.fs_halo_pack(L.ptr(A.data), L.ptr(idx), idx.numel(), L.ptr(self._sbuf[q]), s), "fs_halo_pack")
+        for q, idx in send.items():
+            L.check(lib.fs_halo_pack(L.ptr(data), L.ptr(idx), idx.numel(), L.ptr(sbuf[q]), s), "fs_halo_pack")
         if dist.get_backend() == "nccl":     # RCCL: grouped ncclSend/ncclRecv on device buffers
-            sb, rb = self._sbuf, self._rbuf
+            sb, rb = sbuf, rbuf
         else:                                # gloo rehearsal (one-GPU box): stage through the host
-            sb = {q: b.cpu() for q, b in self._sbuf.items()}
-            rb = {q: torch.empty(b.numel(), dtype=torch.float64) for q, b in self._rbuf.items()}
+            sb = {q: b.cpu() for q, b in sbuf.items()}
+            rb = {q: torch.empty(b.numel(), dtype=torch.float64) for q, b in rbuf.items()}
         ops = [dist.P2POp(dist.isend, sb[q], q) for q in sorted(sb)] + \
               [dist.P2POp(dist.irecv, rb[q], q) for q in sorted(rb)]
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        if rb is not self._rbuf:
+        if rb is not rbuf:
             for q in rb:
-                self._rbuf[q].copy_(rb[q])
-        for q in sorted(self._recv):
-            idx = self._recv[q]
-            L.check(lib.fs_halo_add(L.ptr(self._rbuf[q]), L.ptr(idx), idx.numel(), L.ptr(A.data), s), "fs_halo_add")
-        return A
+                rbuf[q].copy_(rb[q])
+        for q in sorted(recv):
+            idx = recv[q]
+            L.check(lib.fs_halo_add(L.ptr(rbuf[q]), L.ptr(idx), idx.numel(), L.ptr(data), s), "fs_halo_add")
 
     def assemble_stiffness_matrix(self, recompute=False):
         """Owned rows of the returned CSR (see `owned_rows`) hold the globally assembled values;
@@ -267,3 +292,24 @@ class DistributedAssembler:
     def assemble_mass_matrix(self, recompute=False):
         self.finish()
         return self._exchange(self.local.assemble_mass_matrix(recompute=recompute))
+
+    # --- Newton re-assembly (SURVEY.md 8a "New", 8e: vectors use the same plan with d values per interface node) ---
+    def _exchange_vector(self, f):
+        self.finish()
+        self._halo(f, self._vsend, self._vrecv, self._vsbuf, self._vrbuf)
+        return f
+
+    def assemble_tangent_stiffness(self, u):
+        """u: displacements of this rank's extended node set (consistent on shared nodes).  Owned rows hold K_T."""
+        self.finish()
+        return self._exchange(self.local.assemble_tangent_stiffness(u))
+
+    def assemble_internal_forces(self, u):
+        """Owned rows of the returned device vector hold the globally summed f_int."""
+        return self._exchange_vector(self.local.assemble_internal_forces(u))
+
+    def assemble_tangent_and_forces(self, u):
+        self.finish()
+        K, f = self.local.assemble_tangent_and_forces(u)
+        f = self._exchange_vector(f)        # on the caller's stream; the matrix exchange may run on the side stream
+        return self._exchange(K), f

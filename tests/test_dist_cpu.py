@@ -64,6 +64,18 @@ def _worker(rank, world, port, nx, ny, q):
                 got = data[ip[r]:ip[r + 1]]
                 assert np.abs(got - ref).max() <= 1e-13 * np.abs(gdata).max(), (rank, I, k)
                 nchk += 1
+        # vector exchange (f_int / load vectors): element vectors summed per rank, interface rows exchanged
+        rng = np.random.default_rng(100)
+        fe_g = rng.standard_normal((g.conn.shape[0], 24))               # one "element force" per global element
+        gdofs = (g.conn[:, :, None] * 6 + np.arange(6)).reshape(g.conn.shape[0], -1)
+        f_ref = np.zeros(g.node_count * 6)
+        np.add.at(f_ref, gdofs.reshape(-1), fe_g.reshape(-1))
+        ldofs = (dp.conn_x[:, :, None] * 6 + np.arange(6)).reshape(loc.conn.shape[0], -1)
+        f_loc = np.zeros(X.shape[0] * 6)
+        np.add.at(f_loc, ldofs.reshape(-1), fe_g[eg].reshape(-1))
+        f_loc = dp.exchange_vector_host(f_loc)
+        for I in np.flatnonzero(dp.owned):
+            assert np.abs(f_loc[6 * I:6 * I + 6] - f_ref[6 * X[I]:6 * X[I] + 6]).max() <= 1e-13 * np.abs(f_ref).max(), (rank, I)
         owned_g = torch.zeros(g.node_count, dtype=torch.int64)
         owned_g[torch.from_numpy(X[dp.owned])] = 1
         dist.all_reduce(owned_g)

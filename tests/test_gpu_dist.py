@@ -71,3 +71,69 @@ def test_ranks_share_one_gpu(world, overlap):
     for rank, n, err in res:
         assert err is None, err
     assert sum(n for _, n, _ in res) == 6 * (9 * world + 1) * 8
+
+
+def _worker_newton(rank, world, port, nx, ny, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fem_shell_amd as fsa
+        from fem_shell_amd import meshes
+        from fem_shell_amd.assembler import MeshAssembler
+        from fem_shell_amd.dist import DistributedAssembler
+        from fem_shell_amd.elements import ElementFamily
+        mat = fsa.IsotropicMaterial("cant", 1.2e6, 0.3, 1.0)
+        model = {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.1, "nonlinear": True}}
+        g = meshes.jittered_plate(nx * world, ny, cell=0.1, n_sets=1)
+        ug = 1e-3 * np.random.default_rng(5).standard_normal(g.node_count * 6)       # the same field on every rank
+        serial = MeshAssembler(g, model)
+        Kg, fg = serial.assemble_tangent_and_forces(ug)
+        Kg, fg = Kg.to_scipy(), fg.cpu().numpy()
+        loc = meshes.jittered_plate(nx, ny, cell=0.1, n_sets=1, x_offset_cells=rank * nx)
+        da = DistributedAssembler(loc, model, strip=(rank, world, nx, ny), overlap=True)
+        X = da.dplan.nodes_g
+        ul = ug.reshape(-1, 6)[X].reshape(-1)
+        A, f = da.assemble_tangent_and_forces(ul)
+        f_only = da.assemble_internal_forces(ul)
+        A_only = da.assemble_tangent_stiffness(ul)
+        da.finish()
+        ip, ix, data = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy()
+        assert bool((A_only.data == A.data).all()) and bool((f_only == f).all())
+        f = f.cpu().numpy()
+        worstK = worstF = 0.0
+        for r in np.flatnonzero(da.owned_rows):
+            gr = 6 * X[r // 6] + r % 6
+            cols = 6 * X[ix[ip[r]:ip[r + 1]] // 6] + ix[ip[r]:ip[r + 1]] % 6
+            assert np.array_equal(cols, Kg.indices[Kg.indptr[gr]:Kg.indptr[gr + 1]])
+            worstK = max(worstK, np.abs(data[ip[r]:ip[r + 1]] - Kg.data[Kg.indptr[gr]:Kg.indptr[gr + 1]]).max())
+            worstF = max(worstF, abs(f[r] - fg[gr]))
+        assert worstK <= 1e-13 * np.abs(Kg.data).max() and worstF <= 1e-12 * np.abs(fg).max(), (worstK, worstF)
+        q.put((rank, int(da.owned_rows.sum()), None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_newton_reassembly():
+    """K_T(u) and f_int(u) over 3 ranks sharing the GPU: matrix interface exchange (side stream) + vector exchange;
+    owned rows equal the serial re-assembly."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_worker_newton, args=(r, world, port, 6, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 6 * (6 * world + 1) * 6
