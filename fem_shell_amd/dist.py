@@ -85,8 +85,9 @@ class DistributedPlan:
         self.rank, self.world, self.d = rank, world, int(d)
         conn = np.asarray(conn, dtype=np.int64)
         l2g = np.asarray(l2g, dtype=np.int64)
-        gconn = l2g[conn]
-        mine = np.unique(gconn)
+        pad = conn < 0                                     # mixed node counts: rows padded with trailing -1
+        gconn = np.where(pad, -1, l2g[np.where(pad, 0, conn)])
+        mine = np.unique(gconn[~pad])
         # --- who else holds my nodes?  owner = lowest rank holding the node
         all_nodes = _allgather_arrays(mine)
         owner = np.full(mine.shape[0], rank, dtype=np.int64)
@@ -100,7 +101,7 @@ class DistributedPlan:
                 owner = np.where(shared & (q < owner), q, owner)
         self.neighbors = sorted(sharers)
         # --- local node graph in global ids (provisional plan on the compact local numbering)
-        loc = np.searchsorted(mine, gconn)
+        loc = np.where(pad, -1, np.searchsorted(mine, np.where(pad, mine[0], gconn)))
         p0 = BlockPlan(loc, mine.shape[0], d)
         gI, gJ = mine[p0.blk_row], mine[p0.nbr]
         ghost_row = owner[p0.blk_row] != rank
@@ -116,7 +117,7 @@ class DistributedPlan:
         extra_nodes = [v[:, 1] for v in recv_pairs.values()]
         self.nodes_g = np.unique(np.concatenate([mine] + extra_nodes)) if extra_nodes else mine
         X = self.nodes_g
-        self.conn_x = np.searchsorted(X, gconn)
+        self.conn_x = np.where(pad, -1, np.searchsorted(X, np.where(pad, X[0], gconn)))
         extra = [np.searchsorted(X, v) for v in recv_pairs.values()]
         self.plan = BlockPlan(self.conn_x, X.shape[0], d, np.concatenate(extra) if extra else None,
                               tiled=can_tile(self.conn_x, d))
@@ -207,7 +208,9 @@ class DistributedAssembler:
             gx = np.arange(nx + 1, dtype=np.int64) + rank * nx
             gy = np.arange(ny + 1, dtype=np.int64)
             l2g = (gy[:, None] * (world * nx + 1) + gx[None, :]).reshape(-1)
-        self.dplan = DistributedPlan(mesh.conn, l2g, 6)
+        from .elements import ElementFamily
+        d = 3 if model["elements"]["element_family"] == ElementFamily.SOLID else 6
+        self.dplan = DistributedPlan(mesh.conn, l2g, d)
         # the local assembler works on the extended node set (ghost columns appended in id order)
         from .meshes import ArrayMesh
         X = self.dplan.nodes_g
@@ -227,7 +230,7 @@ class DistributedAssembler:
         self._vrbuf = {q: torch.empty(i.numel(), dtype=torch.float64, device=dev) for q, i in self._vrecv.items()}
         self._lib, self._libmod = _lib.load(), _lib
         self._prop_table, self._prop_id = self.local._prop_table, self.local._prop_id
-        self.owned_rows = np.repeat(self.dplan.owned, 6)
+        self.owned_rows = np.repeat(self.dplan.owned, d)
         self.overlap = bool(overlap)
         self._comm = torch.cuda.Stream(device=dev) if self.overlap else None
         self._pending = None
@@ -285,7 +288,7 @@ class DistributedAssembler:
 
     def assemble_stiffness_matrix(self, recompute=False):
         """Owned rows of the returned CSR (see `owned_rows`) hold the globally assembled values;
-        column j of the local matrix is global DOF 6*nodes_g[j//6] + j%6."""
+        column j of the local matrix is global DOF d*nodes_g[j//d] + j%d (d = 6 shells, 3 solids)."""
         self.finish()
         return self._exchange(self.local.assemble_stiffness_matrix(recompute=recompute))
 
@@ -313,3 +316,13 @@ class DistributedAssembler:
         K, f = self.local.assemble_tangent_and_forces(u)
         f = self._exchange_vector(f)        # on the caller's stream; the matrix exchange may run on the side stream
         return self._exchange(K), f
+
+    # --- the other assembler products: same two exchanges -------------------------------------------------
+    def assemble_load_vector(self, load_condition):
+        """Solids: body-load vector (core/assembler.py:338-384), owned rows globally summed."""
+        return self._exchange_vector(self.local.assemble_load_vector(load_condition))
+
+    def assemble_geometric_stiffness(self, *args, **kw):
+        """core/assembler.py:386-516 on this rank's elements (stress_field keyed by LOCAL element ids, or omega)."""
+        self.finish()
+        return self._exchange(self.local.assemble_geometric_stiffness(*args, **kw))

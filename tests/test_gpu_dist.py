@@ -137,3 +137,72 @@ def test_distributed_newton_reassembly():
     for rank, n, err in res:
         assert err is None, err
     assert sum(n for _, n, _ in res) == 6 * (6 * world + 1) * 6
+
+
+def _worker_solid(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fem_shell_amd import meshes
+        from fem_shell_amd.assembler import MeshAssembler
+        from fem_shell_amd.dist import DistributedAssembler
+        from fem_shell_amd.elements import ElementFamily
+        from tests import util
+        nx, ny, nz = 3 * world, 3, 2
+        ids = np.arange((nx + 1) * (ny + 1) * (nz + 1)).reshape(nz + 1, ny + 1, nx + 1)
+        Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
+        coords = np.stack([X, Y, Z], -1).reshape(-1, 3) + 0.05 * np.random.default_rng(4).uniform(-1, 1, (ids.size, 3))
+        n = lambda dz, dy, dx: ids[dz:nz + dz, dy:ny + dy, dx:nx + dx]
+        hexa = np.stack([n(0, 0, 0), n(0, 0, 1), n(0, 1, 1), n(0, 1, 0), n(1, 0, 0), n(1, 0, 1), n(1, 1, 1), n(1, 1, 0)], -1)
+        model = {"elements": {"element_family": ElementFamily.SOLID, "material": util.t300()}}
+        body = SimpleNamespace(value=np.array([0.2, -1.0, -9.81]))
+        serial = MeshAssembler(meshes.ArrayMesh(coords, hexa.reshape(-1, 8)), model)
+        Kg = serial.assemble_stiffness_matrix().to_scipy()
+        fg = serial.assemble_load_vector(body).cpu().numpy()
+        mine = hexa[:, :, 3 * rank:3 * rank + 3].reshape(-1, 8)          # this rank's x-slab of bricks
+        l2g = np.unique(mine)
+        loc = meshes.ArrayMesh(coords[l2g], np.searchsorted(l2g, mine))
+        da = DistributedAssembler(loc, model, l2g=l2g, overlap=True)
+        A = da.assemble_stiffness_matrix(recompute=True)
+        f = da.assemble_load_vector(body)
+        da.finish()
+        ip, ix, data, f = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy(), f.cpu().numpy()
+        Xg = da.dplan.nodes_g
+        worstK = worstF = 0.0
+        for r in np.flatnonzero(da.owned_rows):
+            gr = 3 * Xg[r // 3] + r % 3
+            cols = 3 * Xg[ix[ip[r]:ip[r + 1]] // 3] + ix[ip[r]:ip[r + 1]] % 3
+            assert np.array_equal(cols, Kg.indices[Kg.indptr[gr]:Kg.indptr[gr + 1]])
+            worstK = max(worstK, np.abs(data[ip[r]:ip[r + 1]] - Kg.data[Kg.indptr[gr]:Kg.indptr[gr + 1]]).max())
+            worstF = max(worstF, abs(f[r] - fg[gr]))
+        assert worstK <= 1e-13 * np.abs(Kg.data).max() and worstF <= 1e-13 * np.abs(fg).max(), (worstK, worstF)
+        q.put((rank, int(da.owned_rows.sum()), None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_solid_block():
+    """configs[4]'s solid block is element-partitioned too: HEXA8 x-slabs over 2 ranks (3 dofs per node), K and the
+    body-load vector; owned rows equal the serial assembly."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker_solid, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 3 * (3 * world + 1) * 4 * 3
