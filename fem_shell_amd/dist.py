@@ -65,6 +65,21 @@ def _exchange(send: Dict[int, np.ndarray], peers, dtype=torch.int64):
     return {p: rbuf[p].cpu().numpy() for p in rbuf}
 
 
+def local_block(mesh, rank, world):
+    """Element-block partition of any ArrayMesh: rank r takes the r-th contiguous block of the mesh's
+    element order (structured meshes: strips; unstructured: blocks of whatever locality-preserving order the mesh
+    was numbered in, e.g. the reference's RCM ordering, core/mesh/model.py:229-321).  Returns (local ArrayMesh over
+    the nodes its elements touch, l2g = their global node indices) -- the inputs of DistributedAssembler."""
+    from .meshes import ArrayMesh
+    E = mesh.conn.shape[0]
+    lo, hi = (E * rank) // world, (E * (rank + 1)) // world
+    conn = mesh.conn[lo:hi]
+    l2g = np.unique(conn[conn >= 0])
+    loc = np.where(conn >= 0, np.searchsorted(l2g, np.where(conn >= 0, conn, l2g[0])), -1)
+    set_id = None if getattr(mesh, "set_id", None) is None else mesh.set_id[lo:hi]
+    return ArrayMesh(mesh.coords[l2g], loc, set_id, getattr(mesh, "set_names", None)), l2g
+
+
 class DistributedPlan:
     """Symbolic phase of the distributed assembly for one rank.
 

@@ -206,3 +206,61 @@ def test_distributed_solid_block():
     for rank, n, err in res:
         assert err is None, err
     assert sum(n for _, n, _ in res) == 3 * (3 * world + 1) * 4 * 3
+
+
+def _worker_blocks(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fem_shell_amd as fsa
+        from fem_shell_amd import meshes
+        from fem_shell_amd.assembler import MeshAssembler
+        from fem_shell_amd.dist import DistributedAssembler, local_block
+        from fem_shell_amd.elements import ElementFamily
+        g = meshes.sphere_patch(10.0, 18.0, 90.0, 90.0, 10, triangular=True)    # 200 MITC3+ triangles
+        model = {"elements": {"element_family": ElementFamily.SHELL, "thickness": 0.04,
+                              "material": fsa.IsotropicMaterial("s", 6.825e7, 0.3, 1.0)}}
+        serial = MeshAssembler(g, model)
+        Kg, Mg = serial.assemble_stiffness_matrix().to_scipy(), serial.assemble_mass_matrix().to_scipy()
+        loc, l2g = local_block(g, rank, world)
+        assert loc.element_count in (66, 67) and np.array_equal(loc.coords, g.coords[l2g])
+        da = DistributedAssembler(loc, model, l2g=l2g)
+        X = da.dplan.nodes_g
+        for A, ref in ((da.assemble_stiffness_matrix(recompute=True), Kg), (da.assemble_mass_matrix(recompute=True), Mg)):
+            ip, ix, data = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy()
+            worst = 0.0
+            for r in np.flatnonzero(da.owned_rows):
+                gr = 6 * X[r // 6] + r % 6
+                cols = 6 * X[ix[ip[r]:ip[r + 1]] // 6] + ix[ip[r]:ip[r + 1]] % 6
+                assert np.array_equal(cols, ref.indices[ref.indptr[gr]:ref.indptr[gr + 1]])
+                worst = max(worst, np.abs(data[ip[r]:ip[r + 1]] - ref.data[ref.indptr[gr]:ref.indptr[gr + 1]]).max())
+            assert worst <= 1e-13 * np.abs(ref.data).max(), worst
+        q.put((rank, int(da.owned_rows.sum()), None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_element_blocks_of_any_mesh():
+    """local_block(): contiguous element blocks of a triangulated hemisphere patch over 3 ranks (interfaces are not
+    straight lines: a block boundary cuts through a row of triangles); K and M owned rows equal the serial result."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_worker_blocks, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 6 * 121
