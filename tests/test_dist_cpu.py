@@ -102,3 +102,70 @@ def test_distributed_plan_matches_serial(world):
     for rank, n, err in res:
         assert err is None, err
         assert n > 0
+
+
+def _worker_quadrants(rank, world, port, nx, ny, q):
+    """2 x 2 element quadrants: the centre node belongs to all four ranks, edge-interface nodes to two."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fem_shell_amd as fsa
+        from fem_shell_amd import meshes
+        from fem_shell_amd.dist import DistributedPlan
+        from fem_shell_amd.symbolic import BlockPlan
+        from oracle import oracle as O
+        from tests import util
+        props = fsa.build_prop_table(util.standard_props())
+        g = meshes.jittered_plate(nx, ny, n_sets=8)
+        gpid = g.set_id.astype(np.int32)
+        Kg, _ = O.mitc4_K_batch(g.coords[g.conn], gpid, props)
+        gplan = BlockPlan(g.conn, g.node_count, 6)
+        gdata = util.host_block_assemble(gplan, util.pack_symblk(Kg))
+        gip, gix = gplan.host_pattern()
+        ex, ey = np.meshgrid(np.arange(nx), np.arange(ny))
+        quadrant = ((ey >= ny // 2) * 2 + (ex >= nx // 2)).reshape(-1)
+        eg = np.flatnonzero(quadrant == rank)                               # global element ids, ascending
+        l2g = np.unique(g.conn[eg])
+        conn = np.searchsorted(l2g, g.conn[eg])
+        dp = DistributedPlan(conn, l2g, 6)
+        assert len(dp.neighbors) == 3                                       # every quadrant touches the other three
+        Kl, _ = O.mitc4_K_batch(g.coords[g.conn[eg]], gpid[eg], props)
+        data = util.host_block_assemble(dp.plan, util.pack_symblk(Kl, tiled=dp.plan.tiled))
+        data = dp.exchange_host(data)
+        ip, ix = dp.plan.host_pattern()
+        X = dp.nodes_g
+        nchk = 0
+        for I in np.flatnonzero(dp.owned):
+            for k in range(6):
+                r, gr = 6 * I + k, 6 * X[I] + k
+                cols = 6 * X[ix[ip[r]:ip[r + 1]] // 6] + ix[ip[r]:ip[r + 1]] % 6
+                assert np.array_equal(cols, gix[gip[gr]:gip[gr + 1]]), (rank, I, k)
+                assert np.abs(data[ip[r]:ip[r + 1]] - gdata[gip[gr]:gip[gr + 1]]).max() <= 1e-13 * np.abs(gdata).max()
+                nchk += 1
+        owned_g = torch.zeros(g.node_count, dtype=torch.int64)
+        owned_g[torch.from_numpy(X[dp.owned])] = 1
+        dist.all_reduce(owned_g)
+        assert bool((owned_g == 1).all())
+        q.put((rank, nchk, None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_plan_two_by_two_quadrants():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_quadrants, args=(r, 4, port, 6, 6, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 6 * 49
