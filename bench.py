@@ -517,7 +517,11 @@ def main():
                                    f"striped by x-band, {coupled_frac:.0%} of this rank's elements coupled; "
                                    "step = element K kernel + CSR assembly"
                                    + (" + RCCL interface-row exchange" if world > 1 else ""),
-                       "elements_per_gpu": E, "nnz_per_gpu": int(K.nnz), "partition": f"x-strips x{world}"},
+                       "elements_per_gpu": E, "nnz_per_gpu": int(K.nnz), "partition": f"x-strips x{world}",
+                       "interface_exchange_MB_rank0": (sum(b.numel() for b in list(asm._sbuf.values()) + list(asm._rbuf.values()))
+                                                       * 8 / 1e6) if world > 1 else 0.0,
+                       "exchange": ("RCCL grouped send/recv on a side stream, overlapped with the next element kernel"
+                                    if world > 1 and asm.overlap else ("RCCL grouped send/recv" if world > 1 else "none"))},
             "roofline": dominant,          # the kernel with the longer average launch
             "roofline_other_kernel": other,
         }
