@@ -49,8 +49,11 @@ def test_reduced_solve_matches_reference_displacement(oracle):
     u_red = spsolve(K_red.to_scipy().tocsc(), F_red.cpu().numpy())
     u = bcm.expand_solution(u_red).cpu().numpy()
     err = np.abs(u - g["u"]).max() / np.abs(g["u"]).max()
-    print("reduced solve vs reference displacement", err)
-    assert err < 1e-9 and not u[g["fixed"]].any()
+    # north_star asks 1e-12 for the displacements; the reference itself moves by `floor` when its input coordinates
+    # move by 1 ulp (tools/gen_golden_asm_ko.py), so the gate is max(1e-12, 10 x floor) with both numbers printed
+    floor = float(golden("asm_scordelis_16_floor")["u_floor"])
+    print("reduced solve vs reference displacement", err, "reference 1-ulp floor", floor)
+    assert err <= max(1e-12, 10.0 * floor) and not u[g["fixed"]].any()
     assert abs(abs(u[int(g["node"]) * 6]) / 3.0240e-1 - 0.9973) < 0.05 * 0.9973   # Ko-2017 table value
     v = bcm.expand_state_vector(np.ones(len(free))).cpu().numpy()
     assert v.sum() == len(free) and not v[g["fixed"]].any()

@@ -100,6 +100,38 @@ def test_c2_hemisphere_256(oracle, tri):
     assert abs(mu / (1.0 * 0.04 * area) - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("thick", [0.32, 0.0032])
+@pytest.mark.parametrize("tri", [False, True])
+def test_c2_twisted_beam_256(oracle, tri, thick):
+    """configs[1]'s second mesh at full size: MacNeal-Harder twisted beam, 256 x 256 (mesh of
+    tests/benchmarks/test_ko2017_performance.py:1195-1229, L = 12, b = 1.1, 90 degrees; both thicknesses of
+    :1256-1261).  L/h ~ 2.8e3: the case SURVEY.md A.1 singles out as breaking 1e-12 unless the geometry stage is
+    bit-faithful -- same property set as the hemisphere."""
+    from fem_shell_amd.assembler import MeshAssembler
+    n = 256
+    mesh = meshes.twisted_beam(12.0, 1.1, 90.0, n, n, triangular=tri)
+    mat = fsa.IsotropicMaterial("Ko2017_TwistedBeam", 29.0e6, 0.22, 1.0)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": thick}})
+    K = asm.assemble_stiffness_matrix()
+    assert mesh.conn.shape[0] == (131072 if tri else 65536) and asm.dofs_count == 396294
+    assert K.nnz == (16570404 if tri else 21288996)                       # SURVEY.md 8d closed forms
+    rng = np.random.default_rng(3)
+    nodes = np.unique(np.concatenate([[0, n, mesh.node_count - 1], rng.choice(mesh.node_count, 61, replace=False)]))
+    err, sym, rb = _common_checks(asm, mesh, K, oracle, nodes, rng)
+    print("C2 twisted beam", "MITC3+" if tri else "MITC4+", "t", thick, "rows vs oracle", err, "symmetry", sym,
+          "rigid translation", rb)
+    assert err < 1e-12 and sym < 1e-12 and rb < 1e-9
+    again = asm.assemble_stiffness_matrix(recompute=True)
+    assert bool((again.data == K.data).all())                            # bitwise repeatable
+    M = asm.assemble_mass_matrix()
+    assert _sample_rows(asm, mesh, M, oracle, "M", nodes[:16]) < 1e-12
+    # total mass: the ruled (helicoidal) strip's area is close to L * b * (mean stretch); lumped == consistent total
+    t = torch.zeros(asm.dofs_count, dtype=torch.float64, device=M.data.device); t[0::6] = 1.0
+    tot = float(M.lump_rows()[0::6].sum())
+    assert abs(float(t @ _spmv(M, t)) / tot - 1.0) < 1e-12
+    assert 1.0 <= tot / (1.0 * thick * 12.0 * 1.1) < 1.002               # helicoid area >= flat area, < +0.2 %
+
+
 def test_c3_blade_like_tube(oracle):
     from fem_shell_amd.assembler import MeshAssembler
     mesh = meshes.tapered_tube(128, 512)                                   # 65 536 quads, closed section
