@@ -3050,6 +3050,65 @@ int fs_halo_add(const double *buf, const int64_t *idx, int64_t n, double *data, 
     return FS_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// fs_shell_quad_fint_noalloc: internal forces of <= FS_FINT_NOALLOC_MAX_E quads for callers that cannot allocate
+// (HIP graph capture, serving loops).  Same kernels as fs_shell_quad_batch(FS_WANT_FINT) with a KTe workspace; the
+// workspace (the linear blocks K in FS_LAYOUT_SYMBLK_T16) is the file-scope device array below instead of a caller
+// buffer.  `scratch` is a HOST-side stand-in for the symbol: its device address is taken once per device with
+// hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+constexpr int64_t kFintNoallocTiles = FS_FINT_NOALLOC_MAX_E / 16;
+static __device__ __align__(256) double scratch[kFintNoallocTiles * 160 * 36];   // 47 185 920 B per GPU
+constexpr int kMaxDevices = 64;
+double *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// device address of `scratch` on the CURRENT device (each GPU holds its own copy at its own address)
+int scratch_ptr_current(double **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(FS_EHIP, "hipGetDevice", e);
+    if (dev < 0 || dev >= kMaxDevices) return fail(FS_EINVAL, "fs_shell_quad_fint_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(FS_EHIP, "hipGetSymbolAddress(scratch)", e);
+        g_scratch_ptr[dev] = static_cast<double *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return FS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                               int32_t n_props, const double *u_e, int64_t E, double *fe, int32_t *status,
+                               void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_quad_fint_noalloc: bad sizes");
+    if (E > FS_FINT_NOALLOC_MAX_E)
+        return fail(FS_EINVAL, "fs_shell_quad_fint_noalloc: E exceeds FS_FINT_NOALLOC_MAX_E (16384); use "
+                               "fs_shell_quad_batch with a caller-provided KTe workspace");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !u_e || !fe) return fail(FS_EINVAL, "fs_shell_quad_fint_noalloc: null argument");
+    double *ws = nullptr;
+    const int rc = scratch_ptr_current(&ws);
+    if (rc != FS_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((E + 15) / 16);
+    // every block of every tile (the padding of a ragged last tile included) is rewritten by the stiffness kernel
+    // before the force kernel reads it, so nothing of the previous call's contents has to be cleared
+    hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, ws, status);
+    FS_LAUNCH_CHECK("mitc4_k_kernel");
+    hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E, ws, ws, 0, fe);
+    FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
+    return FS_OK;
+}
+
 int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream) {
     if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_gather_dofs: n < 0");
     hipLaunchKernelGGL(gather_dofs_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, u,

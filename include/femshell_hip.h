@@ -401,6 +401,22 @@ int fs_inertial_forces(const double *coords, const double *vel, const double *ma
                        double alpha, const double *axis_host, const double *center_host, uint32_t parts, double *F,
                        void *stream);
 
+/*
+ * fs_shell_quad_fint_noalloc: NO counterpart in the reference.  It is for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the internal forces of
+ * fs_shell_quad_batch(want = FS_WANT_FINT, layout = FS_LAYOUT_SYMBLK_T16, KTe = workspace) -- update_configuration(u_e)
+ * + compute_internal_forces() per element, fe [E][24] -- without the KTe workspace argument.  The workspace (the
+ * elements' linear blocks, 2 880 B per element) lives in a static device array of the library, 47 185 920 B on every
+ * GPU the entry point is used on, held until the process ends.  The call allocates nothing (no hipMalloc / hipFree).
+ *   E > FS_FINT_NOALLOC_MAX_E  ->  FS_EINVAL (use fs_shell_quad_batch with your own workspace)
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race;
+ * serialise them.  Nothing has to be cleared between calls (every workspace block that is read is rewritten first).
+ */
+#define FS_FINT_NOALLOC_MAX_E 16384
+int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                               int32_t n_props, const double *u_e, int64_t E, double *fe, int32_t *status,
+                               void *stream);
+
 /* Diagnostic, no counterpart in the reference: `waves` 64-lane workgroups each run iters * 64 fp64 FMAs per lane in
  * 8 independent chains (2 * 64 * 64 * iters * waves flop per launch); out [waves * 64].  bench.py times it to report
  * the box's own fp64 ceiling beside the vendor peak. */
