@@ -91,6 +91,9 @@ class MeshAssembler:
     use_descriptors = True   # fs_csr_numeric_desc (False: fs_csr_numeric_blk, same result)
     use_symmetric = False    # fs_csr_numeric_sym: each source block read once (same result)
     reuse_linear_blocks = True   # K_T / f_int re-assembly reads the cached linear blocks (tiled quad meshes)
+    use_fused = True             # uniform MITC4+ meshes: assemble_stiffness_matrix(recompute=True) is ONE fused
+                                 # evaluate-and-assemble launch (fs_fused_assemble_quad), bitwise the two-kernel result
+    fused_max_patch_elems = 64   # elements per patch of the fused plan (<= 80)
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
@@ -106,6 +109,7 @@ class MeshAssembler:
         self._row_nnz: Optional[np.ndarray] = None
         self._is_mixed_mesh = False
         self._K_blk = self._M_blk = None
+        self._fplan = self._fplan_d = None
         self._precompute_elements()
         self._compute_sparsity_pattern()
 
@@ -404,8 +408,47 @@ class MeshAssembler:
                                               _lib.ptr(data), _lib.stream_ptr()), "fs_csr_numeric_blk")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
 
-    def assemble_stiffness_matrix(self, recompute=False) -> CsrMatrix:
-        """core/assembler.py:269-303."""
+    # ------------------------------------------------------------------ fused evaluate-and-assemble
+    @property
+    def can_fuse(self):
+        """The fused kernel covers uniform MITC4+ meshes (one quad group, 6 dofs per node)."""
+        return (self._family == ElementFamily.SHELL and len(self._groups) == 1 and self._groups[0]["nn"] == 4
+                and self._groups[0]["pos"] is None)
+
+    def fused_plan(self):
+        """Patch plan of fs_fused_assemble_quad (fem_shell_amd/fused.py), built on first use."""
+        if self._fplan_d is None:
+            from .fused import FusedQuadPlan
+            host = self._plan.host() if hasattr(self._plan, "host") else self._plan
+            self._fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems)
+            self._fplan_d = self._fplan.to_device(self.device)
+            self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
+        return self._fplan
+
+    def assemble_stiffness_fused(self, status=None) -> CsrMatrix:
+        """K straight from the coordinates in one launch: element evaluation (core/assembler.py:160-193 ->
+        MITC4.K) and the ADD_VALUES loop (:287-303) fused, no element matrices in memory.  Bit-identical to
+        refresh_element_matrices() + the descriptor assembly.  `status`: optional int32 [E] device tensor."""
+        if not self.can_fuse:
+            raise NotImplementedError("the fused kernel covers uniform MITC4+ quad meshes")
+        fp = self.fused_plan()
+        d, g = self._fplan_d, self._groups[0]
+        lib = _lib.load()
+        data = torch.empty(self._plan.nnz, dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_fused_assemble_quad(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+                                              len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
+                                              _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]),
+                                              _lib.ptr(d["ser_ev"]), fp.max_patch_elems, self._fused_flags,
+                                              _lib.ptr(data), _lib.ptr(status), _lib.stream_ptr()),
+                   "fs_fused_assemble_quad")
+        return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
+
+    def assemble_stiffness_matrix(self, recompute=False, fused=None) -> CsrMatrix:
+        """core/assembler.py:269-303.  recompute=True re-evaluates the element matrices: on uniform MITC4+ meshes
+        through the fused kernel (fused=False forces element kernel + assembly kernel; same bits)."""
+        fused = self.use_fused if fused is None else fused
+        if recompute and fused and self.can_fuse:
+            return self.assemble_stiffness_fused()
         if recompute or self._K_blk is None:
             self.refresh_element_matrices(want_K=True, want_M=False)
         return self._assemble(self._K_blk)

@@ -119,37 +119,27 @@ __device__ __forceinline__ void tying_weights(int i, double *w) {
 //   K_c = Y^T U + U^T Y,  U_j = sum_g detJ_g W_g^T (B_lam B_kappa_j(g))   (5 x 2 per node)
 // which is the same sum of products as MITC4.py:934-944 re-associated (eps-level difference) and
 // removes B_m from LDS and from the Gauss-point loop of every node-pair task.
+//
+// Stage 1 (quad_stage1) and the node-pair block of stage 2 (quad_pair_block) are shared by mitc4_k_kernel and the
+// fused evaluate-and-assemble kernel (fused_quad_k_kernel), which must produce the SAME bits.  They are therefore
+// compiled with `fp contract(on)`: a*b + c contracts where the SOURCE expression says so (clang emits llvm.fmuladd,
+// always an FMA for f64 on gfx950), never across statements, so the rounding sequence does not depend on the
+// kernel the functions are inlined into (contract(fast) lets the backend pick which product of a*b + c*d to fuse).
 // ------------------------------------------------------------------------------------------
-template <bool TILED>
-__global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
-                                                     const int32_t *__restrict__ prop_id,
-                                                     const fs_shell_prop *__restrict__ props,
-                                                     int64_t E, double *__restrict__ out,
-                                                     int32_t *__restrict__ status) {
-    __shared__ double lds[TILED ? LDS_WAVE_T16 : LDS_WAVE];
-    const int lane = threadIdx.x;
-    const int Q = lane >> 2, g = lane & 3;
-    const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
-    const bool valid = e_raw < E;
-    const int64_t e = valid ? e_raw : (E - 1);
+struct QuadElem {       // per-element results of stage 1 that stage 2 needs beside the LDS image
+    double S[15];       // upper triangle of the 5x5 membrane core, row-major (t <= u)
+    double gt[6][3];    // tying tangents g_r(A), g_r(B), g_s(C), g_s(D), g_r(E), g_s(E) in the element frame
+    double i00, i01, i11;   // Kbb^-1 (zero when singular: no condensation)
+    int st;             // FS_ST_* bits
+};
 
-    double x[4][3];
-    {
-        const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
-        for (int t = 0; t < 6; t++) {
-            const double2 v = p[t];
-            (&x[0][0])[2 * t] = v.x;
-            (&x[0][0])[2 * t + 1] = v.y;
-        }
-    }
-    const fs_shell_prop *pr = props + prop_id[e];
-    const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
-    const bool any_coupled = __any(coupled);
-
-    QuadGeom geo;
+// Stage 1 for Gauss point g of the element held by the 4 lanes of a quad: bit-faithful geometry, then the
+// strain-displacement data of this Gauss point for the 4 nodes -> LDS image `lds` (layout: lds_slot / LDS_* above,
+// element Q of the 16-element tile), bubble blocks and membrane core reduced over the quad with DPP.
+// All four lanes of every quad must be active.  any_coupled: uniform over the quad.
+__device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_shell_prop *pr, bool coupled,
+                                            bool any_coupled, int g, int Q, double *lds, QuadGeom &geo, QuadElem &el) {
     quad_geometry(x, geo);
-
-    // ---------------- stage 1: Gauss point g ----------------
     const double xi = (g == 1 || g == 2) ? kGP : -kGP;
     const double eta = (g >= 2) ? kGP : -kGP;
     double dxi[4], deta[4];
@@ -161,7 +151,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     // tangent vectors at the 5 tying points (MITC4.py:589-612 evaluated at A,B,C,D,E; the zero
     // shape-derivative terms are dropped, which is exact), projected on the frame (:287-296).
     // gt[0..3] = g_r(A), g_r(B), g_s(C), g_s(D); gt[4], gt[5] = g_r(E), g_s(E)
-    double gt[6][3];
+    double (&gt)[6][3] = el.gt;
     {
         double t3[3];
         for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
@@ -179,10 +169,10 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     }
 
     const int qoff = ((Q >> 2) << 4) + (Q & 3);
-    double S[15];         // upper triangle of the 5x5 membrane core, row-major (t <= u)
+    double (&S)[15] = el.S;
     double kbb00, kbb01, kbb11;
     {
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
         // shape-function derivatives in local axes (MITC4.py:642-657)
         double dNx[4], dNy[4];
         for (int i = 0; i < 4; i++) {
@@ -337,16 +327,180 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     st |= __builtin_amdgcn_update_dpp(0, st, 0xB1, 0xF, 0xF, true);
     st |= __builtin_amdgcn_update_dpp(0, st, 0x4E, 0xF, 0xF, true);
     // Kbb^-1 (MITC4.py:994-998; singular -> no condensation)
-    const double kdet = kbb00 * kbb11 - kbb01 * kbb01;
+    const double p0 = kbb00 * kbb11, p1 = kbb01 * kbb01;
+    const double kdet = p0 - p1;
     const bool cond_ok = (kdet != 0.0) && (kdet == kdet);
     const double rkdet = recip(kdet);
-    const double i00 = cond_ok ? divr(kbb11, kdet, rkdet) : 0.0, i01 = cond_ok ? divr(-kbb01, kdet, rkdet) : 0.0,
-                 i11 = cond_ok ? divr(kbb00, kdet, rkdet) : 0.0;
-    if (status && valid && g == 0) status[e] = st;
+    el.i00 = cond_ok ? divr(kbb11, kdet, rkdet) : 0.0;
+    el.i01 = cond_ok ? divr(-kbb01, kdet, rkdet) : 0.0;
+    el.i11 = cond_ok ? divr(kbb00, kdet, rkdet) : 0.0;
+    el.st = st;
+}
+
+// Stage 2: the 6x6 block of node pair (ti <= tj) of the element whose LDS image sits at element slot (qoff, Q) of
+// `lds`, in GLOBAL axes:  R^T [ Y_i^T S Y_j + sum_g detJ (B_k^T C_b B_k + B_g^T C_s B_g + k_d B_d B_d^T) [+ coupling]
+//                               - K_nb,i Kbb^-1 K_nb,j^T ] R,   symmetrised when `diag` (ti == tj; MITC4.py:1034).
+__device__ __forceinline__ void quad_pair_block(const double *lds, int qoff, int Q, int ti, int tj, bool diag,
+                                                const double (&Sf)[5][5], const double (&gt)[6][3],
+                                                const double (&R)[3][3], double i00, double i01, double i11,
+                                                const double (&Cb)[3][3], const double (&Cs)[2][2], double kd,
+                                                bool any_coupled, double (&G)[6][6]) {
+#pragma clang fp contract(on)
+    const int oi = (ti << 2) + qoff, oj = (tj << 2) + qoff;
+    // shape-function signs of nodes ti, tj (for N_i at the Gauss points)
+    const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
+    const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
+
+    double L[6][6];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) L[a][b] = 0.0;
+
+    // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j   (MITC4.py:934-944 pre-contracted)
+    double Yi[5][3], Yj[5][3];
+    {
+        double wi[6], wj[6];
+        tying_weights(ti, wi);
+        tying_weights(tj, wj);
+        for (int k = 0; k < 3; k++) {
+            for (int t = 0; t < 4; t++) { Yi[t][k] = wi[t] * gt[t][k]; Yj[t][k] = wj[t] * gt[t][k]; }
+            Yi[4][k] = wi[4] * gt[4][k] + wi[5] * gt[5][k];
+            Yj[4][k] = wj[4] * gt[4][k] + wj[5] * gt[5][k];
+        }
+        for (int b = 0; b < 3; b++) {
+            double SY[5];
+            for (int t = 0; t < 5; t++) {
+                double v = Sf[t][0] * Yj[0][b];
+                for (int u = 1; u < 5; u++) v = FMA(Sf[t][u], Yj[u][b], v);
+                SY[t] = v;
+            }
+            for (int a = 0; a < 3; a++) {
+                double v = Yi[0][a] * SY[0];
+                for (int t = 1; t < 5; t++) v = FMA(Yi[t][a], SY[t], v);
+                L[a][b] = v;
+            }
+        }
+    }
+    // membrane-bending coupling: L[uvw_i][th_j] += Y_i^T U_j ; L[th_i][uvw_j] += U_i^T Y_j
+    if (any_coupled) {
+        for (int c = 0; c < 2; c++) {
+            double Ui[5], Uj[5];
+            for (int t = 0; t < 5; t++) {
+                Ui[t] = lds[LDS_U + ((2 * t + c) << 6) + oi];
+                Uj[t] = lds[LDS_U + ((2 * t + c) << 6) + oj];
+            }
+            for (int a = 0; a < 3; a++) {
+                double v = L[a][3 + c], w2 = L[3 + c][a];
+                for (int t = 0; t < 5; t++) { v = FMA(Yi[t][a], Uj[t], v); w2 = FMA(Ui[t], Yj[t][a], w2); }
+                L[a][3 + c] = v; L[3 + c][a] = w2;
+            }
+        }
+    }
+
+    for (int gg = 0; gg < 4; gg++) {
+        const double w = lds[LDS_DET + Q * 4 + gg];
+        const int gi = (((ti + gg) & 3) << 2) + qoff, gj = (((tj + gg) & 3) << 2) + qoff;
+        double bsi[2][3], bsj[2][3];
+        const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + gi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + gi];
+        const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + gj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + gj];
+        for (int c = 0; c < 6; c++) {
+            (&bsi[0][0])[c] = w * lds[(((C_BS + c) * 4 + gg) << 6) + gi];
+            (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + gj];
+        }
+        const double wdxi = w * dxi_, wdyi = w * dyi_;
+        // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
+        double CK[3][2];
+        for (int rr = 0; rr < 3; rr++) {
+            CK[rr][0] = -FMA(Cb[rr][1], dyj, Cb[rr][2] * dxj);
+            CK[rr][1] = FMA(Cb[rr][0], dxj, Cb[rr][2] * dyj);
+        }
+        for (int c = 0; c < 2; c++) {
+            L[3][3 + c] = FMA(-wdyi, CK[1][c], FMA(-wdxi, CK[2][c], L[3][3 + c]));
+            L[4][3 + c] = FMA(wdxi, CK[0][c], FMA(wdyi, CK[2][c], L[4][3 + c]));
+        }
+        // shear: L[w,thx,thy][w,thx,thy] += w Bs_i^T Cs Bs_j        (MITC4.py:986)
+        double CS[2][3];
+        for (int rr = 0; rr < 2; rr++)
+            for (int b = 0; b < 3; b++) CS[rr][b] = FMA(Cs[rr][0], bsj[0][b], Cs[rr][1] * bsj[1][b]);
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(bsi[0][a], CS[0][b], FMA(bsi[1][a], CS[1][b], L[2 + a][2 + b]));
+        // drilling: k w outer(Bd_i, Bd_j) on (u,v,thz)                (MITC4.py:909-928,1014)
+        const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
+        const double Ni = 0.25 * (1.0 + sxi * xg) * (1.0 + syi * yg);
+        const double Nj = 0.25 * (1.0 + sxj * xg) * (1.0 + syj * yg);
+        const double bdi[3] = {-0.5 * wdyi * kd, 0.5 * wdxi * kd, -Ni * (w * kd)};
+        const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
+        const int dm[3] = {0, 1, 5};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) L[dm[a]][dm[b]] = FMA(bdi[a], bdj[b], L[dm[a]][dm[b]]);
+    }
+    // bubble condensation: L[w,thx,thy][w,thx,thy] -= (Knb_i Kbb^-1) Knb_j^T (MITC4.py:996)
+    {
+        double ki[3][2], kj[3][2];
+        for (int k = 0; k < 3; k++) {
+            ki[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oi]; ki[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oi];
+            kj[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oj]; kj[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oj];
+        }
+        for (int a = 0; a < 3; a++) {
+            const double h0 = ki[a][0] * i00 + ki[a][1] * i01, h1 = ki[a][0] * i01 + ki[a][1] * i11;
+            for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(-h0, kj[b][0], FMA(-h1, kj[b][1], L[2 + a][2 + b]));
+        }
+    }
+    // rotation to global axes, 3x3 block-wise: G = R^T X R  (MITC4.py:634-640,1032-1033)
+    for (int ba = 0; ba < 2; ba++)
+        for (int bb = 0; bb < 2; bb++) {
+            double Y[3][3];
+            for (int p = 0; p < 3; p++)
+                for (int q = 0; q < 3; q++)
+                    Y[p][q] = FMA(R[2][p], L[3 * ba + 2][3 * bb + q], FMA(R[1][p], L[3 * ba + 1][3 * bb + q], R[0][p] * L[3 * ba][3 * bb + q]));
+            for (int p = 0; p < 3; p++)
+                for (int q = 0; q < 3; q++)
+                    G[3 * ba + p][3 * bb + q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], Y[p][0] * R[0][q]));
+        }
+    if (diag) {  // diagonal block: K = 0.5 (K + K^T)  (MITC4.py:1034)
+        for (int a = 0; a < 6; a++)
+            for (int b = a + 1; b < 6; b++) {
+                const double m = 0.5 * (G[a][b] + G[b][a]);
+                G[a][b] = m; G[b][a] = m;
+            }
+    }
+}
+
+template <bool TILED>
+__global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
+                                                     const int32_t *__restrict__ prop_id,
+                                                     const fs_shell_prop *__restrict__ props,
+                                                     int64_t E, double *__restrict__ out,
+                                                     int32_t *__restrict__ status) {
+    __shared__ double lds[TILED ? LDS_WAVE_T16 : LDS_WAVE];
+    const int lane = threadIdx.x;
+    const int Q = lane >> 2, g = lane & 3;
+    const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
+    const bool valid = e_raw < E;
+    const int64_t e = valid ? e_raw : (E - 1);
+
+    double x[4][3];
+    {
+        const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
+        for (int t = 0; t < 6; t++) {
+            const double2 v = p[t];
+            (&x[0][0])[2 * t] = v.x;
+            (&x[0][0])[2 * t + 1] = v.y;
+        }
+    }
+    const fs_shell_prop *pr = props + prop_id[e];
+    const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
+    const bool any_coupled = __any(coupled);
+
+    // ---------------- stage 1: Gauss point g ----------------
+    QuadGeom geo;
+    QuadElem el;
+    quad_stage1(x, pr, coupled, any_coupled, g, Q, lds, geo, el);
+    if (status && valid && g == 0) status[e] = el.st;
 
     __syncthreads();
 
     // ---------------- stage 2: node-pair tasks ----------------
+    const int qoff = ((Q >> 2) << 4) + (Q & 3);
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
@@ -356,134 +510,18 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     {
         int n = 0;
         for (int t = 0; t < 5; t++)
-            for (int u = t; u < 5; u++) { Sf[t][u] = S[n]; Sf[u][t] = S[n]; n++; }
+            for (int u = t; u < 5; u++) { Sf[t][u] = el.S[n]; Sf[u][t] = el.S[n]; n++; }
     }
 
     for (int round = 0; round < 3; round++) {
-#pragma clang fp contract(fast)
         int ti, tj;
         bool active = valid;
         if (round == 0) { ti = g; tj = g; }
         else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
         else { ti = g & 1; tj = (g & 1) + 2; active = active && (g < 2); }
-        const int oi = (ti << 2) + qoff, oj = (tj << 2) + qoff;
-        // shape-function signs of nodes ti, tj (for N_i at the Gauss points)
-        const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
-        const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
-
-        double L[6][6];
-        for (int a = 0; a < 6; a++)
-            for (int b = 0; b < 6; b++) L[a][b] = 0.0;
-
-        // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j   (MITC4.py:934-944 pre-contracted)
-        double Yi[5][3], Yj[5][3];
-        {
-            double wi[6], wj[6];
-            tying_weights(ti, wi);
-            tying_weights(tj, wj);
-            for (int k = 0; k < 3; k++) {
-                for (int t = 0; t < 4; t++) { Yi[t][k] = wi[t] * gt[t][k]; Yj[t][k] = wj[t] * gt[t][k]; }
-                Yi[4][k] = wi[4] * gt[4][k] + wi[5] * gt[5][k];
-                Yj[4][k] = wj[4] * gt[4][k] + wj[5] * gt[5][k];
-            }
-            for (int b = 0; b < 3; b++) {
-                double SY[5];
-                for (int t = 0; t < 5; t++) {
-                    double v = Sf[t][0] * Yj[0][b];
-                    for (int u = 1; u < 5; u++) v = FMA(Sf[t][u], Yj[u][b], v);
-                    SY[t] = v;
-                }
-                for (int a = 0; a < 3; a++) {
-                    double v = Yi[0][a] * SY[0];
-                    for (int t = 1; t < 5; t++) v = FMA(Yi[t][a], SY[t], v);
-                    L[a][b] = v;
-                }
-            }
-        }
-        // membrane-bending coupling: L[uvw_i][th_j] += Y_i^T U_j ; L[th_i][uvw_j] += U_i^T Y_j
-        if (any_coupled) {
-            for (int c = 0; c < 2; c++) {
-                double Ui[5], Uj[5];
-                for (int t = 0; t < 5; t++) {
-                    Ui[t] = lds[LDS_U + ((2 * t + c) << 6) + oi];
-                    Uj[t] = lds[LDS_U + ((2 * t + c) << 6) + oj];
-                }
-                for (int a = 0; a < 3; a++) {
-                    double v = L[a][3 + c], w2 = L[3 + c][a];
-                    for (int t = 0; t < 5; t++) { v = FMA(Yi[t][a], Uj[t], v); w2 = FMA(Ui[t], Yj[t][a], w2); }
-                    L[a][3 + c] = v; L[3 + c][a] = w2;
-                }
-            }
-        }
-
-        for (int gg = 0; gg < 4; gg++) {
-            const double w = lds[LDS_DET + Q * 4 + gg];
-            const int gi = (((ti + gg) & 3) << 2) + qoff, gj = (((tj + gg) & 3) << 2) + qoff;
-            double bsi[2][3], bsj[2][3];
-            const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + gi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + gi];
-            const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + gj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + gj];
-            for (int c = 0; c < 6; c++) {
-                (&bsi[0][0])[c] = w * lds[(((C_BS + c) * 4 + gg) << 6) + gi];
-                (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + gj];
-            }
-            const double wdxi = w * dxi_, wdyi = w * dyi_;
-            // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
-            double CK[3][2];
-            for (int rr = 0; rr < 3; rr++) {
-                CK[rr][0] = -FMA(Cb[rr][1], dyj, Cb[rr][2] * dxj);
-                CK[rr][1] = FMA(Cb[rr][0], dxj, Cb[rr][2] * dyj);
-            }
-            for (int c = 0; c < 2; c++) {
-                L[3][3 + c] = FMA(-wdyi, CK[1][c], FMA(-wdxi, CK[2][c], L[3][3 + c]));
-                L[4][3 + c] = FMA(wdxi, CK[0][c], FMA(wdyi, CK[2][c], L[4][3 + c]));
-            }
-            // shear: L[w,thx,thy][w,thx,thy] += w Bs_i^T Cs Bs_j        (MITC4.py:986)
-            double CS[2][3];
-            for (int rr = 0; rr < 2; rr++)
-                for (int b = 0; b < 3; b++) CS[rr][b] = FMA(Cs[rr][0], bsj[0][b], Cs[rr][1] * bsj[1][b]);
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(bsi[0][a], CS[0][b], FMA(bsi[1][a], CS[1][b], L[2 + a][2 + b]));
-            // drilling: k w outer(Bd_i, Bd_j) on (u,v,thz)                (MITC4.py:909-928,1014)
-            const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
-            const double Ni = 0.25 * (1.0 + sxi * xg) * (1.0 + syi * yg);
-            const double Nj = 0.25 * (1.0 + sxj * xg) * (1.0 + syj * yg);
-            const double bdi[3] = {-0.5 * wdyi * kd, 0.5 * wdxi * kd, -Ni * (w * kd)};
-            const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
-            const int dm[3] = {0, 1, 5};
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) L[dm[a]][dm[b]] = FMA(bdi[a], bdj[b], L[dm[a]][dm[b]]);
-        }
-        // bubble condensation: L[w,thx,thy][w,thx,thy] -= (Knb_i Kbb^-1) Knb_j^T (MITC4.py:996)
-        {
-            double ki[3][2], kj[3][2];
-            for (int k = 0; k < 3; k++) {
-                ki[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oi]; ki[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oi];
-                kj[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oj]; kj[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oj];
-            }
-            for (int a = 0; a < 3; a++) {
-                const double h0 = ki[a][0] * i00 + ki[a][1] * i01, h1 = ki[a][0] * i01 + ki[a][1] * i11;
-                for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(-h0, kj[b][0], FMA(-h1, kj[b][1], L[2 + a][2 + b]));
-            }
-        }
-        // rotation to global axes, 3x3 block-wise: G = R^T X R  (MITC4.py:634-640,1032-1033)
         double G[6][6];
-        for (int ba = 0; ba < 2; ba++)
-            for (int bb = 0; bb < 2; bb++) {
-                double Y[3][3];
-                for (int p = 0; p < 3; p++)
-                    for (int q = 0; q < 3; q++)
-                        Y[p][q] = FMA(R[2][p], L[3 * ba + 2][3 * bb + q], FMA(R[1][p], L[3 * ba + 1][3 * bb + q], R[0][p] * L[3 * ba][3 * bb + q]));
-                for (int p = 0; p < 3; p++)
-                    for (int q = 0; q < 3; q++)
-                        G[3 * ba + p][3 * bb + q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], Y[p][0] * R[0][q]));
-            }
-        if (round == 0) {  // diagonal block: K = 0.5 (K + K^T)  (MITC4.py:1034)
-            for (int a = 0; a < 6; a++)
-                for (int b = a + 1; b < 6; b++) {
-                    const double m = 0.5 * (G[a][b] + G[b][a]);
-                    G[a][b] = m; G[b][a] = m;
-                }
-        }
+        quad_pair_block(lds, qoff, Q, ti, tj, round == 0, Sf, el.gt, R, el.i00, el.i01, el.i11, Cb, Cs, kd,
+                        any_coupled, G);
         if constexpr (TILED) {
             // ---- FS_LAYOUT_SYMBLK_T16 output.  A lane that stores its own 288-byte block issues 18
             // instructions of 64 scattered 16-byte pieces; that form costs 0.45 ms of 1.58 ms per 1.25 M
@@ -514,6 +552,190 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
             const int p = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
             double2 *dst = reinterpret_cast<double2 *>(out + (e * 10 + p) * 36);
             for (int t = 0; t < 18; t++) dst[t] = make_double2((&G[0][0])[2 * t], (&G[0][0])[2 * t + 1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused evaluate-and-assemble, GATHER form (fs_fused_assemble_quad): no element matrices in HBM.
+//
+// A workgroup owns a PATCH of nodes (fem_shell_amd/fused.py builds the plan for any quad mesh):
+//   stage 1  every element that touches a patch node (<= 16 NT of them; the one-element halo is recomputed) runs
+//            quad_stage1 exactly as in mitc4_k_kernel, 16 elements per wave; besides the strain-displacement image
+//            the per-element data that stage 2 of mitc4_k_kernel keeps in registers (membrane core S, tying
+//            tangents, frame, Kbb^-1) goes to LDS, because here a lane meets elements it did not evaluate;
+//   stage 2  a lane evaluates ONE contribution (element, local node pair) of a CSR node-pair block (I <= J) with
+//            quad_pair_block -- the same bits as mitc4_k_kernel writes to FS_LAYOUT_SYMBLK -- the <= 4
+//            contributions of a block sit on adjacent lanes of a quad and are summed IN ELEMENT ORDER with DPP
+//            ( ((x0 + x1) + x2) + x3, absent terms +0.0: the sum of csr_numeric_desc6_lds_kernel and of the
+//            reference's ADD_VALUES insertion order), and the group's first lane stores the block to (I,J) and,
+//            transposed, to (J,I).  Blocks with more than 4 contributions (nodes of valence > 4) are summed by one
+//            lane serially (0 + y0 + y1 + ..., again the order of the descriptor kernel).
+// The result is bitwise the CSR of mitc4_k_kernel + csr_numeric_desc6_lds_kernel; HBM traffic per element drops from
+// 2 880 (blocks out) + 2 880 (blocks in) + 2 592 (CSR out) + 432 (descriptors) to 2 592 + ~330 (plan records).
+// ------------------------------------------------------------------------------------------
+constexpr int FQ_S = 0, FQ_GT = 15, FQ_R = 33, FQ_INV = 42, FQ_NEX = 45;   // per-element extras, [component][Q]
+
+template <bool COUPLED>
+struct FusedLayout {
+    static constexpr int EXB = COUPLED ? LDS_WAVE : LDS_U;      // extras start (uncoupled meshes: no U region)
+    static constexpr int TILE = EXB + FQ_NEX * 16;              // doubles per 16-element tile
+};
+
+#define FS_EV_SLOT(ev) ((int)((ev) & 255u))
+#define FS_EV_TI(ev) ((int)(((ev) >> 8) & 3u))
+#define FS_EV_TJ(ev) ((int)(((ev) >> 10) & 3u))
+#define FS_EV_TR(ev) ((((ev) >> 12) & 1u) != 0)
+#define FS_EV_N(ev) ((int)(((ev) >> 13) & 7u))
+#define FS_EV_LEADER(ev) ((((ev) >> 16) & 1u) != 0)
+#define FS_EV_ACTIVE(ev) ((((ev) >> 17) & 1u) != 0)
+#define FS_EV_SERCNT(ev) ((int)((ev) >> 20))
+
+template <bool COUPLED>
+__device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const int *s_pid,
+                                           const fs_shell_prop *__restrict__ props, double (&Y)[36]) {
+    using LY = FusedLayout<COUPLED>;
+    const int slot = FS_EV_SLOT(ev), ti = FS_EV_TI(ev), tj = FS_EV_TJ(ev);
+    const int T = slot >> 4, Q = slot & 15;
+    const int qoff = ((Q >> 2) << 4) + (Q & 3);
+    const double *img = lds + T * LY::TILE;
+    const double *ex = img + LY::EXB + Q;
+    double Sf[5][5], gt[6][3], R[3][3];
+    {
+        int n = 0;
+        for (int t = 0; t < 5; t++)
+            for (int u = t; u < 5; u++) { const double v = ex[(FQ_S + n) << 4]; Sf[t][u] = v; Sf[u][t] = v; n++; }
+    }
+    for (int t = 0; t < 18; t++) (&gt[0][0])[t] = ex[(FQ_GT + t) << 4];
+    for (int t = 0; t < 9; t++) (&R[0][0])[t] = ex[(FQ_R + t) << 4];
+    const double i00 = ex[(FQ_INV + 0) << 4], i01 = ex[(FQ_INV + 1) << 4], i11 = ex[(FQ_INV + 2) << 4];
+    const fs_shell_prop *pr = props + s_pid[slot];
+    const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
+    const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
+    const double kd = pr->k_drill;
+    double G[6][6];
+    quad_pair_block(img, qoff, Q, ti, tj, ti == tj, Sf, gt, R, i00, i01, i11, Cb, Cs, kd, COUPLED, G);
+    const bool tr = FS_EV_TR(ev);
+    for (int k = 0; k < 6; k++)
+        for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
+}
+
+template <bool COUPLED, int NT>
+__global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restrict__ xyz,
+                                                           const int32_t *__restrict__ prop_id,
+                                                           const fs_shell_prop *__restrict__ props, int32_t n_props,
+                                                           int64_t n_pat, const int64_t *__restrict__ pat_eptr,
+                                                           const int32_t *__restrict__ pat_elems,
+                                                           const int64_t *__restrict__ pat_rptr,
+                                                           const fs_fused_rec *__restrict__ recs,
+                                                           const uint32_t *__restrict__ ser_ev,
+                                                           double *__restrict__ data, int32_t *__restrict__ status) {
+    using LY = FusedLayout<COUPLED>;
+    __shared__ double lds[NT * LY::TILE];
+    __shared__ int s_pid[NT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so XCD k gets the k-th contiguous range of
+    // patches -- neighbouring patches (shared halo elements, shared CSR lines) meet in one L2
+    const int64_t per_xcd = (gridDim.x + 7) / 8;
+    const int64_t p = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (p >= n_pat) return;
+    const int64_t e0 = pat_eptr[p];
+    const int ne = (int)(pat_eptr[p + 1] - e0);
+
+    // ---------------- stage 1: the patch's elements, 16 per wave ----------------
+    for (int T = wave; T * 16 < ne; T += 4) {
+        const int Q = lane >> 2, g = lane & 3;
+        const int slot = T * 16 + Q;
+        const bool valid = slot < ne;
+        const int64_t e = pat_elems[e0 + (valid ? slot : ne - 1)];
+        double x[4][3];
+        {
+            const double2 *xp = reinterpret_cast<const double2 *>(xyz + e * 12);
+            for (int t = 0; t < 6; t++) {
+                const double2 v = xp[t];
+                (&x[0][0])[2 * t] = v.x;
+                (&x[0][0])[2 * t + 1] = v.y;
+            }
+        }
+        int pid = prop_id[e];
+        int bad = 0;
+        if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
+        const fs_shell_prop *pr = props + pid;
+        const bool flagged = (pr->flags & FS_PROP_COUPLED) != 0;
+        if (!COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
+        double *img = lds + T * LY::TILE;
+        QuadGeom geo;
+        QuadElem el;
+        quad_stage1(x, pr, COUPLED && flagged, COUPLED, g, Q, img, geo, el);
+        double *ex = img + LY::EXB + Q;
+        if (g == 0) {
+            for (int n = 0; n < 15; n++) ex[(FQ_S + n) << 4] = el.S[n];
+            s_pid[slot] = pid;
+            if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
+        } else if (g == 1) {
+            for (int t = 0; t < 18; t++) ex[(FQ_GT + t) << 4] = (&el.gt[0][0])[t];
+        } else if (g == 2) {
+            for (int k = 0; k < 3; k++) {
+                ex[(FQ_R + k) << 4] = geo.e1[k]; ex[(FQ_R + 3 + k) << 4] = geo.e2[k]; ex[(FQ_R + 6 + k) << 4] = geo.e3[k];
+            }
+        } else {
+            ex[(FQ_INV + 0) << 4] = el.i00; ex[(FQ_INV + 1) << 4] = el.i01; ex[(FQ_INV + 2) << 4] = el.i11;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- stage 2: one contribution per lane, in-order sums inside quads ----------------
+    const int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
+    for (int64_t rb = r0; rb < r1; rb += 256) {
+        const int64_t r = rb + tid;
+        fs_fused_rec rec;
+        rec.dst = 0; rec.dst_t = -1; rec.stride = 0; rec.stride_t = 0; rec.ev = 0; rec.aux = 0;
+        if (r < r1) {
+            const int4 *rp = reinterpret_cast<const int4 *>(recs + r);
+            const int4 a = rp[0], b = rp[1];
+            rec.dst = ((int64_t)(uint32_t)a.x) | ((int64_t)a.y << 32);
+            rec.dst_t = ((int64_t)(uint32_t)a.z) | ((int64_t)a.w << 32);
+            rec.stride = b.x; rec.stride_t = b.y; rec.ev = (uint32_t)b.z; rec.aux = (uint32_t)b.w;
+        }
+        const uint32_t ev = rec.ev;
+        const int n = FS_EV_N(ev);
+        const bool serial = n == 7;
+        // X = sum of this lane's contributions: one (X = -0.0 + y == y, bit for bit) or, serial tasks, 0.0 + y0 + y1 ...
+        double X[36];
+        for (int t = 0; t < 36; t++) X[t] = serial ? 0.0 : -0.0;
+        const int nev = serial ? FS_EV_SERCNT(ev) : (FS_EV_ACTIVE(ev) ? 1 : 0);
+        for (int c = 0; c < nev; c++) {
+            const uint32_t code = serial ? ser_ev[rec.aux + c] : ev;
+            double Y[36];
+            fused_eval<COUPLED>(code, lds, s_pid, props, Y);
+            for (int t = 0; t < 36; t++) X[t] = X[t] + Y[t];
+        }
+        // in-order sum over the lanes of a group: the leader at quad position q reads q+1, q+2, q+3; absent terms
+        // are +0.0 (the padded sum of the descriptor kernel); serial tasks add -0.0, which changes nothing
+        const bool g2 = n >= 2 && n <= 4, g3 = n >= 3 && n <= 4, g4 = n == 4;
+        const double z = serial ? -0.0 : 0.0;
+        for (int t = 0; t < 36; t++) {
+            const double t1 = quad_perm<0x39>(X[t]);   // quad_perm:[1,2,3,0]: lane i reads lane i+1
+            const double t2 = quad_perm<0x4E>(X[t]);   // [2,3,0,1]
+            const double t3 = quad_perm<0x93>(X[t]);   // [3,0,1,2]
+            double a = X[t] + (g2 ? t1 : z);
+            a = a + (g3 ? t2 : z);
+            a = a + (g4 ? t3 : z);
+            X[t] = a;
+        }
+        if (FS_EV_LEADER(ev)) {
+            double *d = data + rec.dst;
+            for (int k = 0; k < 6; k++) {
+                double2 *row = reinterpret_cast<double2 *>(d + (int64_t)k * rec.stride);
+                for (int m = 0; m < 3; m++) row[m] = make_double2(X[k * 6 + 2 * m], X[k * 6 + 2 * m + 1]);
+            }
+            if (rec.dst_t >= 0) {
+                double *dt = data + rec.dst_t;
+                for (int l = 0; l < 6; l++) {
+                    double2 *row = reinterpret_cast<double2 *>(dt + (int64_t)l * rec.stride_t);
+                    for (int m = 0; m < 3; m++) row[m] = make_double2(X[(2 * m) * 6 + l], X[(2 * m + 1) * 6 + l]);
+                }
+            }
         }
     }
 }
@@ -3106,6 +3328,30 @@ int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const 
     FS_LAUNCH_CHECK("mitc4_k_kernel");
     hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E, ws, ws, 0, fe);
     FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
+    return FS_OK;
+}
+
+int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,
+                           int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
+                           const int64_t *pat_rptr, const fs_fused_rec *recs, const uint32_t *ser_ev,
+                           int32_t max_patch_elems, uint32_t flags, double *data, int32_t *status, void *stream) {
+    if (E < 0 || n_props <= 0 || n_patches < 0) return fail(FS_EINVAL, "fs_fused_assemble_quad: bad sizes");
+    if (E == 0 || n_patches == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !pat_eptr || !pat_elems || !pat_rptr || !recs || !data)
+        return fail(FS_EINVAL, "fs_fused_assemble_quad: null argument");
+    if (max_patch_elems <= 0 || max_patch_elems > FS_FUSED_MAX_PATCH_ELEMS)
+        return fail(FS_EINVAL, "fs_fused_assemble_quad: a patch may hold at most FS_FUSED_MAX_PATCH_ELEMS elements");
+    if (n_patches > (int64_t)INT32_MAX - 8) return fail(FS_EINVAL, "fs_fused_assemble_quad: too many patches");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(((n_patches + 7) / 8) * 8);
+#define FS_FUSED_LAUNCH(C, NT)                                                                                       \
+    hipLaunchKernelGGL((fused_quad_k_kernel<C, NT>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
+                       n_patches, pat_eptr, pat_elems, pat_rptr, recs, ser_ev, data, status)
+    const bool coupled = (flags & FS_FUSED_HAS_COUPLED) != 0;
+    if (max_patch_elems <= 64) { if (coupled) FS_FUSED_LAUNCH(true, 4); else FS_FUSED_LAUNCH(false, 4); }
+    else { if (coupled) FS_FUSED_LAUNCH(true, 5); else FS_FUSED_LAUNCH(false, 5); }
+#undef FS_FUSED_LAUNCH
+    FS_LAUNCH_CHECK("fused_quad_k_kernel");
     return FS_OK;
 }
 

@@ -54,6 +54,8 @@ extern "C" {
 #define FS_ST_NAN_FRAME 1   /* zero-area / zero-norm local frame (MITC4.py:436-476 silently NaNs) */
 #define FS_ST_BAD_COEFF 2   /* characteristic-vector solve failed (MITC4.py:186-193) */
 #define FS_ST_BAD_JAC 4     /* det J <= 0 at a Gauss point */
+#define FS_ST_BAD_PROP 8    /* prop_id outside [0, n_props) (row 0 was used instead), or a coupled property row in a
+                               call that declared the table free of them (fs_fused_assemble_quad) */
 
 /* property-table flags */
 #define FS_PROP_COUPLED 1   /* add membrane-bending coupling (MITC4_composite.py:98-99,206-248) */
@@ -302,6 +304,48 @@ typedef struct fs_blk_desc_sym {
 } fs_blk_desc_sym; /* 64 bytes */
 int fs_csr_numeric_sym(const double *vals, const fs_blk_desc_sym *desc, const int64_t *contrib,
                        int64_t ndesc, int32_t d, double *data, void *stream);
+
+/*
+ * Fused evaluate-and-assemble for uniform MITC4+ quad meshes, gather form: the CSR values of K straight from the
+ * coordinates, without element matrices in memory.  Replaces the whole loop of MeshAssembler.assemble_stiffness_matrix
+ * over the cached element matrices (core/assembler.py:287-303) TOGETHER with the element evaluations that fill the
+ * cache (core/assembler.py:160-193 -> MITC4.K, elements/MITC4.py:1018-1036); bit-identical to
+ * fs_shell_quad_batch(FS_WANT_K) followed by fs_csr_numeric_desc (same block values, same element-order sums).
+ *
+ * The mesh is cut into PATCHES of nodes (plan built once per mesh: fem_shell_amd/fused.py restates the rules below;
+ * tests/cabi/driver.c builds a plan in plain C).  A workgroup evaluates the elements touching its patch into LDS and
+ * forms every node-pair block (I, J), I in the patch and I <= J (plus pattern-only blocks without a transposed
+ * partner), writing it to (I, J) and transposed to (J, I).
+ *   pat_eptr  [n_patches+1]  ranges into pat_elems; a patch holds <= max_patch_elems <= FS_FUSED_MAX_PATCH_ELEMS
+ *   pat_elems               element indices (rows of xyz / prop_id) of each patch; position in the range = SLOT
+ *   pat_rptr  [n_patches+1]  ranges into recs, one record per lane and round, range starts multiples of 4
+ *   recs                    fs_fused_rec: `ev` = slot | ti << 8 | tj << 10 | transposed << 12 | n << 13 |
+ *                           leader << 16 | active << 17 | serial count << 20:  the lane evaluates block (ti <= tj) of
+ *                           the element in `slot` (transposed: the block contributes as its transpose); the n <= 4
+ *                           contributions of one CSR block occupy n adjacent lanes that do not straddle a multiple
+ *                           of 4, in element order, the first one is the `leader` and carries dst / stride (entry
+ *                           (0,0) and row distance of block (I,J) in `data`, as in fs_blk_desc) and dst_t / stride_t
+ *                           of block (J,I) (dst_t = -1: none).  n = 0: pattern-only block (zeros are stored).
+ *                           n = 7: serial task, `aux` = offset of its `serial count` contribution codes (same
+ *                           slot/ti/tj/transposed bits) in ser_ev, summed in that order by the one lane.
+ *   flags     FS_FUSED_HAS_COUPLED: some property row has FS_PROP_COUPLED (0 selects the kernel without the
+ *             coupling terms; a coupled row met anyway is reported as FS_ST_BAD_PROP)
+ *   status    [E] FS_ST_* bits or NULL
+ */
+typedef struct fs_fused_rec {
+    int64_t dst;
+    int64_t dst_t;
+    int32_t stride;
+    int32_t stride_t;
+    uint32_t ev;
+    uint32_t aux;
+} fs_fused_rec; /* 32 bytes */
+#define FS_FUSED_MAX_PATCH_ELEMS 80
+#define FS_FUSED_HAS_COUPLED 1u
+int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,
+                           int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
+                           const int64_t *pat_rptr, const fs_fused_rec *recs, const uint32_t *ser_ev,
+                           int32_t max_patch_elems, uint32_t flags, double *data, int32_t *status, void *stream);
 
 /* Symbolic companion of fs_csr_numeric_blk (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph.
