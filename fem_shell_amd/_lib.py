@@ -13,7 +13,7 @@ FS_STRESS_MEMBRANE, FS_STRESS_BENDING = 1, 2
 FS_SOLID_STRESS_GP, FS_SOLID_STRESS_MEAN, FS_SOLID_STRESS_NODES = 0, 1, 2
 FS_INERTIAL_CENTRIFUGAL, FS_INERTIAL_CORIOLIS, FS_INERTIAL_EULER = 1, 2, 4
 FS_FUSED_HAS_COUPLED = 1
-FS_FUSED_MAX_PATCH_ELEMS = 80
+FS_FUSED_MAX_PATCH_ELEMS = 64
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
 
@@ -24,7 +24,7 @@ SIGNATURES = {
     "fs_shell_quad_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
                                            _vp, _vp, _vp, _vp]),
     "fs_shell_quad_fint_noalloc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "fs_fused_assemble_quad": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _u32,
+    "fs_fused_assemble_quad": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _u32,
                                               _vp, _vp, _vp]),
     "fs_shell_tri_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
                                           _vp, _vp, _vp, _vp]),

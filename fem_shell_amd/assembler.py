@@ -438,7 +438,7 @@ class MeshAssembler:
         _lib.check(lib.fs_fused_assemble_quad(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
                                               len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
                                               _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]),
-                                              _lib.ptr(d["ser_ev"]), fp.max_patch_elems, self._fused_flags,
+                                              fp.max_patch_elems, self._fused_flags,
                                               _lib.ptr(data), _lib.ptr(status), _lib.stream_ptr()),
                    "fs_fused_assemble_quad")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))

@@ -586,10 +586,15 @@ struct FusedLayout {
 #define FS_EV_TI(ev) ((int)(((ev) >> 8) & 3u))
 #define FS_EV_TJ(ev) ((int)(((ev) >> 10) & 3u))
 #define FS_EV_TR(ev) ((((ev) >> 12) & 1u) != 0)
-#define FS_EV_N(ev) ((int)(((ev) >> 13) & 7u))
-#define FS_EV_LEADER(ev) ((((ev) >> 16) & 1u) != 0)
-#define FS_EV_ACTIVE(ev) ((((ev) >> 17) & 1u) != 0)
-#define FS_EV_SERCNT(ev) ((int)((ev) >> 20))
+#define FS_EV_ACTIVE(ev) ((((ev) >> 13) & 1u) != 0)
+
+// lane i reads lane i - 1 of its 16-lane row (row_shr:1); lane 0 of a row reads 0
+__device__ __forceinline__ double row_shr1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 
 template <bool COUPLED>
 __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const int *s_pid,
@@ -620,7 +625,7 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
 }
 
-template <bool COUPLED, int NT>
+template <bool COUPLED, int SP>
 __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
                                                            const fs_shell_prop *__restrict__ props, int32_t n_props,
@@ -628,115 +633,185 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                                                            const int32_t *__restrict__ pat_elems,
                                                            const int64_t *__restrict__ pat_rptr,
                                                            const fs_fused_rec *__restrict__ recs,
-                                                           const uint32_t *__restrict__ ser_ev,
-                                                           double *__restrict__ data, int32_t *__restrict__ status) {
+                                                           double *__restrict__ data, int32_t *__restrict__ status, uint32_t dbg) {
     using LY = FusedLayout<COUPLED>;
+    constexpr int NT = 4;                       // 16-element tiles of the LDS image: one per wave
     __shared__ double lds[NT * LY::TILE];
     __shared__ int s_pid[NT * 16];
+    __shared__ double2 s_stage[4 * 19 * SP];    // per wave: SP staging slots of 19 x 16 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so XCD k gets the k-th contiguous range of
-    // patches -- neighbouring patches (shared halo elements, shared CSR lines) meet in one L2
-    const int64_t per_xcd = (gridDim.x + 7) / 8;
-    const int64_t p = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (p >= n_pat) return;
-    const int64_t e0 = pat_eptr[p];
-    const int ne = (int)(pat_eptr[p + 1] - e0);
+    const int Q = lane >> 2, g = lane & 3, slot = wave * 16 + Q;
+    // PERSISTENT workgroups: workgroup w lives on XCD w & 7 (round-robin dispatch) and walks through that XCD's
+    // contiguous range of patches -- neighbouring patches (shared halo elements, shared CSR lines) meet in one L2,
+    // the stores of a patch drain while stage 1 of the next one runs, and the next patch's inputs are fetched
+    // under the tail of the current one.
+    const int xcd = blockIdx.x & 7, wpx = (int)(gridDim.x >> 3);
+    const int64_t per_xcd = (n_pat + 7) / 8;
+    int64_t p = xcd * per_xcd + (blockIdx.x >> 3);
+    const int64_t pend = ((xcd + 1) * per_xcd < n_pat) ? (xcd + 1) * per_xcd : n_pat;
+    if (p >= pend) return;
 
-    // ---------------- stage 1: the patch's elements, 16 per wave ----------------
-    for (int T = wave; T * 16 < ne; T += 4) {
-        const int Q = lane >> 2, g = lane & 3;
-        const int slot = T * 16 + Q;
-        const bool valid = slot < ne;
-        const int64_t e = pat_elems[e0 + (valid ? slot : ne - 1)];
-        double x[4][3];
-        {
-            const double2 *xp = reinterpret_cast<const double2 *>(xyz + e * 12);
-            for (int t = 0; t < 6; t++) {
-                const double2 v = xp[t];
-                (&x[0][0])[2 * t] = v.x;
-                (&x[0][0])[2 * t + 1] = v.y;
-            }
-        }
-        int pid = prop_id[e];
-        int bad = 0;
-        if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
-        const fs_shell_prop *pr = props + pid;
-        const bool flagged = (pr->flags & FS_PROP_COUPLED) != 0;
-        if (!COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
-        double *img = lds + T * LY::TILE;
-        QuadGeom geo;
-        QuadElem el;
-        quad_stage1(x, pr, COUPLED && flagged, COUPLED, g, Q, img, geo, el);
-        double *ex = img + LY::EXB + Q;
-        if (g == 0) {
-            for (int n = 0; n < 15; n++) ex[(FQ_S + n) << 4] = el.S[n];
-            s_pid[slot] = pid;
-            if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
-        } else if (g == 1) {
-            for (int t = 0; t < 18; t++) ex[(FQ_GT + t) << 4] = (&el.gt[0][0])[t];
-        } else if (g == 2) {
-            for (int k = 0; k < 3; k++) {
-                ex[(FQ_R + k) << 4] = geo.e1[k]; ex[(FQ_R + 3 + k) << 4] = geo.e2[k]; ex[(FQ_R + 6 + k) << 4] = geo.e3[k];
-            }
-        } else {
-            ex[(FQ_INV + 0) << 4] = el.i00; ex[(FQ_INV + 1) << 4] = el.i01; ex[(FQ_INV + 2) << 4] = el.i11;
-        }
+    int ne = (int)(pat_eptr[p + 1] - pat_eptr[p]);
+    int64_t e = pat_elems[pat_eptr[p] + ((slot < ne) ? slot : ne - 1)];
+    double x[4][3];
+    int pid;
+    {
+        const double2 *xp = reinterpret_cast<const double2 *>(xyz + e * 12);
+        for (int t = 0; t < 6; t++) { const double2 v = xp[t]; (&x[0][0])[2 * t] = v.x; (&x[0][0])[2 * t + 1] = v.y; }
+        pid = prop_id[e];
     }
-    __syncthreads();
-
-    // ---------------- stage 2: one contribution per lane, in-order sums inside quads ----------------
-    const int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
-    for (int64_t rb = r0; rb < r1; rb += 256) {
-        const int64_t r = rb + tid;
-        fs_fused_rec rec;
-        rec.dst = 0; rec.dst_t = -1; rec.stride = 0; rec.stride_t = 0; rec.ev = 0; rec.aux = 0;
-        if (r < r1) {
-            const int4 *rp = reinterpret_cast<const int4 *>(recs + r);
-            const int4 a = rp[0], b = rp[1];
-            rec.dst = ((int64_t)(uint32_t)a.x) | ((int64_t)a.y << 32);
-            rec.dst_t = ((int64_t)(uint32_t)a.z) | ((int64_t)a.w << 32);
-            rec.stride = b.x; rec.stride_t = b.y; rec.ev = (uint32_t)b.z; rec.aux = (uint32_t)b.w;
-        }
-        const uint32_t ev = rec.ev;
-        const int n = FS_EV_N(ev);
-        const bool serial = n == 7;
-        // X = sum of this lane's contributions: one (X = -0.0 + y == y, bit for bit) or, serial tasks, 0.0 + y0 + y1 ...
-        double X[36];
-        for (int t = 0; t < 36; t++) X[t] = serial ? 0.0 : -0.0;
-        const int nev = serial ? FS_EV_SERCNT(ev) : (FS_EV_ACTIVE(ev) ? 1 : 0);
-        for (int c = 0; c < nev; c++) {
-            const uint32_t code = serial ? ser_ev[rec.aux + c] : ev;
-            double Y[36];
-            fused_eval<COUPLED>(code, lds, s_pid, props, Y);
-            for (int t = 0; t < 36; t++) X[t] = X[t] + Y[t];
-        }
-        // in-order sum over the lanes of a group: the leader at quad position q reads q+1, q+2, q+3; absent terms
-        // are +0.0 (the padded sum of the descriptor kernel); serial tasks add -0.0, which changes nothing
-        const bool g2 = n >= 2 && n <= 4, g3 = n >= 3 && n <= 4, g4 = n == 4;
-        const double z = serial ? -0.0 : 0.0;
-        for (int t = 0; t < 36; t++) {
-            const double t1 = quad_perm<0x39>(X[t]);   // quad_perm:[1,2,3,0]: lane i reads lane i+1
-            const double t2 = quad_perm<0x4E>(X[t]);   // [2,3,0,1]
-            const double t3 = quad_perm<0x93>(X[t]);   // [3,0,1,2]
-            double a = X[t] + (g2 ? t1 : z);
-            a = a + (g3 ? t2 : z);
-            a = a + (g4 ? t3 : z);
-            X[t] = a;
-        }
-        if (FS_EV_LEADER(ev)) {
-            double *d = data + rec.dst;
-            for (int k = 0; k < 6; k++) {
-                double2 *row = reinterpret_cast<double2 *>(d + (int64_t)k * rec.stride);
-                for (int m = 0; m < 3; m++) row[m] = make_double2(X[k * 6 + 2 * m], X[k * 6 + 2 * m + 1]);
-            }
-            if (rec.dst_t >= 0) {
-                double *dt = data + rec.dst_t;
-                for (int l = 0; l < 6; l++) {
-                    double2 *row = reinterpret_cast<double2 *>(dt + (int64_t)l * rec.stride_t);
-                    for (int m = 0; m < 3; m++) row[m] = make_double2(X[(2 * m) * 6 + l], X[(2 * m + 1) * 6 + l]);
+    for (;;) {
+        // ---------------- stage 1: the patch's elements, 16 per wave ----------------
+        if (wave * 16 < ne && !(dbg & 8)) {
+            const bool valid = slot < ne;
+            int bad = 0;
+            if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
+            const fs_shell_prop *pr = props + pid;
+            const bool flagged = (pr->flags & FS_PROP_COUPLED) != 0;
+            if (!COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
+            double *img = lds + wave * LY::TILE;
+            QuadGeom geo;
+            QuadElem el;
+            quad_stage1(x, pr, COUPLED && flagged, COUPLED, g, Q, img, geo, el);
+            double *ex = img + LY::EXB + Q;
+            if (g == 0) {
+                for (int n = 0; n < 15; n++) ex[(FQ_S + n) << 4] = el.S[n];
+                s_pid[slot] = pid;
+                if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
+            } else if (g == 1) {
+                for (int t = 0; t < 18; t++) ex[(FQ_GT + t) << 4] = (&el.gt[0][0])[t];
+            } else if (g == 2) {
+                for (int k = 0; k < 3; k++) {
+                    ex[(FQ_R + k) << 4] = geo.e1[k]; ex[(FQ_R + 3 + k) << 4] = geo.e2[k]; ex[(FQ_R + 6 + k) << 4] = geo.e3[k];
                 }
+            } else {
+                ex[(FQ_INV + 0) << 4] = el.i00; ex[(FQ_INV + 1) << 4] = el.i01; ex[(FQ_INV + 2) << 4] = el.i11;
             }
         }
+        __syncthreads();
+
+        // header and element index of the next patch (its coordinates follow under the last round's stores)
+        const int64_t pn = p + wpx;
+        const bool more = pn < pend;
+        int nen = 0;
+        int64_t en = 0;
+        if (more) {
+            const int64_t e0n = pat_eptr[pn];
+            nen = (int)(pat_eptr[pn + 1] - e0n);
+            en = pat_elems[e0n + ((slot < nen) ? slot : nen - 1)];
+        }
+        double xn[12];
+        int pidn = 0;
+
+        // ---------------- stage 2: two contributions per lane, chained lanes for blocks with more ----------------
+        const int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
+        for (int64_t rb = r0; rb < r1; rb += 256) {
+            const int64_t r = rb + tid;
+            int4 ra = make_int4(-1, -1, -1, -1), rb4 = ra, rc = make_int4(0, 0, 0, 0), rd = make_int4(0, 0, 0, -1);
+            if (r < r1) {
+                const int4 *rp = reinterpret_cast<const int4 *>(recs + r);
+                ra = rp[0]; rb4 = rp[1]; rc = rp[2]; rd = rp[3];
+            }
+            const uint32_t ev0 = (uint32_t)rd.x, ev1 = (uint32_t)rd.y, fl = (uint32_t)rd.z, slots = (uint32_t)rd.w;
+            // X = first contribution (-0.0 + y == y bit for bit; blocks with more than 4 contributions start from +0.0
+            // like the descriptor kernel's loop), Y = second one (-0.0 when absent: adds nothing)
+            double X[36], Y[36];
+            const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
+            const bool a0 = FS_EV_ACTIVE(ev0) && !(dbg & 4), a1 = FS_EV_ACTIVE(ev1) && !(dbg & 4);
+            if (a0) fused_eval<COUPLED>(ev0, lds, s_pid, props, Y);
+            for (int t = 0; t < 36; t++) X[t] = a0 ? z0 + Y[t] : z0;
+            if (a1) fused_eval<COUPLED>(ev1, lds, s_pid, props, Y);
+            if (!a1)
+                for (int t = 0; t < 36; t++) Y[t] = -0.0;
+            // sums in element order: one lane x0 + x1; a lane chained to its left neighbour (R_left + x2) + x3, ...
+            // Lanes that carry two single-contribution blocks keep X and Y apart.
+            const bool two = (fl & FS_FL_OUT1) != 0, chain = (fl & FS_FL_CHAIN) != 0;
+            const int pos = (int)((fl >> 16) & 15u);
+            const int maxc = __builtin_amdgcn_readfirstlane((int)((fl >> 8) & 255u));
+            double R[36];
+            for (int t = 0; t < 36; t++) R[t] = X[t] + Y[t];
+            if (!(dbg & 2))
+            for (int it = 1; it < maxc; it++)
+                for (int t = 0; t < 36; t++) {
+                    const double T = row_shr1(R[t]);
+                    const double v = (T + X[t]) + Y[t];
+                    R[t] = (chain && pos == it) ? v : R[t];
+                }
+            // blocks with fewer than 4 contributions: the padded sum of the descriptor kernel ends in + 0.0
+            const double padv = (fl & FS_FL_PAD) ? 0.0 : -0.0;
+            for (int t = 0; t < 36; t++) {
+                X[t] = (two ? X[t] : R[t]) + padv;       // output block 0
+                Y[t] = Y[t] + padv;                      // output block 1 (lanes with two blocks)
+            }
+            // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
+            // arrive while the stores below are issued
+            if (more && rb + 256 >= r1) {
+                const double2 *xp = reinterpret_cast<const double2 *>(xyz + en * 12);
+                for (int t = 0; t < 6; t++) { const double2 v = xp[t]; xn[2 * t] = v.x; xn[2 * t + 1] = v.y; }
+                pidn = prop_id[en];
+            }
+            // ---- stores: through a wave-private LDS staging area, one block row at a time, so that the wave's store
+            // instructions sweep the memory in address order -- the plan numbers the blocks a wave stores (direct and
+            // transposed) by address (`slot`), neighbouring slots are neighbouring 48-byte row pieces of the CSR rows of
+            // consecutive nodes.  A lane that stores its own block touches 36 different lines with 36 instructions.
+            const bool st_on = !(dbg & 1);
+            const int s0d = (st_on && (fl & FS_FL_OUT0)) ? (int)(slots & 255u) : 255;
+            const int s0t = (st_on && (fl & FS_FL_OUT0)) ? (int)((slots >> 8) & 255u) : 255;
+            const int s1d = (st_on && two) ? (int)((slots >> 16) & 255u) : 255;
+            const int s1t = (st_on && two) ? (int)((slots >> 24) & 255u) : 255;
+            const int ns = __popcll(__ballot(s0d != 255)) + __popcll(__ballot(s0t != 255)) +
+                           __popcll(__ballot(s1d != 255)) + __popcll(__ballot(s1t != 255));
+            // staging slot = 19 x 16 bytes: the block's 18 pieces (row k, piece c at 3 k + c) and (dst, stride); the
+            // odd slot size keeps the 8-lane groups of ds_write_b128 on distinct banks
+            double2 *stg = s_stage + wave * (19 * SP);
+            const int64_t dst0 = ((int64_t)(uint32_t)ra.x) | ((int64_t)ra.y << 32), dst1 = ((int64_t)(uint32_t)ra.z) | ((int64_t)ra.w << 32);
+            const int64_t dst0t = ((int64_t)(uint32_t)rb4.x) | ((int64_t)rb4.y << 32), dst1t = ((int64_t)(uint32_t)rb4.z) | ((int64_t)rb4.w << 32);
+            const int rbk = (lane * 21846) >> 16, rcc = lane - 3 * rbk;        // readback: block lane / 3, piece lane % 3
+            for (int s0 = 0; s0 < ns; s0 += SP) {
+                const int q0d = s0d - s0, q0t = s0t - s0, q1d = s1d - s0, q1t = s1t - s0;
+                if (s0d != 255 && q0d >= 0 && q0d < SP) {
+                    double2 *sp = stg + q0d * 19;
+                    for (int t = 0; t < 18; t++) sp[t] = make_double2(X[2 * t], X[2 * t + 1]);
+                    sp[18] = make_double2(__longlong_as_double(dst0), __longlong_as_double((long long)rc.x));
+                }
+                if (s0t != 255 && q0t >= 0 && q0t < SP) {
+                    double2 *sp = stg + q0t * 19;
+                    for (int k = 0; k < 6; k++)
+                        for (int m = 0; m < 3; m++) sp[k * 3 + m] = make_double2(X[(2 * m) * 6 + k], X[(2 * m + 1) * 6 + k]);
+                    sp[18] = make_double2(__longlong_as_double(dst0t), __longlong_as_double((long long)rc.z));
+                }
+                if (s1d != 255 && q1d >= 0 && q1d < SP) {
+                    double2 *sp = stg + q1d * 19;
+                    for (int t = 0; t < 18; t++) sp[t] = make_double2(Y[2 * t], Y[2 * t + 1]);
+                    sp[18] = make_double2(__longlong_as_double(dst1), __longlong_as_double((long long)rc.y));
+                }
+                if (s1t != 255 && q1t >= 0 && q1t < SP) {
+                    double2 *sp = stg + q1t * 19;
+                    for (int k = 0; k < 6; k++)
+                        for (int m = 0; m < 3; m++) sp[k * 3 + m] = make_double2(Y[(2 * m) * 6 + k], Y[(2 * m + 1) * 6 + k]);
+                    sp[18] = make_double2(__longlong_as_double(dst1t), __longlong_as_double((long long)rc.w));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // lane -> (block lane / 3, piece lane % 3): one store instruction per row k covers row k of all SP
+                // blocks, neighbouring lanes on neighbouring 16-byte pieces
+                if (rbk < SP && s0 + rbk < ns) {
+                    const double2 *sp = stg + rbk * 19;
+                    const double2 t = sp[18];
+                    double *d = data + (int64_t)__double_as_longlong(t.x) + 2 * rcc;
+                    const int64_t str = (int64_t)__double_as_longlong(t.y);
+                    double2 v[6];
+                    for (int k = 0; k < 6; k++) v[k] = sp[k * 3 + rcc];
+                    for (int k = 0; k < 6; k++) *reinterpret_cast<double2 *>(d + k * str) = v[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!more) break;
+        __syncthreads();        // every wave is done with the image: stage 1 of the next patch may overwrite it
+        p = pn; ne = nen; e = en; pid = pidn;
+        for (int t = 0; t < 12; t++) (&x[0][0])[t] = xn[t];
     }
 }
 
@@ -3333,23 +3408,32 @@ int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const 
 
 int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,
                            int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
-                           const int64_t *pat_rptr, const fs_fused_rec *recs, const uint32_t *ser_ev,
-                           int32_t max_patch_elems, uint32_t flags, double *data, int32_t *status, void *stream) {
+                           const int64_t *pat_rptr, const fs_fused_rec *recs, int32_t max_patch_elems,
+                           uint32_t flags, double *data, int32_t *status, void *stream) {
     if (E < 0 || n_props <= 0 || n_patches < 0) return fail(FS_EINVAL, "fs_fused_assemble_quad: bad sizes");
     if (E == 0 || n_patches == 0) return FS_OK;
     if (!xyz || !prop_id || !props || !pat_eptr || !pat_elems || !pat_rptr || !recs || !data)
         return fail(FS_EINVAL, "fs_fused_assemble_quad: null argument");
     if (max_patch_elems <= 0 || max_patch_elems > FS_FUSED_MAX_PATCH_ELEMS)
         return fail(FS_EINVAL, "fs_fused_assemble_quad: a patch may hold at most FS_FUSED_MAX_PATCH_ELEMS elements");
-    if (n_patches > (int64_t)INT32_MAX - 8) return fail(FS_EINVAL, "fs_fused_assemble_quad: too many patches");
     hipStream_t s = (hipStream_t)stream;
-    const unsigned grid = (unsigned)(((n_patches + 7) / 8) * 8);
-#define FS_FUSED_LAUNCH(C, NT)                                                                                       \
-    hipLaunchKernelGGL((fused_quad_k_kernel<C, NT>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
-                       n_patches, pat_eptr, pat_elems, pat_rptr, recs, ser_ev, data, status)
-    const bool coupled = (flags & FS_FUSED_HAS_COUPLED) != 0;
-    if (max_patch_elems <= 64) { if (coupled) FS_FUSED_LAUNCH(true, 4); else FS_FUSED_LAUNCH(false, 4); }
-    else { if (coupled) FS_FUSED_LAUNCH(true, 5); else FS_FUSED_LAUNCH(false, 5); }
+    // persistent workgroups: as many as are resident at once (one per CU with the 124 KB image), a multiple of 8
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(FS_EHIP, "fs_fused_assemble_quad: hipGetDeviceProperties");
+        cus = prop.multiProcessorCount;
+    }
+    int64_t wgs = ((int64_t)cus / 8) * 8;
+    if (wgs < 8) wgs = 8;
+    if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
+    const unsigned grid = (unsigned)wgs;
+#define FS_FUSED_LAUNCH(C)                                                                                           \
+    hipLaunchKernelGGL((fused_quad_k_kernel<C, 21>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
+                       n_patches, pat_eptr, pat_elems, pat_rptr, recs, data, status, flags >> 8)
+    if (flags & FS_FUSED_HAS_COUPLED) FS_FUSED_LAUNCH(true); else FS_FUSED_LAUNCH(false);
 #undef FS_FUSED_LAUNCH
     FS_LAUNCH_CHECK("fused_quad_k_kernel");
     return FS_OK;

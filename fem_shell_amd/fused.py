@@ -19,8 +19,13 @@ import numpy as np
 
 from .symbolic import _T16_RG
 
-REC_DTYPE = np.dtype([("dst", "i8"), ("dst_t", "i8"), ("stride", "i4"), ("stride_t", "i4"), ("ev", "u4"), ("aux", "u4")])
-assert REC_DTYPE.itemsize == 32
+REC_DTYPE = np.dtype([("dst", "i8", (2,)), ("dst_t", "i8", (2,)), ("stride", "i4", (2,)), ("stride_t", "i4", (2,)),
+                      ("ev", "u4", (2,)), ("flags", "u4"), ("slots", "u4")])
+assert REC_DTYPE.itemsize == 64
+# ev bits: element slot [0:8) | ti [8:10) | tj [10:12) | transposed 12 | active 13
+# flags bits (include/femshell_hip.h FS_FL_*)
+FL_CHAIN, FL_OUT0, FL_OUT1, FL_ZERO_START, FL_PAD = 1, 2, 4, 8, 16
+FL_MAXCHAIN_SHIFT, FL_POS_SHIFT = 8, 16
 
 # local node pair p -> (ti, tj), ti <= tj, of FS_LAYOUT_SYMBLK (nn = 4)
 _PAIR_I = np.array([0, 0, 0, 0, 1, 1, 1, 2, 2, 3], dtype=np.uint32)
@@ -43,32 +48,54 @@ def _t16_inverse():
 _T16_Q, _T16_P = _t16_inverse()
 
 
-def partition_nodes(coords, conn, max_elems=64, target_nodes=49):
+GROUP_NODES = 12     # nodes whose tasks share one wave (5 lanes per interior node of a structured mesh)
+GRID_NODES = 6       # nodes per grid cell along the node-numbering direction (a wave = 2 grid rows of 6)
+
+
+def _numbering_axis(coords, used):
+    """Global axis along which consecutive node indices advance (structured meshes: the fastest index)."""
+    idx = np.flatnonzero(used)
+    if idx.shape[0] < 2:
+        return 0
+    d = np.abs(coords[idx[1:]] - coords[idx[:-1]])
+    return int(np.argmax(np.median(d, axis=0)))
+
+
+def partition_nodes(coords, conn, max_elems=64):
     """node -> patch id (int64 [N]); the elements touching any patch number <= max_elems.
 
-    Grid binning with cells of sqrt(target_nodes) mean element edges (patch ids follow the grid row-major, so
-    consecutive patches are spatial neighbours), then recursive median bisection, along the longest extent, of the
-    patches that still touch too many elements."""
+    Grid binning: cells of a x b nodes, a (<= GROUP_NODES) along the direction in which consecutive node indices run
+    and a b as large as (a + 1)(b + 1) <= max_elems allows (6 x 8 nodes / 63 elements for 64; patch ids follow the
+    grid, so consecutive patches are spatial neighbours), then recursive median bisection, along the longest
+    extent, of the patches that still touch too many elements.  Any mesh works; compact patches recompute fewer
+    halo elements and rows of consecutively numbered nodes give the kernel's stores long contiguous runs."""
     coords = np.asarray(coords, dtype=np.float64)
     conn = np.asarray(conn, dtype=np.int64)
     N, E = coords.shape[0], conn.shape[0]
     if E == 0:
         return np.zeros(N, dtype=np.int64)
-    x = coords[conn]
-    # mean edge length per direction of the element's local numbering (anisotropic meshes get anisotropic cells
-    # only through the bisection step; the grid uses the geometric mean)
-    h1 = float(np.linalg.norm(x[:, 1] - x[:, 0], axis=1).mean())
-    h2 = float(np.linalg.norm(x[:, 3] - x[:, 0], axis=1).mean())
-    h = max(np.sqrt(h1 * h2), 1e-300)
-    side = np.sqrt(float(target_nodes)) * h
     used = np.zeros(N, dtype=bool)
     used[conn.reshape(-1)] = True
-    lo = coords[used].min(axis=0) - 0.5 * h
-    b = np.floor((coords - lo) / side).astype(np.int64)
-    b = np.clip(b, 0, None)
+    x = coords[conn]
+    e1, e2 = np.abs(x[:, 1] - x[:, 0]), np.abs(x[:, 3] - x[:, 0])
+    hk = np.maximum(np.maximum(e1, e2).mean(axis=0), 1e-300)          # node spacing seen along each global axis
+    hmax = float(hk.max())
+    hk = np.maximum(hk, 1e-3 * hmax)
+    best = (1, 1)
+    for a in range(1, GRID_NODES + 1):
+        for bb in range(1, 40):
+            if (a + 1) * (bb + 1) <= max_elems and a * bb > best[0] * best[1]:
+                best = (a, bb)
+    ax = _numbering_axis(coords, used)
+    nodes_per_cell = np.full(3, float(best[1]))
+    nodes_per_cell[ax] = float(best[0])
+    side = nodes_per_cell * hk
+    lo = coords[used].min(axis=0) - 0.5 * hk
+    b = np.clip(np.floor((coords - lo) / side).astype(np.int64), 0, None)
     nb = b[used].max(axis=0) + 1
     b = np.minimum(b, nb - 1)
-    key = (b[:, 2] * nb[1] + b[:, 1]) * nb[0] + b[:, 0]
+    order_axes = [ax] + [k for k in range(3) if k != ax]              # numbering axis fastest
+    key = (b[:, order_axes[2]] * nb[order_axes[1]] + b[:, order_axes[1]]) * nb[ax] + b[:, ax]
     _, patch = np.unique(key, return_inverse=True)
     patch = patch.astype(np.int64)
     earange = np.repeat(np.arange(E, dtype=np.int64), conn.shape[1])
@@ -87,7 +114,7 @@ def partition_nodes(coords, conn, max_elems=64, target_nodes=49):
         seg = np.cumsum(np.r_[False, pb[1:] != pb[:-1]])
         size = np.diff(np.r_[starts, pb.shape[0]])
         c = coords[nodes]
-        ext = np.maximum.reduceat(c, starts, axis=0) - np.minimum.reduceat(c, starts, axis=0)
+        ext = (np.maximum.reduceat(c, starts, axis=0) - np.minimum.reduceat(c, starts, axis=0)) / hk
         axis = np.argmax(ext, axis=1)
         val = c[np.arange(c.shape[0]), axis[seg]]
         o2 = np.lexsort((val, seg))                      # inside each patch: nodes by the chosen coordinate
@@ -101,15 +128,22 @@ def partition_nodes(coords, conn, max_elems=64, target_nodes=49):
 
 
 class FusedQuadPlan:
-    """Host arrays of fs_fused_assemble_quad's plan: pat_eptr, pat_elems, pat_rptr, recs, ser_ev."""
+    """Host arrays of fs_fused_assemble_quad's plan: pat_eptr, pat_elems, pat_rptr, recs (one 64-byte record per lane).
+
+    A lane evaluates TWO contributions (step 0, step 1).  A block with n contributions (element order x0, x1, ...):
+      n = 3, 4   two adjacent lanes A, B:  A -> x0, x1;  B -> x2, x3 and, chained to A, ((x0 + x1) + x2) + x3
+      n = 2      one lane: x0 + x1                          (n < 4: + 0.0, the padded sum of fs_csr_numeric_desc)
+      n <= 1     half a lane: two such blocks share a lane (step 0 -> block 0, step 1 -> block 1)
+      n > 4      ceil(n / 2) chained lanes inside one 16-lane row, summed 0 + x0 + x1 + ... like fs_csr_numeric_desc
+    """
 
     def __init__(self, plan, conn, coords, max_patch_elems=64, node_patch=None):
         """plan: symbolic.BlockPlan (host) of a uniform quad mesh with d = 6 (tiled or element-major block indices)."""
         conn = np.asarray(conn, dtype=np.int64)
         if plan.d != 6 or conn.ndim != 2 or conn.shape[1] != 4:
             raise ValueError("the fused kernel is built for uniform MITC4+ meshes (4 nodes, 6 dofs per node)")
-        if not 16 <= max_patch_elems <= 80:
-            raise ValueError("max_patch_elems must lie in [16, 80]")
+        if not 16 <= max_patch_elems <= 64:
+            raise ValueError("max_patch_elems must lie in [16, 64]")
         E, N, d = conn.shape[0], plan.n_nodes, 6
         self.max_patch_elems = int(max_patch_elems)
         if node_patch is None:
@@ -124,38 +158,64 @@ class FusedQuadPlan:
         cnt_all = np.diff(plan.blk_ptr)
         if np.any(~has_partner & (cnt_all > 0)):
             raise ValueError("block with contributions but no transposed partner: connectivity is not symmetric")
+        if cnt_all.size and cnt_all.max() > 32:
+            raise ValueError("a node pair shared by more than 32 elements is beyond the fused kernel (use fused=False)")
         m = np.diff(plan.nbr_ptr)
         r0 = plan.nbr_ptr[I]
         dst_all = d * d * r0 + d * (np.arange(nblk, dtype=np.int64) - r0)
         stride_all = (d * m[I]).astype(np.int64)
         tb = np.flatnonzero((I <= J) | ~has_partner)
+        nt = tb.shape[0]
         t_cnt = cnt_all[tb]
-        t_patch_raw = node_patch[I[tb]]
+        lead = I[tb]
         # compact patch ids to those that own a task, keeping their order
-        upatch, t_patch = np.unique(t_patch_raw, return_inverse=True)
+        upatch, t_patch = np.unique(node_patch[lead], return_inverse=True)
         npat = upatch.shape[0]
-        serial = t_cnt > 4
-        width = np.where(serial, 1, np.where(t_cnt >= 3, 4, np.where(t_cnt == 2, 2, 1))).astype(np.int64)
-        cls = np.where(serial, 3, np.where(width == 4, 0, np.where(width == 2, 1, 2)))
-        order = np.lexsort((np.arange(tb.shape[0]), cls, t_patch))
-        tb, t_cnt, t_patch, serial, width = tb[order], t_cnt[order], t_patch[order], serial[order], width[order]
-        # lane offset of every task inside its patch (widths sorted 4, 2, 1: no group straddles a quad)
-        wsum = np.cumsum(width) - width
-        pstart = np.searchsorted(t_patch, np.arange(npat + 1))
-        pbase = wsum[np.minimum(pstart[:-1], max(tb.shape[0] - 1, 0))] if tb.shape[0] else np.zeros(npat, dtype=np.int64)
-        lanes = np.zeros(npat, dtype=np.int64)
-        np.add.at(lanes, t_patch, width)
-        lanes = (lanes + 3) // 4 * 4
-        self.pat_rptr = np.zeros(npat + 1, dtype=np.int64)
-        np.cumsum(lanes, out=self.pat_rptr[1:])
-        base = self.pat_rptr[t_patch] + (wsum - pbase[t_patch])
-        nrec = int(self.pat_rptr[-1])
+        # ---- wave groups: the tasks led by GROUP_NODES consecutive (by index) nodes of a patch share a wave; blocks
+        # with more than 4 contributions get 16-lane rows of their own in extra groups at the end of the patch ----
+        unk, ninv = np.unique(t_patch * N + lead, return_inverse=True)          # leading nodes by (patch, node)
+        npatch_of = unk // N
+        nfirst = np.searchsorted(npatch_of, np.arange(npat + 1))
+        rank = np.arange(unk.shape[0], dtype=np.int64) - nfirst[npatch_of]
+        long_t = t_cnt > 4
+        nlong = np.bincount(t_patch[long_t], minlength=npat)
+        gnorm = (np.diff(nfirst) + GROUP_NODES - 1) // GROUP_NODES             # normal groups per patch
+        gpp = gnorm + (nlong + 3) // 4
+        gbase = np.cumsum(gpp) - gpp
+        t_group = (gbase[npatch_of] + rank // GROUP_NODES)[ninv]
+        if long_t.any():
+            lt = np.flatnonzero(long_t)
+            o = np.lexsort((J[tb][lt], lead[lt], t_patch[lt]))
+            lt = lt[o]
+            lp = t_patch[lt]
+            lrank = np.arange(lt.shape[0]) - np.searchsorted(lp, lp)
+            t_group[lt] = gbase[lp] + gnorm[lp] + lrank // 4
+            long_row = np.zeros(nt, dtype=np.int64)
+            long_row[lt] = lrank % 4
+        ngroups = int(gpp.sum())
+        # half-lanes a task needs: 4 (n = 3, 4), 2 (n = 2), 1 (n <= 1); long tasks: a 16-lane row = 32 half-lanes
+        hw = np.where(long_t, 32, np.where(t_cnt >= 3, 4, np.where(t_cnt == 2, 2, 1))).astype(np.int64)
+        cls = np.where(long_t, 0, np.where(hw == 4, 1, np.where(hw == 2, 2, 3)))
+        order = np.lexsort((J[tb], lead, cls, t_group))
+        tb, t_cnt, t_patch, t_group, hw, long_t, lead = (a[order] for a in (tb, t_cnt, t_patch, t_group, hw, long_t, lead))
+        hsum = np.cumsum(hw) - hw
+        gstart = np.searchsorted(t_group, np.arange(ngroups + 1))
+        ghalf = np.zeros(ngroups, dtype=np.int64)
+        np.add.at(ghalf, t_group, hw)
+        gpad = ((ghalf + 1) // 2 + 63) // 64 * 64                              # lanes of a group: whole waves
+        grec = np.cumsum(gpad) - gpad
+        hbase = 2 * grec[t_group] + (hsum - hsum[gstart[:-1]][t_group])        # first half-lane of every task
+        nrec = int(gpad.sum())
+        self.pat_rptr = (np.append(grec[np.minimum(gbase, max(ngroups - 1, 0))], nrec).astype(np.int64)
+                         if npat else np.zeros(1, dtype=np.int64))
         rec = np.zeros(nrec, dtype=REC_DTYPE)
+        rec["dst"] = -1
         rec["dst_t"] = -1
+        rec["slots"] = 0xFFFFFFFF
         # ---- contributions -> (element, pair, transposed) ----
         start = plan.blk_ptr[tb]
         tot = int(t_cnt.sum())
-        owner = np.repeat(np.arange(tb.shape[0], dtype=np.int64), t_cnt)          # task of every contribution
+        owner = np.repeat(np.arange(nt, dtype=np.int64), t_cnt)               # task of every contribution
         within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(t_cnt) - t_cnt, t_cnt)
         cc = plan.contrib[start[owner] + within]
         src, tr = cc >> 1, (cc & 1).astype(np.uint32)
@@ -177,34 +237,63 @@ class FusedQuadPlan:
             raise ValueError(f"a patch touches {int(per_patch.max())} elements (> {max_patch_elems}): "
                              "node_patch does not respect the limit")
         slot = (inv - self.pat_eptr[t_patch[owner]]).astype(np.uint32)
-        code = slot | (_PAIR_I[pr] << 8) | (_PAIR_J[pr] << 10) | (tr << 12)
-        # ---- records ----
-        ser_c = serial[owner]
-        lane_of = base[owner] + within
-        nn = np.minimum(t_cnt, 4).astype(np.uint32)
-        rec["ev"][lane_of[~ser_c]] = code[~ser_c] | (np.uint32(1) << 17) | (nn[owner[~ser_c]] << 13)
-        # leaders (first lane of every task)
-        lead_ev = rec["ev"][base] | (np.uint32(1) << 16)
-        ns = int(serial.sum())
-        self.ser_ev = np.zeros(max(int(t_cnt[serial].sum()), 1), dtype=np.uint32)
-        if ns:
-            if t_cnt[serial].max() >= 4096:
-                raise ValueError("more than 4095 contributions to one block")
-            self.ser_ev[:int(ser_c.sum())] = code[ser_c]                   # contributions are grouped by task already
-            off = np.cumsum(t_cnt[serial]) - t_cnt[serial]
-            aux = np.zeros(tb.shape[0], dtype=np.uint32)
-            aux[serial] = off.astype(np.uint32)
-            rec["aux"][base] = aux
-            lead_ev = np.where(serial, (np.uint32(7) << 13) | (np.uint32(1) << 16) | (t_cnt.astype(np.uint32) << 20), lead_ev)
-        rec["ev"][base] = lead_ev
-        rec["dst"][base] = dst_all[tb]
-        rec["stride"][base] = stride_all[tb]
+        code = slot | (_PAIR_I[pr] << 8) | (_PAIR_J[pr] << 10) | (tr << 12) | (np.uint32(1) << 13)
+        # contribution c of a task sits at half-lane hbase + c (lane = half >> 1, step = half & 1)
+        chalf = hbase[owner] + within
+        rec["ev"][chalf >> 1, chalf & 1] = code
+        # ---- roles ----
+        lane0 = hbase >> 1
+        nl = np.where(hw >= 2, (np.maximum(t_cnt, 1) + 1) // 2, 1)            # lanes of the task (half tasks: 1)
+        last = lane0 + nl - 1                                                  # lane that emits the block
+        half_task = hw == 1
+        which = np.where(half_task, hbase & 1, 0)                              # output 0 / 1 of that lane
         off_diag = (I[tb] < J[tb]) & has_partner[tb]
-        rec["dst_t"][base] = np.where(off_diag, dst_all[pidx[tb]], -1)
-        rec["stride_t"][base] = np.where(off_diag, stride_all[pidx[tb]], 0)
+        dst, dst_t = dst_all[tb], np.where(off_diag, dst_all[pidx[tb]], -1)
+        rec["dst"][last, which], rec["stride"][last, which] = dst, stride_all[tb]
+        rec["dst_t"][last, which], rec["stride_t"][last, which] = dst_t, np.where(off_diag, stride_all[pidx[tb]], 0)
+        fl = np.zeros(nrec, dtype=np.uint32)
+        np.bitwise_or.at(fl, last, np.where(which == 0, FL_OUT0, FL_OUT1).astype(np.uint32))
+        np.bitwise_or.at(fl, last[~half_task & (t_cnt < 4)], np.uint32(FL_PAD))
+        np.bitwise_or.at(fl, last[half_task], np.uint32(FL_PAD))
+        np.bitwise_or.at(fl, lane0[long_t], np.uint32(FL_ZERO_START))
+        multi = np.flatnonzero(nl > 1)
+        if multi.size:                                                         # chained lanes: position 1 .. nl-1
+            reps = nl[multi] - 1
+            cl = np.repeat(lane0[multi], reps) + (np.arange(int(reps.sum())) - np.repeat(np.cumsum(reps) - reps, reps)) + 1
+            cpos = cl - np.repeat(lane0[multi], reps)
+            fl[cl] |= np.uint32(FL_CHAIN) | (cpos.astype(np.uint32) << FL_POS_SHIFT)
+            if np.any((cl & 15) == 0):
+                raise AssertionError("a chain crosses a 16-lane row")
+        # longest chain of every wave (uniform over the wave): the kernel's propagation loop count
+        wave_of = np.arange(nrec) >> 6
+        mc = np.ones(max(nrec >> 6, 1), dtype=np.uint32)
+        np.maximum.at(mc, lane0 >> 6, nl.astype(np.uint32))
+        fl |= mc[wave_of] << FL_MAXCHAIN_SHIFT
+        rec["flags"] = fl
+        # ---- staging slots: the blocks a wave stores (direct and transposed), numbered by address, so that the
+        # wave's stores run through memory in order ----
+        tt = np.flatnonzero(dst_t >= 0)
+        o_task = np.concatenate([np.arange(nt), tt])
+        o_addr = np.concatenate([dst, dst_t[tt]])
+        o_kind = np.concatenate([np.zeros(nt, dtype=np.int64), np.ones(tt.shape[0], dtype=np.int64)])
+        o_wave = last[o_task] >> 6
+        # inside a wave: blocks of output 0 as (I,J), then output 0 transposed, then the second blocks of two-block lanes
+        # (a staging pass then writes from one register set with most lanes active), each class by address
+        o_class = np.where(which[o_task] == 1, 2, o_kind)
+        oo = np.lexsort((o_addr, o_class, o_wave))
+        ws = o_wave[oo]
+        srank = np.arange(oo.shape[0], dtype=np.int64) - np.searchsorted(ws, ws)
+        if srank.size and srank.max() > 254:
+            raise ValueError("more than 255 blocks stored by one wave")
+        sl = rec["slots"].copy()
+        shift = (8 * (2 * which[o_task[oo]] + o_kind[oo])).astype(np.uint32)
+        ln = last[o_task[oo]]
+        np.bitwise_and.at(sl, ln, ~(np.uint32(255) << shift))
+        np.bitwise_or.at(sl, ln, srank.astype(np.uint32) << shift)
+        rec["slots"] = sl
         self.recs = rec
         self.n_patches = npat
-        self.n_tasks = int(tb.shape[0])
+        self.n_tasks = int(nt)
         self.n_evals = tot
         self.n_elem_slots = int(self.pat_elems.shape[0])
         self.E = E
@@ -216,11 +305,12 @@ class FusedQuadPlan:
         return {"patches": self.n_patches, "elements_per_patch": self.n_elem_slots / max(self.n_patches, 1),
                 "stage1_recompute": self.n_elem_slots / max(self.E, 1),
                 "stage1_tile_fill": self.n_elem_slots / max(int(tiles.sum()) * 16, 1),
-                "stage2_lane_fill": self.n_evals / max(int(rounds.sum()) * 256, 1),
+                "stage2_lane_fill": self.n_evals / max(int(rounds.sum()) * 512, 1),
+                "stage2_wave_fill": self.n_evals / max(2 * self.recs.shape[0], 1),
                 "record_bytes_per_element": self.recs.nbytes / max(self.E, 1)}
 
     def to_device(self, device):
         import torch
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         return {"pat_eptr": t(self.pat_eptr), "pat_elems": t(self.pat_elems), "pat_rptr": t(self.pat_rptr),
-                "recs": t(self.recs.view(np.uint8).reshape(-1)), "ser_ev": t(self.ser_ev.view(np.int32))}
+                "recs": t(self.recs.view(np.uint8).reshape(-1))}

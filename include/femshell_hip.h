@@ -318,34 +318,47 @@ int fs_csr_numeric_sym(const double *vals, const fs_blk_desc_sym *desc, const in
  * partner), writing it to (I, J) and transposed to (J, I).
  *   pat_eptr  [n_patches+1]  ranges into pat_elems; a patch holds <= max_patch_elems <= FS_FUSED_MAX_PATCH_ELEMS
  *   pat_elems               element indices (rows of xyz / prop_id) of each patch; position in the range = SLOT
- *   pat_rptr  [n_patches+1]  ranges into recs, one record per lane and round, range starts multiples of 4
- *   recs                    fs_fused_rec: `ev` = slot | ti << 8 | tj << 10 | transposed << 12 | n << 13 |
- *                           leader << 16 | active << 17 | serial count << 20:  the lane evaluates block (ti <= tj) of
- *                           the element in `slot` (transposed: the block contributes as its transpose); the n <= 4
- *                           contributions of one CSR block occupy n adjacent lanes that do not straddle a multiple
- *                           of 4, in element order, the first one is the `leader` and carries dst / stride (entry
- *                           (0,0) and row distance of block (I,J) in `data`, as in fs_blk_desc) and dst_t / stride_t
- *                           of block (J,I) (dst_t = -1: none).  n = 0: pattern-only block (zeros are stored).
- *                           n = 7: serial task, `aux` = offset of its `serial count` contribution codes (same
- *                           slot/ti/tj/transposed bits) in ser_ev, summed in that order by the one lane.
+ *   pat_rptr  [n_patches+1]  ranges into recs: one record per LANE, range starts multiples of 64 (whole waves)
+ *   recs      fs_fused_rec.  A lane evaluates up to two contributions ev[0], ev[1] (step 0, step 1):
+ *               ev = slot | ti << 8 | tj << 10 | transposed << 12 | active << 13 -- block (ti <= tj) of the element in
+ *               `slot` (transposed: it contributes as its transpose).
+ *             The contributions x0, x1, ... of a CSR block, in ELEMENT ORDER, occupy consecutive (lane, step)
+ *             positions: n = 2: one lane (x0 + x1); n = 3, 4: two adjacent lanes, the second one FS_FL_CHAIN at
+ *             position 1: ((x0 + x1) + x2) + x3; n > 4: more chained lanes (positions 1, 2, ...) inside one 16-lane
+ *             row, the first one FS_FL_ZERO_START (0 + x0 + x1 + ..., the order of fs_csr_numeric_desc); n <= 1: the
+ *             block takes one step of a lane, and the lane's other step may carry another such block
+ *             (FS_FL_OUT0 -> step 0 is output block 0, FS_FL_OUT1 -> step 1 is output block 1, kept apart).
+ *             FS_FL_PAD: the block has fewer than 4 contributions (its sum ends in + 0.0, as in the descriptor kernel).
+ *             The LAST lane of a block carries FS_FL_OUT0 (or OUT1) and the block's destination: dst / stride = entry
+ *             (0,0) and row distance of block (I,J) in `data` (as in fs_blk_desc), dst_t / stride_t those of block
+ *             (J,I) (-1: none).  flags bits 8..15: length of the longest chain of the lane's wave (uniform over the
+ *             wave, >= 1), bits 16..19: position of the lane in its chain.  slots: four bytes (output 0 direct,
+ *             output 0 transposed, output 1 direct, output 1 transposed; 255 = none) numbering the blocks a wave
+ *             stores by ascending address -- the order in which the wave's staged stores sweep memory.
  *   flags     FS_FUSED_HAS_COUPLED: some property row has FS_PROP_COUPLED (0 selects the kernel without the
  *             coupling terms; a coupled row met anyway is reported as FS_ST_BAD_PROP)
  *   status    [E] FS_ST_* bits or NULL
  */
 typedef struct fs_fused_rec {
-    int64_t dst;
-    int64_t dst_t;
-    int32_t stride;
-    int32_t stride_t;
-    uint32_t ev;
-    uint32_t aux;
-} fs_fused_rec; /* 32 bytes */
-#define FS_FUSED_MAX_PATCH_ELEMS 80
+    int64_t dst[2];
+    int64_t dst_t[2];
+    int32_t stride[2];
+    int32_t stride_t[2];
+    uint32_t ev[2];
+    uint32_t flags;
+    uint32_t slots;
+} fs_fused_rec; /* 64 bytes */
+#define FS_FL_CHAIN 1u
+#define FS_FL_OUT0 2u
+#define FS_FL_OUT1 4u
+#define FS_FL_ZERO_START 8u
+#define FS_FL_PAD 16u
+#define FS_FUSED_MAX_PATCH_ELEMS 64
 #define FS_FUSED_HAS_COUPLED 1u
 int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,
                            int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
-                           const int64_t *pat_rptr, const fs_fused_rec *recs, const uint32_t *ser_ev,
-                           int32_t max_patch_elems, uint32_t flags, double *data, int32_t *status, void *stream);
+                           const int64_t *pat_rptr, const fs_fused_rec *recs, int32_t max_patch_elems,
+                           uint32_t flags, double *data, int32_t *status, void *stream);
 
 /* Symbolic companion of fs_csr_numeric_blk (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph.

@@ -12,6 +12,9 @@ nx = int(sys.argv[1]) if len(sys.argv) > 2 else bench.STRIP_NX
 ny = int(sys.argv[2]) if len(sys.argv) > 2 else bench.STRIP_NY
 mpe = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 lams = bench.c5_laminates()
+import os
+if os.environ.get("FUSED_BENCH_UNCOUPLED"):
+    lams = [lams[i] for i in (0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3)]     # symmetric stacks only
 mesh = meshes.jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16)
 asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
                                         "properties": {mesh.set_names[i]: lams[i] for i in range(16)}}})
@@ -36,6 +39,9 @@ def two():
     return asm.assemble_stiffness_matrix(recompute=False)
 
 
+if os.environ.get("FUSED_BENCH_ONLY"):
+    print("fused only: %.3f ms" % timed(asm.assemble_stiffness_fused, n=int(os.environ["FUSED_BENCH_ONLY"])))
+    sys.exit(0)
 t2 = timed(two)
 tf = timed(asm.assemble_stiffness_fused)
 K2, Kf = two(), asm.assemble_stiffness_fused()
@@ -43,3 +49,7 @@ same = bool((K2.data.view(torch.int64) == Kf.data.view(torch.int64)).all())
 print(f"E={E} two-kernel {t2:.3f} ms  fused {tf:.3f} ms  ({E / tf * 1e3:.3e} el/s)  bitwise equal: {same}")
 print(f"fused step roofline: {E * 2708 / tf * 1e3 / 1e12:.2f} TB/s of 8 ({E * 2708 / tf * 1e3 / 8e12:.3f}), "
       f"{E * 27750 / tf * 1e3 / 1e12:.1f} TFLOP/s of 78.6 ({E * 27750 / tf * 1e3 / 78.6e12:.3f})")
+
+for dbg, what in ((1, "no stores"), (2, "no DPP combine"), (3, "no stores, no combine"), (4, "no evals"), (5, "no evals no stores"), (8, "no stage 1"), (12, "no stage1, no evals"), (13, "plan read only")):
+    asm._fused_flags = (asm._fused_flags & 1) | (dbg << 8)
+    print(f"  dbg {dbg:2d} ({what}): {timed(asm.assemble_stiffness_fused):.3f} ms")
