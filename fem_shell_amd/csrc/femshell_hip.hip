@@ -49,23 +49,25 @@ int fail(int code, const char *what, hipError_t e = hipSuccess) {
     } while (0)
 
 // ------------------------------------------------------------------------------------------
-// LDS layout of one wave (16 elements): component-major, g-major, then a (node, quad) swizzle:
-// in-slab index = (Q>>2)*16 + ((node+g)&3)*4 + (Q&3).  ds_write_b64 is serviced in 16-lane groups
-// over 16 double-banks (MI355X_MICROARCH.md "LDS"): the stage-1 store of one node by the 4 Gauss-point
-// lanes of 4 quads hits 16 distinct banks thanks to the +g rotation; stage-2 reads (uniform
-// component and Gauss point, per-lane node) hit 16 / 32 distinct double-banks per 16 / 32-lane group,
-// so they stay conflict-free whether the compiler emits ds_read_b64 or ds_read2_b64.
+// LDS image of a 16-element tile, [component][element Q]: what stage 2 (node-pair blocks) needs from stage 1.  It is
+// kept COMPACT -- per Gauss point only J^-1, the two edge-shear scale factors and detJ; dN/dx, dN/dy and the edge-tied
+// shear rows B_gamma are rebuilt in stage 2 from these with the very expressions stage 1 uses (same bits) -- because
+// the fused kernel holds the image of a whole patch (64 elements) and LDS capacity decides its occupancy.
+//   IM_GP   [g < 4][7]   ia ib ic id (J^-1 at Gauss point g), f1, f2 (r1 / 8 detJ, r2 / 8 detJ), detJ
+//   IM_ROT  sa ca sb cb  (shear rotation, MITC4.py:844-850 in algebraic form)
+//   IM_EX, IM_EY [4]     edge deltas 41, 21, 32, 34 in local axes
+//   IM_KNB  [c < 6][node]  condensation rows
+//   IM_S [15] IM_GT [18] IM_R [9] IM_INV [3]   membrane core, tying tangents, frame, Kbb^-1 (fused kernel only: the
+//                        element kernel keeps them in registers)
+//   IM_U    [c < 10][node] coupling cores (only when some element of the launch is coupled)
 // ------------------------------------------------------------------------------------------
-constexpr int NC = 8;  // per (node, gp): dNdx dNdy | Bs[2][3]
-constexpr int C_DN = 0, C_BS = 2;
-constexpr int LDS_DET = NC * 4 * 64;       // detJ[g][Q]
-constexpr int LDS_KNB = LDS_DET + 64;      // condensation rows Knb[c<6][node][Q]
-constexpr int LDS_U = LDS_KNB + 6 * 64;    // coupling U[c<10][node][Q] (only written when coupled)
+constexpr int IM_GP = 0, IM_ROT = 28, IM_EX = 32, IM_EY = 36, IM_KNB = 40, IM_S = 64, IM_GT = 79, IM_R = 97, IM_INV = 106;
+constexpr int IM_U = 109, IM_NC = 109, IM_NC_COUPLED = 149;
 constexpr int STG_SLOT = 38;               // staging slot of one 6x6 block: 36 doubles + 2 pad (304 B: the
                                            // 8-lane groups of ds_write_b128 then hit 32 distinct banks)
-constexpr int LDS_WAVE = LDS_U + 10 * 64;  // 3136 doubles = 25088 B
+constexpr int LDS_WAVE = IM_NC_COUPLED * 16;            // 2384 doubles = 19072 B
 constexpr int LDS_STG = LDS_WAVE;          // output staging of the tiled layout, 32 slots (half a wave per pass)
-constexpr int LDS_WAVE_T16 = LDS_STG + 32 * STG_SLOT;  // 4352 doubles = 34816 B
+constexpr int LDS_WAVE_T16 = LDS_STG + 32 * STG_SLOT;   // 3600 doubles = 28800 B
 
 // FS_LAYOUT_SYMBLK_T16 (quads only): tiles of 16 elements, 160 blocks per tile, stored in the order the
 // stiffness kernel produces them -- round 0: pairs (g,g); round 1: (g,g+1),(0,3); round 2: (0,2),(1,3);
@@ -79,10 +81,6 @@ __host__ __device__ __forceinline__ int64_t blk_t16(int64_t e, int p) {
 }
 __host__ __device__ __forceinline__ int64_t quad_blk(int tiled, int64_t e, int p) {
     return tiled ? blk_t16(e, p) : e * 10 + p;
-}
-
-__device__ __forceinline__ int lds_slot(int c, int g, int node, int Q) {
-    return ((c * 4 + g) << 6) + ((Q >> 2) << 4) + (((node + g) & 3) << 2) + (Q & 3);
 }
 
 // Exchange inside a quad of lanes through DPP quad_perm (VALU rate) instead of __shfl_xor, which
@@ -133,9 +131,9 @@ struct QuadElem {       // per-element results of stage 1 that stage 2 needs bes
     int st;             // FS_ST_* bits
 };
 
-// Stage 1 for Gauss point g of the element held by the 4 lanes of a quad: bit-faithful geometry, then the
-// strain-displacement data of this Gauss point for the 4 nodes -> LDS image `lds` (layout: lds_slot / LDS_* above,
-// element Q of the 16-element tile), bubble blocks and membrane core reduced over the quad with DPP.
+// Stage 1 for Gauss point g of the element held by the 4 lanes of a quad: bit-faithful geometry, then the data of this
+// Gauss point -> LDS image `lds` (layout IM_* above, element Q of the 16-element tile), bubble blocks and membrane
+// core reduced over the quad with DPP.
 // All four lanes of every quad must be active.  any_coupled: uniform over the quad.
 __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_shell_prop *pr, bool coupled,
                                             bool any_coupled, int g, int Q, double *lds, QuadGeom &geo, QuadElem &el) {
@@ -168,19 +166,19 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
     }
 
-    const int qoff = ((Q >> 2) << 4) + (Q & 3);
+    double *im = lds + Q;
     double (&S)[15] = el.S;
     double kbb00, kbb01, kbb11;
     {
 #pragma clang fp contract(on)
-        // shape-function derivatives in local axes (MITC4.py:642-657)
+        // shape-function derivatives in local axes (MITC4.py:642-657); stage 2 rebuilds them from J^-1 (quad_node_gp)
         double dNx[4], dNy[4];
         for (int i = 0; i < 4; i++) {
             dNx[i] = ia * dxi[i] + ib * deta[i];
             dNy[i] = ic * dxi[i] + id * deta[i];
-            lds[lds_slot(C_DN + 0, g, i, 0) + qoff] = dNx[i];
-            lds[lds_slot(C_DN + 1, g, i, 0) + qoff] = dNy[i];
         }
+        im[(IM_GP + g * 7 + 0) << 4] = ia; im[(IM_GP + g * 7 + 1) << 4] = ib;
+        im[(IM_GP + g * 7 + 2) << 4] = ic; im[(IM_GP + g * 7 + 3) << 4] = id;
         // ---- MITC4+ membrane (MITC4.py:351-392): W = T_eps * blend (3x5) ----
         const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
         const double r = xi, s = eta;
@@ -236,7 +234,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
                 for (int t = 0; t < 5; t++)
                     for (int c = 0; c < 2; c++) {
                         const double u = quad_sum(W[0][t] * LK[0][c] + W[1][t] * LK[1][c] + W[2][t] * LK[2][c]);
-                        if (j == g) lds[LDS_U + ((2 * t + c) << 6) + (j << 2) + qoff] = u;
+                        if (j == g) im[(IM_U + (2 * t + c) * 4 + j) << 4] = u;
                     }
             }
         }
@@ -271,6 +269,11 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         }
         const double d8 = 8.0 * detJ, rd8 = recip(d8);
         const double f1 = divr(r1, d8, rd8), f2 = divr(r2, d8, rd8);
+        im[(IM_GP + g * 7 + 4) << 4] = f1; im[(IM_GP + g * 7 + 5) << 4] = f2; im[(IM_GP + g * 7 + 6) << 4] = detJ;
+        if (g == 0) {
+            im[(IM_ROT + 0) << 4] = sa; im[(IM_ROT + 1) << 4] = ca; im[(IM_ROT + 2) << 4] = sb; im[(IM_ROT + 3) << 4] = cb;
+            for (int t = 0; t < 4; t++) { im[(IM_EX + t) << 4] = ex[t]; im[(IM_EY + t) << 4] = ey[t]; }
+        }
         // node -> (edge of row 0 [eta-edges 21/34], weight), (edge of row 1 [xi-edges 41/32], weight)
         const double me = 1.0 - eta, pe = 1.0 + eta, mx = 1.0 - xi, px = 1.0 + xi;
         const int e0[4] = {1, 1, 3, 3}, e1[4] = {0, 2, 2, 0};
@@ -301,8 +304,6 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             for (int k = 0; k < 3; k++) {
                 const double b0 = sb * v0[k] - sa * v1[k];
                 const double b1 = -cb * v0[k] + ca * v1[k];
-                lds[lds_slot(C_BS + k, g, i, 0) + qoff] = b0;
-                lds[lds_slot(C_BS + 3 + k, g, i, 0) + qoff] = b1;
                 double n0 = b0 * s00 + b1 * s10;
                 double n1 = b0 * s01 + b1 * s11;
                 if (k == 1) { n0 += kx0; n1 += kx1; }
@@ -311,12 +312,11 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
                 n0 = quad_sum(detJ * n0);
                 n1 = quad_sum(detJ * n1);
                 if (i == g) {
-                    lds[LDS_KNB + ((2 * k) << 6) + (i << 2) + qoff] = n0;
-                    lds[LDS_KNB + ((2 * k + 1) << 6) + (i << 2) + qoff] = n1;
+                    im[(IM_KNB + (2 * k) * 4 + i) << 4] = n0;
+                    im[(IM_KNB + (2 * k + 1) * 4 + i) << 4] = n1;
                 }
             }
         }
-        lds[LDS_DET + Q * 4 + g] = detJ;
         // Kbb = Bkb^T Cb Bkb + Bsb^T Cs Bsb
         kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
         kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
@@ -337,19 +337,54 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
     el.st = st;
 }
 
-// Stage 2: the 6x6 block of node pair (ti <= tj) of the element whose LDS image sits at element slot (qoff, Q) of
-// `lds`, in GLOBAL axes:  R^T [ Y_i^T S Y_j + sum_g detJ (B_k^T C_b B_k + B_g^T C_s B_g + k_d B_d B_d^T) [+ coupling]
-//                               - K_nb,i Kbb^-1 K_nb,j^T ] R,   symmetrised when `diag` (ti == tj; MITC4.py:1034).
-__device__ __forceinline__ void quad_pair_block(const double *lds, int qoff, int Q, int ti, int tj, bool diag,
+// Shape-function derivatives and edge-tied shear rows of node n at Gauss point (xg, yg), rebuilt from the compact
+// image with the expressions of quad_stage1 / dshape (MITC4.py:141-155, 642-657, 792-878): the factors (1 -+ eta),
+// (1 -+ xi) come out of one FMA with an exact product, the signs and the 0.25 are exact scalings -- same bits.
+struct QuadNodeConst { double qx, qy, sx, sy, c0[3], c1[3]; };   // 0.25 sx, 0.25 sy, signs, G rows of the node's 2 edges
+
+__device__ __forceinline__ void quad_node_const(const double *im, int n, QuadNodeConst &c) {
+#pragma clang fp contract(on)
+    c.sx = (n == 1 || n == 2) ? 1.0 : -1.0;
+    c.sy = (n >= 2) ? 1.0 : -1.0;
+    c.qx = 0.25 * c.sx; c.qy = 0.25 * c.sy;
+    const int e0 = (n < 2) ? 1 : 3, e1 = (n == 1 || n == 2) ? 2 : 0;     // eta-edge (21 / 34), xi-edge (41 / 32)
+    const double ex0 = im[(IM_EX + e0) << 4], ey0 = im[(IM_EY + e0) << 4];
+    const double ex1 = im[(IM_EX + e1) << 4], ey1 = im[(IM_EY + e1) << 4];
+    c.c0[0] = 0.5 * c.sx; c.c0[1] = -ey0 * 0.25; c.c0[2] = ex0 * 0.25;   // h0 = -.5 .5 .5 -.5 == 0.5 sx
+    c.c1[0] = 0.5 * c.sy; c.c1[1] = -ey1 * 0.25; c.c1[2] = ex1 * 0.25;   // h1 = -.5 -.5 .5 .5 == 0.5 sy
+}
+
+__device__ __forceinline__ void quad_node_gp(const QuadNodeConst &c, double xg, double yg, double ia, double ib,
+                                             double ic, double id, double f1, double f2, double sa, double ca,
+                                             double sb, double cb, double &dNx, double &dNy, double (&bs)[2][3]) {
+#pragma clang fp contract(on)
+    const double E = 1.0 + c.sy * yg;        // 1 -+ eta: w0 of the node, factor of dN/dxi
+    const double X = 1.0 + c.sx * xg;        // 1 -+ xi : w1 of the node, factor of dN/deta
+    const double dxi = c.qx * E, deta = c.qy * X;
+    dNx = ia * dxi + ib * deta;
+    dNy = ic * dxi + id * deta;
+    const double a0 = E * f1, a1 = X * f2;
+    for (int k = 0; k < 3; k++) {
+        const double v0 = a0 * c.c0[k], v1 = a1 * c.c1[k];
+        bs[0][k] = sb * v0 - sa * v1;
+        bs[1][k] = -cb * v0 + ca * v1;
+    }
+}
+
+// Stage 2: the 6x6 block of node pair (ti <= tj) of element Q of the image `lds`, in GLOBAL axes:
+//   R^T [ Y_i^T S Y_j + sum_g detJ (B_k^T C_b B_k + B_g^T C_s B_g + k_d B_d B_d^T) [+ coupling]
+//         - K_nb,i Kbb^-1 K_nb,j^T ] R,   symmetrised when `diag` (ti == tj; MITC4.py:1034).
+__device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti, int tj, bool diag,
                                                 const double (&Sf)[5][5], const double (&gt)[6][3],
                                                 const double (&R)[3][3], double i00, double i01, double i11,
                                                 const double (&Cb)[3][3], const double (&Cs)[2][2], double kd,
                                                 bool any_coupled, double (&G)[6][6]) {
 #pragma clang fp contract(on)
-    const int oi = (ti << 2) + qoff, oj = (tj << 2) + qoff;
-    // shape-function signs of nodes ti, tj (for N_i at the Gauss points)
-    const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
-    const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
+    const double *im = lds + Q;
+    QuadNodeConst ci, cj;
+    quad_node_const(im, ti, ci);
+    quad_node_const(im, tj, cj);
+    const double sa = im[(IM_ROT + 0) << 4], ca = im[(IM_ROT + 1) << 4], sb = im[(IM_ROT + 2) << 4], cb = im[(IM_ROT + 3) << 4];
 
     double L[6][6];
     for (int a = 0; a < 6; a++)
@@ -385,8 +420,8 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int qoff, int
         for (int c = 0; c < 2; c++) {
             double Ui[5], Uj[5];
             for (int t = 0; t < 5; t++) {
-                Ui[t] = lds[LDS_U + ((2 * t + c) << 6) + oi];
-                Uj[t] = lds[LDS_U + ((2 * t + c) << 6) + oj];
+                Ui[t] = im[(IM_U + (2 * t + c) * 4 + ti) << 4];
+                Uj[t] = im[(IM_U + (2 * t + c) * 4 + tj) << 4];
             }
             for (int a = 0; a < 3; a++) {
                 double v = L[a][3 + c], w2 = L[3 + c][a];
@@ -397,15 +432,14 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int qoff, int
     }
 
     for (int gg = 0; gg < 4; gg++) {
-        const double w = lds[LDS_DET + Q * 4 + gg];
-        const int gi = (((ti + gg) & 3) << 2) + qoff, gj = (((tj + gg) & 3) << 2) + qoff;
-        double bsi[2][3], bsj[2][3];
-        const double dxi_ = lds[(((C_DN + 0) * 4 + gg) << 6) + gi], dyi_ = lds[(((C_DN + 1) * 4 + gg) << 6) + gi];
-        const double dxj = lds[(((C_DN + 0) * 4 + gg) << 6) + gj], dyj = lds[(((C_DN + 1) * 4 + gg) << 6) + gj];
-        for (int c = 0; c < 6; c++) {
-            (&bsi[0][0])[c] = w * lds[(((C_BS + c) * 4 + gg) << 6) + gi];
-            (&bsj[0][0])[c] = lds[(((C_BS + c) * 4 + gg) << 6) + gj];
-        }
+        const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
+        const double *gp = im + ((IM_GP + gg * 7) << 4);
+        const double ia = gp[0 << 4], ib = gp[1 << 4], ic = gp[2 << 4], id = gp[3 << 4];
+        const double f1 = gp[4 << 4], f2 = gp[5 << 4], w = gp[6 << 4];
+        double dxi_, dyi_, dxj, dyj, bi[2][3], bsj[2][3], bsi[2][3];
+        quad_node_gp(ci, xg, yg, ia, ib, ic, id, f1, f2, sa, ca, sb, cb, dxi_, dyi_, bi);
+        quad_node_gp(cj, xg, yg, ia, ib, ic, id, f1, f2, sa, ca, sb, cb, dxj, dyj, bsj);
+        for (int c = 0; c < 6; c++) (&bsi[0][0])[c] = w * (&bi[0][0])[c];
         const double wdxi = w * dxi_, wdyi = w * dyi_;
         // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
         double CK[3][2];
@@ -424,9 +458,8 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int qoff, int
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(bsi[0][a], CS[0][b], FMA(bsi[1][a], CS[1][b], L[2 + a][2 + b]));
         // drilling: k w outer(Bd_i, Bd_j) on (u,v,thz)                (MITC4.py:909-928,1014)
-        const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
-        const double Ni = 0.25 * (1.0 + sxi * xg) * (1.0 + syi * yg);
-        const double Nj = 0.25 * (1.0 + sxj * xg) * (1.0 + syj * yg);
+        const double Ni = 0.25 * (1.0 + ci.sx * xg) * (1.0 + ci.sy * yg);
+        const double Nj = 0.25 * (1.0 + cj.sx * xg) * (1.0 + cj.sy * yg);
         const double bdi[3] = {-0.5 * wdyi * kd, 0.5 * wdxi * kd, -Ni * (w * kd)};
         const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
         const int dm[3] = {0, 1, 5};
@@ -437,8 +470,8 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int qoff, int
     {
         double ki[3][2], kj[3][2];
         for (int k = 0; k < 3; k++) {
-            ki[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oi]; ki[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oi];
-            kj[k][0] = lds[LDS_KNB + ((2 * k) << 6) + oj]; kj[k][1] = lds[LDS_KNB + ((2 * k + 1) << 6) + oj];
+            ki[k][0] = im[(IM_KNB + (2 * k) * 4 + ti) << 4]; ki[k][1] = im[(IM_KNB + (2 * k + 1) * 4 + ti) << 4];
+            kj[k][0] = im[(IM_KNB + (2 * k) * 4 + tj) << 4]; kj[k][1] = im[(IM_KNB + (2 * k + 1) * 4 + tj) << 4];
         }
         for (int a = 0; a < 3; a++) {
             const double h0 = ki[a][0] * i00 + ki[a][1] * i01, h1 = ki[a][0] * i01 + ki[a][1] * i11;
@@ -500,7 +533,6 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     __syncthreads();
 
     // ---------------- stage 2: node-pair tasks ----------------
-    const int qoff = ((Q >> 2) << 4) + (Q & 3);
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
@@ -520,8 +552,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
         else { ti = g & 1; tj = (g & 1) + 2; active = active && (g < 2); }
         double G[6][6];
-        quad_pair_block(lds, qoff, Q, ti, tj, round == 0, Sf, el.gt, R, el.i00, el.i01, el.i11, Cb, Cs, kd,
-                        any_coupled, G);
+        quad_pair_block(lds, Q, ti, tj, round == 0, Sf, el.gt, R, el.i00, el.i01, el.i11, Cb, Cs, kd, any_coupled, G);
         if constexpr (TILED) {
             // ---- FS_LAYOUT_SYMBLK_T16 output.  A lane that stores its own 288-byte block issues 18
             // instructions of 64 scattered 16-byte pieces; that form costs 0.45 ms of 1.58 ms per 1.25 M
@@ -574,12 +605,9 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
 // The result is bitwise the CSR of mitc4_k_kernel + csr_numeric_desc6_lds_kernel; HBM traffic per element drops from
 // 2 880 (blocks out) + 2 880 (blocks in) + 2 592 (CSR out) + 432 (descriptors) to 2 592 + ~330 (plan records).
 // ------------------------------------------------------------------------------------------
-constexpr int FQ_S = 0, FQ_GT = 15, FQ_R = 33, FQ_INV = 42, FQ_NEX = 45;   // per-element extras, [component][Q]
-
 template <bool COUPLED>
 struct FusedLayout {
-    static constexpr int EXB = COUPLED ? LDS_WAVE : LDS_U;      // extras start (uncoupled meshes: no U region)
-    static constexpr int TILE = EXB + FQ_NEX * 16;              // doubles per 16-element tile
+    static constexpr int TILE = (COUPLED ? IM_NC_COUPLED : IM_NC) * 16;     // doubles per 16-element tile
 };
 
 #define FS_EV_SLOT(ev) ((int)((ev) & 255u))
@@ -602,24 +630,23 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
     using LY = FusedLayout<COUPLED>;
     const int slot = FS_EV_SLOT(ev), ti = FS_EV_TI(ev), tj = FS_EV_TJ(ev);
     const int T = slot >> 4, Q = slot & 15;
-    const int qoff = ((Q >> 2) << 4) + (Q & 3);
     const double *img = lds + T * LY::TILE;
-    const double *ex = img + LY::EXB + Q;
+    const double *ex = img + Q;
     double Sf[5][5], gt[6][3], R[3][3];
     {
         int n = 0;
         for (int t = 0; t < 5; t++)
-            for (int u = t; u < 5; u++) { const double v = ex[(FQ_S + n) << 4]; Sf[t][u] = v; Sf[u][t] = v; n++; }
+            for (int u = t; u < 5; u++) { const double v = ex[(IM_S + n) << 4]; Sf[t][u] = v; Sf[u][t] = v; n++; }
     }
-    for (int t = 0; t < 18; t++) (&gt[0][0])[t] = ex[(FQ_GT + t) << 4];
-    for (int t = 0; t < 9; t++) (&R[0][0])[t] = ex[(FQ_R + t) << 4];
-    const double i00 = ex[(FQ_INV + 0) << 4], i01 = ex[(FQ_INV + 1) << 4], i11 = ex[(FQ_INV + 2) << 4];
+    for (int t = 0; t < 18; t++) (&gt[0][0])[t] = ex[(IM_GT + t) << 4];
+    for (int t = 0; t < 9; t++) (&R[0][0])[t] = ex[(IM_R + t) << 4];
+    const double i00 = ex[(IM_INV + 0) << 4], i01 = ex[(IM_INV + 1) << 4], i11 = ex[(IM_INV + 2) << 4];
     const fs_shell_prop *pr = props + s_pid[slot];
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
     double G[6][6];
-    quad_pair_block(img, qoff, Q, ti, tj, ti == tj, Sf, gt, R, i00, i01, i11, Cb, Cs, kd, COUPLED, G);
+    quad_pair_block(img, Q, ti, tj, ti == tj, Sf, gt, R, i00, i01, i11, Cb, Cs, kd, COUPLED, G);
     const bool tr = FS_EV_TR(ev);
     for (int k = 0; k < 6; k++)
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                                                            const int32_t *__restrict__ pat_elems,
                                                            const int64_t *__restrict__ pat_rptr,
                                                            const fs_fused_rec *__restrict__ recs,
-                                                           double *__restrict__ data, int32_t *__restrict__ status, uint32_t dbg) {
+                                                           double *__restrict__ data, int32_t *__restrict__ status) {
     using LY = FusedLayout<COUPLED>;
     constexpr int NT = 4;                       // 16-element tiles of the LDS image: one per wave
     __shared__ double lds[NT * LY::TILE];
@@ -652,6 +679,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     if (p >= pend) return;
 
     int ne = (int)(pat_eptr[p + 1] - pat_eptr[p]);
+    int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
     int64_t e = pat_elems[pat_eptr[p] + ((slot < ne) ? slot : ne - 1)];
     double x[4][3];
     int pid;
@@ -661,8 +689,14 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         pid = prop_id[e];
     }
     for (;;) {
+        // this lane's record of the first round: fetched now, used after stage 1
+        int4 pa = make_int4(-1, -1, -1, -1), pb = pa, pc4 = make_int4(0, 0, 0, 0), pd = make_int4(0, 0, 0, -1);
+        if (r0 + tid < r1) {
+            const int4 *rp = reinterpret_cast<const int4 *>(recs + r0 + tid);
+            pa = rp[0]; pb = rp[1]; pc4 = rp[2]; pd = rp[3];
+        }
         // ---------------- stage 1: the patch's elements, 16 per wave ----------------
-        if (wave * 16 < ne && !(dbg & 8)) {
+        if (wave * 16 < ne) {
             const bool valid = slot < ne;
             int bad = 0;
             if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
@@ -673,19 +707,19 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             QuadGeom geo;
             QuadElem el;
             quad_stage1(x, pr, COUPLED && flagged, COUPLED, g, Q, img, geo, el);
-            double *ex = img + LY::EXB + Q;
+            double *ex = img + Q;
             if (g == 0) {
-                for (int n = 0; n < 15; n++) ex[(FQ_S + n) << 4] = el.S[n];
+                for (int n = 0; n < 15; n++) ex[(IM_S + n) << 4] = el.S[n];
                 s_pid[slot] = pid;
                 if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
             } else if (g == 1) {
-                for (int t = 0; t < 18; t++) ex[(FQ_GT + t) << 4] = (&el.gt[0][0])[t];
+                for (int t = 0; t < 18; t++) ex[(IM_GT + t) << 4] = (&el.gt[0][0])[t];
             } else if (g == 2) {
                 for (int k = 0; k < 3; k++) {
-                    ex[(FQ_R + k) << 4] = geo.e1[k]; ex[(FQ_R + 3 + k) << 4] = geo.e2[k]; ex[(FQ_R + 6 + k) << 4] = geo.e3[k];
+                    ex[(IM_R + k) << 4] = geo.e1[k]; ex[(IM_R + 3 + k) << 4] = geo.e2[k]; ex[(IM_R + 6 + k) << 4] = geo.e3[k];
                 }
             } else {
-                ex[(FQ_INV + 0) << 4] = el.i00; ex[(FQ_INV + 1) << 4] = el.i01; ex[(FQ_INV + 2) << 4] = el.i11;
+                ex[(IM_INV + 0) << 4] = el.i00; ex[(IM_INV + 1) << 4] = el.i01; ex[(IM_INV + 2) << 4] = el.i11;
             }
         }
         __syncthreads();
@@ -694,34 +728,39 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         const int64_t pn = p + wpx;
         const bool more = pn < pend;
         int nen = 0;
-        int64_t en = 0;
+        int64_t en = 0, r0n = 0, r1n = 0;
         if (more) {
             const int64_t e0n = pat_eptr[pn];
             nen = (int)(pat_eptr[pn + 1] - e0n);
+            r0n = pat_rptr[pn]; r1n = pat_rptr[pn + 1];
             en = pat_elems[e0n + ((slot < nen) ? slot : nen - 1)];
         }
         double xn[12];
         int pidn = 0;
 
         // ---------------- stage 2: two contributions per lane, chained lanes for blocks with more ----------------
-        const int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
         for (int64_t rb = r0; rb < r1; rb += 256) {
             const int64_t r = rb + tid;
-            int4 ra = make_int4(-1, -1, -1, -1), rb4 = ra, rc = make_int4(0, 0, 0, 0), rd = make_int4(0, 0, 0, -1);
-            if (r < r1) {
-                const int4 *rp = reinterpret_cast<const int4 *>(recs + r);
-                ra = rp[0]; rb4 = rp[1]; rc = rp[2]; rd = rp[3];
+            int4 ra = pa, rb4 = pb, rc = pc4, rd = pd;
+            if (rb != r0) {          // further rounds (patches of more than 256 lanes): fetched on the spot
+                ra = make_int4(-1, -1, -1, -1); rb4 = ra; rc = make_int4(0, 0, 0, 0); rd = make_int4(0, 0, 0, -1);
+                if (r < r1) {
+                    const int4 *rp = reinterpret_cast<const int4 *>(recs + r);
+                    ra = rp[0]; rb4 = rp[1]; rc = rp[2]; rd = rp[3];
+                }
             }
             const uint32_t ev0 = (uint32_t)rd.x, ev1 = (uint32_t)rd.y, fl = (uint32_t)rd.z, slots = (uint32_t)rd.w;
             // X = first contribution (-0.0 + y == y bit for bit; blocks with more than 4 contributions start from +0.0
             // like the descriptor kernel's loop), Y = second one (-0.0 when absent: adds nothing)
             double X[36], Y[36];
             const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
-            const bool a0 = FS_EV_ACTIVE(ev0) && !(dbg & 4), a1 = FS_EV_ACTIVE(ev1) && !(dbg & 4);
+            const bool a0 = FS_EV_ACTIVE(ev0), a1 = FS_EV_ACTIVE(ev1);
             if (a0) fused_eval<COUPLED>(ev0, lds, s_pid, props, Y);
-            for (int t = 0; t < 36; t++) X[t] = a0 ? z0 + Y[t] : z0;
+            else
+                for (int t = 0; t < 36; t++) Y[t] = -0.0;
+            for (int t = 0; t < 36; t++) X[t] = z0 + Y[t];
             if (a1) fused_eval<COUPLED>(ev1, lds, s_pid, props, Y);
-            if (!a1)
+            else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
             // sums in element order: one lane x0 + x1; a lane chained to its left neighbour (R_left + x2) + x3, ...
             // Lanes that carry two single-contribution blocks keep X and Y apart.
@@ -730,7 +769,6 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             const int maxc = __builtin_amdgcn_readfirstlane((int)((fl >> 8) & 255u));
             double R[36];
             for (int t = 0; t < 36; t++) R[t] = X[t] + Y[t];
-            if (!(dbg & 2))
             for (int it = 1; it < maxc; it++)
                 for (int t = 0; t < 36; t++) {
                     const double T = row_shr1(R[t]);
@@ -754,11 +792,10 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             // instructions sweep the memory in address order -- the plan numbers the blocks a wave stores (direct and
             // transposed) by address (`slot`), neighbouring slots are neighbouring 48-byte row pieces of the CSR rows of
             // consecutive nodes.  A lane that stores its own block touches 36 different lines with 36 instructions.
-            const bool st_on = !(dbg & 1);
-            const int s0d = (st_on && (fl & FS_FL_OUT0)) ? (int)(slots & 255u) : 255;
-            const int s0t = (st_on && (fl & FS_FL_OUT0)) ? (int)((slots >> 8) & 255u) : 255;
-            const int s1d = (st_on && two) ? (int)((slots >> 16) & 255u) : 255;
-            const int s1t = (st_on && two) ? (int)((slots >> 24) & 255u) : 255;
+            const int s0d = (fl & FS_FL_OUT0) ? (int)(slots & 255u) : 255;
+            const int s0t = (fl & FS_FL_OUT0) ? (int)((slots >> 8) & 255u) : 255;
+            const int s1d = two ? (int)((slots >> 16) & 255u) : 255;
+            const int s1t = two ? (int)((slots >> 24) & 255u) : 255;
             const int ns = __popcll(__ballot(s0d != 255)) + __popcll(__ballot(s0t != 255)) +
                            __popcll(__ballot(s1d != 255)) + __popcll(__ballot(s1t != 255));
             // staging slot = 19 x 16 bytes: the block's 18 pieces (row k, piece c at 3 k + c) and (dst, stride); the
@@ -766,7 +803,6 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             double2 *stg = s_stage + wave * (19 * SP);
             const int64_t dst0 = ((int64_t)(uint32_t)ra.x) | ((int64_t)ra.y << 32), dst1 = ((int64_t)(uint32_t)ra.z) | ((int64_t)ra.w << 32);
             const int64_t dst0t = ((int64_t)(uint32_t)rb4.x) | ((int64_t)rb4.y << 32), dst1t = ((int64_t)(uint32_t)rb4.z) | ((int64_t)rb4.w << 32);
-            const int rbk = (lane * 21846) >> 16, rcc = lane - 3 * rbk;        // readback: block lane / 3, piece lane % 3
             for (int s0 = 0; s0 < ns; s0 += SP) {
                 const int q0d = s0d - s0, q0t = s0t - s0, q1d = s1d - s0, q1t = s1t - s0;
                 if (s0d != 255 && q0d >= 0 && q0d < SP) {
@@ -793,16 +829,20 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // lane -> (block lane / 3, piece lane % 3): one store instruction per row k covers row k of all SP
-                // blocks, neighbouring lanes on neighbouring 16-byte pieces
-                if (rbk < SP && s0 + rbk < ns) {
-                    const double2 *sp = stg + rbk * 19;
-                    const double2 t = sp[18];
-                    double *d = data + (int64_t)__double_as_longlong(t.x) + 2 * rcc;
-                    const int64_t str = (int64_t)__double_as_longlong(t.y);
-                    double2 v[6];
-                    for (int k = 0; k < 6; k++) v[k] = sp[k * 3 + rcc];
-                    for (int k = 0; k < 6; k++) *reinterpret_cast<double2 *>(d + k * str) = v[k];
+                // piece pc -> (block pc / 3, piece pc % 3): one store instruction per row k covers row k of 21 blocks,
+                // neighbouring lanes on neighbouring 16-byte pieces
+                for (int q = 0; q < (3 * SP + 63) / 64; q++) {
+                    const int pc = q * 64 + lane;
+                    const int bk = (pc * 21846) >> 16, cc = pc - 3 * bk;
+                    if (pc < 3 * SP && s0 + bk < ns) {
+                        const double2 *sp = stg + bk * 19;
+                        const double2 t = sp[18];
+                        double *d = data + (int64_t)__double_as_longlong(t.x) + 2 * cc;
+                        const int64_t str = (int64_t)__double_as_longlong(t.y);
+                        double2 v[6];
+                        for (int k = 0; k < 6; k++) v[k] = sp[k * 3 + cc];
+                        for (int k = 0; k < 6; k++) *reinterpret_cast<double2 *>(d + k * str) = v[k];
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -810,7 +850,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         }
         if (!more) break;
         __syncthreads();        // every wave is done with the image: stage 1 of the next patch may overwrite it
-        p = pn; ne = nen; e = en; pid = pidn;
+        p = pn; ne = nen; e = en; pid = pidn; r0 = r0n; r1 = r1n;
         for (int t = 0; t < 12; t++) (&x[0][0])[t] = xn[t];
     }
 }
@@ -3431,8 +3471,8 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
     const unsigned grid = (unsigned)wgs;
 #define FS_FUSED_LAUNCH(C)                                                                                           \
-    hipLaunchKernelGGL((fused_quad_k_kernel<C, 21>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
-                       n_patches, pat_eptr, pat_elems, pat_rptr, recs, data, status, flags >> 8)
+    hipLaunchKernelGGL((fused_quad_k_kernel<C, 63>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
+                       n_patches, pat_eptr, pat_elems, pat_rptr, recs, data, status)
     if (flags & FS_FUSED_HAS_COUPLED) FS_FUSED_LAUNCH(true); else FS_FUSED_LAUNCH(false);
 #undef FS_FUSED_LAUNCH
     FS_LAUNCH_CHECK("fused_quad_k_kernel");

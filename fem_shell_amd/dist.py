@@ -168,6 +168,7 @@ class DistributedPlan:
         key = I.astype(np.int64) * P.n_nodes + J
         allkey = P.blk_row.astype(np.int64) * P.n_nodes + P.nbr
         b = np.searchsorted(allkey, key)
+        b = np.minimum(b, max(allkey.shape[0] - 1, 0))
         assert np.array_equal(allkey[b], key), "exchange pair missing from the local pattern"
         r0 = P.nbr_ptr[I]
         base = d * d * r0 + d * (b - r0)                       # entry (k=0,l=0)
@@ -230,8 +231,10 @@ class DistributedAssembler:
         from .meshes import ArrayMesh
         X = self.dplan.nodes_g
         coords = np.full((X.shape[0], 3), np.nan)
-        order = np.argsort(np.asarray(l2g), kind="stable")
-        coords[np.searchsorted(X, np.asarray(l2g)[order])] = mesh.coords[order]
+        l2g = np.asarray(l2g, dtype=np.int64)
+        pos = np.minimum(np.searchsorted(X, l2g), X.shape[0] - 1)
+        sel = X[pos] == l2g                      # local nodes no element references are not part of the plan
+        coords[pos[sel]] = mesh.coords[sel]
         ext = ArrayMesh(coords, self.dplan.conn_x, mesh.set_id, mesh.set_names)
         self.local = MeshAssembler(ext, model, plan=self.dplan.plan)
         dev = self.local.device
@@ -267,6 +270,9 @@ class DistributedAssembler:
             return self._exchange_on_current_stream(A)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
+        # the values were allocated on the caller's stream and are packed from / added into on the side stream: tell
+        # the caching allocator, or a caller that drops the matrix early could see its block reused under the exchange
+        A.data.record_stream(self._comm)
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ready)
             self._exchange_on_current_stream(A)

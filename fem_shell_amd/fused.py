@@ -91,7 +91,8 @@ def partition_nodes(coords, conn, max_elems=64):
     nodes_per_cell[ax] = float(best[0])
     side = nodes_per_cell * hk
     lo = coords[used].min(axis=0) - 0.5 * hk
-    b = np.clip(np.floor((coords - lo) / side).astype(np.int64), 0, None)
+    cc = np.where(used[:, None], coords, lo)          # nodes no element touches (ghost columns) may carry NaN
+    b = np.clip(np.floor((cc - lo) / side).astype(np.int64), 0, None)
     nb = b[used].max(axis=0) + 1
     b = np.minimum(b, nb - 1)
     order_axes = [ax] + [k for k in range(3) if k != ax]              # numbering axis fastest

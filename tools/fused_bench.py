@@ -50,6 +50,3 @@ print(f"E={E} two-kernel {t2:.3f} ms  fused {tf:.3f} ms  ({E / tf * 1e3:.3e} el/
 print(f"fused step roofline: {E * 2708 / tf * 1e3 / 1e12:.2f} TB/s of 8 ({E * 2708 / tf * 1e3 / 8e12:.3f}), "
       f"{E * 27750 / tf * 1e3 / 1e12:.1f} TFLOP/s of 78.6 ({E * 27750 / tf * 1e3 / 78.6e12:.3f})")
 
-for dbg, what in ((1, "no stores"), (2, "no DPP combine"), (3, "no stores, no combine"), (4, "no evals"), (5, "no evals no stores"), (8, "no stage 1"), (12, "no stage1, no evals"), (13, "plan read only")):
-    asm._fused_flags = (asm._fused_flags & 1) | (dbg << 8)
-    print(f"  dbg {dbg:2d} ({what}): {timed(asm.assemble_stiffness_fused):.3f} ms")
