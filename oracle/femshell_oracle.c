@@ -752,6 +752,44 @@ int fso_csr_numeric(const int64_t *dofs, int64_t E, int nd, const double *vals_e
     return 0;
 }
 
+/* Row-parallel form of fso_csr_numeric for the CPU baseline (bench.py): every row gathers the rows of the element
+ * matrices that touch it, elements in ascending order -- the same sums in the same order as the element loop above
+ * (core/assembler.py:295-300), so the result is bit-identical, but rows are independent and go to OpenMP threads. */
+int fso_csr_numeric_rows(const int64_t *dofs, int64_t E, int nd, const double *vals_e, int64_t ndof,
+                         const int64_t *indptr, const int32_t *indices, double *data, int nthreads) {
+    int64_t *cnt = (int64_t *)calloc(ndof + 1, sizeof(int64_t));
+    for (int64_t e = 0; e < E; e++)
+        for (int a = 0; a < nd; a++) cnt[dofs[e * nd + a] + 1]++;
+    for (int64_t r = 0; r < ndof; r++) cnt[r + 1] += cnt[r];
+    int64_t *el = (int64_t *)malloc((cnt[ndof] > 0 ? cnt[ndof] : 1) * sizeof(int64_t));   /* (element * nd + a) per row */
+    int64_t *pos = (int64_t *)malloc((ndof + 1) * sizeof(int64_t));
+    memcpy(pos, cnt, (ndof + 1) * sizeof(int64_t));
+    for (int64_t e = 0; e < E; e++)
+        for (int a = 0; a < nd; a++) el[pos[dofs[e * nd + a]]++] = e * nd + a;
+    int bad = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static) reduction(| : bad)
+#endif
+    for (int64_t r = 0; r < ndof; r++) {
+        const int64_t lo0 = indptr[r], hi0 = indptr[r + 1];
+        for (int64_t q = cnt[r]; q < cnt[r + 1]; q++) {
+            const int64_t e = el[q] / nd;
+            const int a = (int)(el[q] - e * nd);
+            const int64_t *d = dofs + e * nd;
+            const double *ke = vals_e + ((int64_t)e * nd + a) * nd;
+            for (int b = 0; b < nd; b++) {
+                int64_t c = d[b], lo = lo0, hi = hi0;
+                while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (indices[mid] < c) lo = mid + 1; else hi = mid; }
+                if (lo >= hi0 || indices[lo] != c) { bad = 1; continue; }
+                data[lo] += ke[b];
+            }
+        }
+    }
+    free(pos); free(el); free(cnt);
+    return bad ? -1 : 0;
+}
+
 /* ====================================================================================
  * MITC3+ (elements/MITC3.py): CST membrane + drilling, enriched-rotation bending, 6-tying-point
  * assumed shear, cubic bubble condensed 20 -> 18.  Literal dense restatement.

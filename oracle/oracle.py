@@ -179,6 +179,18 @@ def csr_assemble(dofs, ndof, vals_e):
     return indptr, indices, data
 
 
+def csr_numeric_rows(dofs, ndof, vals_e, indptr, indices, nthreads=0):
+    """Row-parallel element-order summation (fso_csr_numeric_rows): bit-identical to csr_assemble's values."""
+    dofs = np.ascontiguousarray(dofs, dtype=np.int64)
+    vals_e = np.ascontiguousarray(vals_e, dtype=np.float64)
+    E, nd = dofs.shape
+    data = np.zeros(indices.shape[0])
+    rc = lib().fso_csr_numeric_rows(_p(dofs), ctypes.c_int64(E), ctypes.c_int(nd), _p(vals_e), ctypes.c_int64(ndof),
+                                    _p(indptr), _p(indices), _p(data), ctypes.c_int(nthreads))
+    assert rc == 0
+    return data
+
+
 def csr_assemble_mixed(dofs_list, ndof, ke_list):
     """Mixed-mesh branch of the reference assembler (core/assembler.py:232-241 pattern by set
     union, :287-292 values added element by element).  Pure NumPy/Python: small meshes only."""

@@ -255,3 +255,18 @@ def test_centrifugal_prestress_vs_reference(oracle):
             s = oracle.centrifugal(g[f"sxyz{nn}"][e], float(g[f"srho{nn}"][e]), par[0], par[1:4], par[4:7], shell=False)
             ref = g[f"scf{nn}"][e]
             assert np.abs(s - ref).max() <= 1e-13 * max(np.abs(ref).max(), 1e-300), (nn, e)
+
+
+def test_row_parallel_csr_summation_is_bit_identical(oracle):
+    """bench.py's all-core CPU baseline sums rows in parallel (fso_csr_numeric_rows): same sums, same element order."""
+    from fem_shell_amd import meshes
+    import fem_shell_amd as fsa
+    from tests import util
+    mesh = meshes.jittered_plate(23, 17, n_sets=8)
+    table = fsa.build_prop_table(util.standard_props())
+    Ke, _ = oracle.mitc4_K_batch(mesh.coords[mesh.conn], mesh.set_id, table)
+    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
+    ip, ix, kd = oracle.csr_assemble(dofs, mesh.node_count * 6, Ke)
+    for nt in (1, 3):
+        assert np.array_equal(oracle.csr_numeric_rows(dofs, mesh.node_count * 6, Ke, ip, ix, nthreads=nt).view(np.int64),
+                              kd.view(np.int64))
