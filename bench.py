@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- MITC4+ element stiffness matrices assembled into CSR per second (fp64).
 
-One "step" = one pass of the hot path over the rank's shard: HIP element kernel (K of every
-element, FS_LAYOUT_SYMBLK) + node-pair-block CSR assembly (+ interface-row exchange when N > 1).
-Inputs (coordinates, connectivity, property table, scatter plan) are resident in HBM before the
-timed region; the symbolic phase (pattern + plan) is precomputed, as north_star specifies.
+One "step" = one pass of the hot path over the rank's shard: ONE launch of the fused evaluate-and-assemble kernel
+(fs_fused_assemble_quad: element K of every element and the element-order CSR sums, no element matrices in memory;
++ interface-row exchange when N > 1).  Inputs (coordinates, property table, patch plan, CSR pattern) are resident in
+HBM before the timed region; the symbolic phase (pattern + plans) is precomputed, as north_star specifies.
 
-Workload (BASELINE.json configs[4], the configuration the metric is quoted on, weak-scaled):
-each rank owns a 400 x 3125 strip (1.25 M elements) of the synthetic 3200 x 3125 = 10 M element
-MITC4+ laminate plate (16 laminates striped by x-band, jittered nodes); at N = 8
-the job is the full 10 M element plate.  configs[1] (256x256 hemisphere / twisted beam) and the
-others are parity-test cases (tests/), not bench lines.
+Workload (BASELINE.json configs[4], the configuration the metric is quoted on): the synthetic 3200 x 3125 = 10 M element
+MITC4+ laminate plate (16 laminates striped by x-band, jittered nodes).
+  N = 1   the whole 10 M plate on one GPU (about 75 GB of device memory) is `value`; the 400 x 3125 strip one rank owns at
+          N = 8 is timed in the same run and reported as `weak_scaling_point`.
+  N > 1   each rank owns a 400 x 3125 strip (1.25 M elements; the full plate at N = 8), x-strip partition, interface rows
+          exchanged with the two neighbours over RCCL.
+configs[0..3] and the HEXA8 block of configs[4] are timed in their own legs outside `value`; tests/ holds their parity.
 
 Contract: python bench.py --gpus N --steps K --warmup W  (N > 1: launched by torch.distributed.run,
 one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
@@ -18,6 +20,7 @@ one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,10 +30,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STRIP_NX, STRIP_NY = 400, 3125
-FLOP_PER_ELEM = 27000.0           # MITC4+ K, structured count
-FLOP_PER_ELEM_COUPLING = 4000.0   # + laminate coupling (asymmetric layups only)
-PEAK_FP64_TFLOPS = 78.6           # MI355X fp64 vector == matrix peak
+FULL_NX, FULL_NY = 3200, 3125
+# bench/FLOPS.md (tools/count_flops.py: fp64 instruction count of the shipped device functions, FMA = 2):
+FLOP_PER_ELEM = 18779.0           # algorithmic, geometry once per element
+FLOP_PER_ELEM_COUPLED = 21783.0   # membrane-bending coupling active (asymmetric laminates)
+BYTES_PER_ELEM = 2708.0           # SURVEY.md 8(d) fused path: 96 B coordinates + 4 B property id + 4 B status
+                                  # + 324 amortised CSR values x 8 B (+ 12 B of node / pattern data it rounds in)
+PEAK_FP64_TFLOPS = 78.6           # MI355X fp64 vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def log(msg):
+    """Progress on stderr (the one JSON line goes to stdout)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def avg_ms(torch, fn, steps):
+    """Average GPU time of fn() over `steps` back-to-back calls, HIP events on the launch stream (torch's current
+    stream is the stream every fs_* call is given)."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
 
 
 def c5_laminates():
@@ -59,46 +86,83 @@ def c5_laminates():
     return lams
 
 
-def cpu_baseline(n_threads):
-    """Oracle (CPU restatement of the reference algorithm, oracle/) on a bounded sample of the same
-    workload: element K for a 400 x 1250 piece of the strip on all host threads + element-order
-    CSR summation.  Reported baseline only."""
+def host_threads():
+    """Threads for the all-core figure: the CPUs this process may really use.  On the GPU box os.cpu_count() shows the
+    whole machine while the job owns a 16-CPU share (the harness exports OMP_NUM_THREADS = 16 for that reason)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return n
+
+
+def cpu_baseline():
+    """Oracle (CPU restatement of the reference algorithm, oracle/) on bounded samples of the same workload.  `value` is
+    the all-core figure: element K on every usable host thread + row-parallel element-order CSR summation
+    (fso_csr_numeric_rows, bit-identical to the serial loop) on the same threads.  Also reported: one core, and the
+    route of the reference's own benchmark (tests/benchmarks/test_ko2017_performance.py:365-398): element matrices ->
+    COO triplets -> scipy coo_matrix.tocsr().  Reported baselines only."""
     import fem_shell_amd as fsa
     from fem_shell_amd import meshes
     from oracle import oracle as O
-    nx, ny = 400, 1250      # 500 000 elements: about 10 CPU-seconds of oracle work, 2.3 GB of dense element matrices
-    mesh = meshes.jittered_plate(nx, ny, n_sets=16)
+    from scipy.sparse import coo_matrix
+    nt = host_threads()
     table = fsa.build_prop_table(c5_laminates())
-    pid = mesh.set_id.astype(np.int32)
-    xyz = mesh.coords[mesh.conn]
-    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
-    indptr, indices, _ = O.csr_assemble(dofs, mesh.node_count * 6, None)   # symbolic: untimed
-    O.mitc4_K_batch(xyz[:1000], pid[:1000], table, nthreads=n_threads)    # warm the library
+
+    def sample(nx, ny):
+        mesh = meshes.jittered_plate(nx, ny, n_sets=16)
+        dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
+        return mesh, mesh.coords[mesh.conn], mesh.set_id.astype(np.int32), dofs
+
+    def run(nx, ny, threads):
+        mesh, xyz, pid, dofs = sample(nx, ny)
+        indptr, indices, _ = O.csr_assemble(dofs, mesh.node_count * 6, None)      # symbolic: untimed
+        O.mitc4_K_batch(xyz[:1000], pid[:1000], table, nthreads=threads)          # warm the library
+        t0 = time.perf_counter()
+        Ke, _ = O.mitc4_K_batch(xyz, pid, table, nthreads=threads)
+        t1 = time.perf_counter()
+        O.csr_numeric_rows(dofs, mesh.node_count * 6, Ke, indptr, indices, nthreads=threads)
+        t2 = time.perf_counter()
+        E = xyz.shape[0]
+        return E, E / (t2 - t0), E / (t1 - t0), E / (t2 - t1)
+
+    nx, ny = 400, 1250          # 500 000 elements, 2.3 GB of dense element matrices
+    E, v_all, k_all, a_all = run(nx, ny, nt)
+    E1, v_one, k_one, a_one = run(400, 100, 1)
+    # the reference benchmark's route, vectorised: all-core oracle K, NumPy triplets, SciPy COO -> CSR
+    mesh, xyz, pid, dofs = sample(400, 250)
     t0 = time.perf_counter()
-    Ke, _ = O.mitc4_K_batch(xyz, pid, table, nthreads=n_threads)
-    t1 = time.perf_counter()
-    data = np.zeros(indices.shape[0])
-    import ctypes
-    O.lib().fso_csr_numeric(O._p(dofs), ctypes.c_int64(dofs.shape[0]), ctypes.c_int(24), O._p(Ke),
-                            O._p(indptr), O._p(indices), O._p(data))
-    t2 = time.perf_counter()
-    E = xyz.shape[0]
-    return {"value": E / (t2 - t0), "unit": "elements/s", "cores": n_threads, "kind": "port",
-            "sample": f"{nx}x{ny}={E} element piece of the same jittered laminate plate; oracle C "
-                      f"element K on {n_threads} OpenMP threads ({E / (t1 - t0):.3e} el/s) + "
-                      f"single-thread element-order CSR summation ({E / (t2 - t1):.3e} el/s)"}
+    Ke, _ = O.mitc4_K_batch(xyz, pid, table, nthreads=nt)
+    rows = np.repeat(dofs, 24, axis=1).reshape(-1)
+    cols = np.tile(dofs, (1, 24)).reshape(-1)
+    n = mesh.node_count * 6
+    Kc = coo_matrix((Ke.reshape(-1), (rows, cols)), shape=(n, n)).tocsr()
+    v_coo = xyz.shape[0] / (time.perf_counter() - t0)
+    return {"value": v_all, "unit": "elements/s", "cores": nt, "kind": "port",
+            "sample": f"{nx}x{ny}={E} element piece of the same jittered laminate plate; oracle C element K on {nt} "
+                      f"OpenMP threads ({k_all:.3e} el/s) + row-parallel element-order CSR summation on {nt} threads "
+                      f"({a_all:.3e} el/s)",
+            "host_cpu_count": os.cpu_count(),
+            "single_core": {"value": v_one, "unit": "elements/s", "cores": 1, "element_K_el_per_s": k_one,
+                            "csr_summation_el_per_s": a_one, "sample": f"400x100={E1} elements"},
+            "scipy_coo_route": {"value": v_coo, "unit": "elements/s", "cores": nt, "nnz": int(Kc.nnz),
+                                "sample": f"400x250={xyz.shape[0]} elements; oracle element K on {nt} threads, NumPy "
+                                          "triplets, scipy.sparse.coo_matrix(...).tocsr() (single-threaded in SciPy)"}}
 
 
 def hex8_leg(torch, steps=5):
-    """configs[4] also names a HEXA8 block (1 048 576 bricks over 8 GPUs = 128x128x8 per GPU).  The
-    reference cannot put shells and solids into one MeshAssembler (element_family is a single
-    value, elements/elements.py:236-256), so it is a second, SOLID-family assembler; timed on its
-    own, outside `value`."""
+    """configs[4] also names a HEXA8 block of 1 048 576 bricks (128 x 128 x 64), here whole on one GPU.  The reference
+    cannot put shells and solids into one MeshAssembler (element_family is a single value, elements/elements.py:236-256),
+    so it is a second, SOLID-family assembler; timed on its own, outside `value`."""
     import fem_shell_amd as fsa
     from fem_shell_amd import meshes
     from fem_shell_amd.assembler import MeshAssembler
     from fem_shell_amd.elements import ElementFamily
-    nx, ny, nz = 128, 128, 8
+    nx, ny, nz = 128, 128, 64
     ids = np.arange((nx + 1) * (ny + 1) * (nz + 1), dtype=np.int64).reshape(nz + 1, ny + 1, nx + 1)
     Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
     coords = np.stack([X, Y, Z], -1).reshape(-1, 3) * 1e-3
@@ -108,31 +172,33 @@ def hex8_leg(torch, steps=5):
                     -1).reshape(-1, 8)
     mat = fsa.OrthotropicMaterial("T300/5208", (181e9, 10.3e9, 10.3e9), (7.17e9, 3.0e9, 7.17e9),
                                   (0.28, 0.28, 0.28), 1600.0)
+    t0 = time.perf_counter()
     asm = MeshAssembler(meshes.ArrayMesh(coords, conn),
                         {"elements": {"element_family": ElementFamily.SOLID, "material": mat}})
-    asm.assemble_stiffness_matrix(recompute=True)
+    K = asm.assemble_stiffness_matrix(recompute=True)
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    k_ms = a_ms = 0.0
-    for _ in range(steps):
-        ev[0].record()
-        asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
-        ev[1].record()
-        K = asm.assemble_stiffness_matrix(recompute=False)
-        ev[2].record()
-        torch.cuda.synchronize()
-        k_ms += ev[0].elapsed_time(ev[1]) / steps
-        a_ms += ev[1].elapsed_time(ev[2]) / steps
+    setup = time.perf_counter() - t0
+    k_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=True, want_M=False, check=False), steps)
+    a_ms = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=False), steps)
     E = conn.shape[0]
-    return {"workload": f"{nx}x{ny}x{nz}={E} jittered HEXA8, orthotropic C, SOLID-family assembler",
-            "value": E / ((k_ms + a_ms) * 1e-3), "unit": "elements/s", "solid_kernel_ms": k_ms,
-            "assembly_ms": a_ms, "nnz": int(K.nnz),
-            "k_tflops": E * 47000.0 / (k_ms * 1e-3) / 1e12, "flop_per_element": 47000.0}
+    flop = 47000.0                    # SURVEY.md 8(d) estimate for the 2x2x2 HEXA8 stiffness (not re-derived)
+    # element kernel: 192 B coordinates in, 36 upper 3x3 node-pair blocks out; assembly: those blocks in, CSR values out
+    a_bytes = 36 * 72 + 8.0 * K.nnz / E
+    return {"workload": f"{nx}x{ny}x{nz}={E} jittered HEXA8, orthotropic C, SOLID-family assembler (two kernels per step)",
+            "value": E / ((k_ms + a_ms) * 1e-3), "unit": "elements/s", "nnz": int(K.nnz), "setup_s": setup,
+            "kernels": {
+                "solid_kernel<8>": {"kernel_ms": k_ms, "bound": "valu_fp64", "achieved": E * flop / (k_ms * 1e-3) / 1e12,
+                                    "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": E * flop / (k_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "flop_per_element": flop},
+                "csr_numeric_desc3_row_kernel": {"kernel_ms": a_ms, "bound": "hbm", "achieved": E * a_bytes / (a_ms * 1e-3) / 1e9,
+                                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                 "frac": E * a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                 "bytes_per_element": a_bytes}}}
 
 
 def c2_leg(torch, steps=20):
-    """configs[1]: pinched hemisphere with an 18 degree cut-out, 256 x 256, MITC4+ (65 536 quads) and MITC3+
-    (131 072 triangles) on one GPU.  Step = element K kernel + CSR assembly, as in `value`."""
+    """configs[1]: pinched hemisphere with an 18 degree cut-out, 256 x 256, MITC4+ (65 536 quads: the fused kernel) and
+    MITC3+ (131 072 triangles: element kernel + assembly kernel) on one GPU."""
     import fem_shell_amd as fsa
     from fem_shell_amd import meshes
     from fem_shell_amd.assembler import MeshAssembler
@@ -142,25 +208,19 @@ def c2_leg(torch, steps=20):
     for tag, tri in (("mitc4_256x256", False), ("mitc3_256x256", True)):
         mesh = meshes.sphere_patch(10.0, 18.0, 90.0, 90.0, 256, triangular=tri)
         asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.04}})
-        for _ in range(3):
-            asm.assemble_stiffness_matrix(recompute=True)
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        k_ms = a_ms = 0.0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ev[0].record()
-            asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
-            ev[1].record()
-            K = asm.assemble_stiffness_matrix(recompute=False)
-            ev[2].record()
-            torch.cuda.synchronize()
-            k_ms += ev[0].elapsed_time(ev[1]) / steps
-            a_ms += ev[1].elapsed_time(ev[2]) / steps
-        wall = (time.perf_counter() - t0) / steps * 1e3
+        K = asm.assemble_stiffness_matrix(recompute=True)
         E = mesh.element_count
-        out[tag] = {"elements": E, "nnz": int(K.nnz), "element_kernel_ms": k_ms, "assembly_ms": a_ms,
-                    "ms_per_step_wall": wall, "elements_per_s": E / ((k_ms + a_ms) * 1e-3)}
+        ms = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=True), steps)
+        out[tag] = {"elements": E, "nnz": int(K.nnz), "ms_per_step": ms, "elements_per_s": E / (ms * 1e-3)}
+        if tri:
+            k_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=True, want_M=False, check=False), steps)
+            kb = 72 + 4 + 4 + 6 * 288          # 3 nodes in, 6 upper node-pair blocks out
+            out[tag]["kernels"] = {"mitc3_k_lds_kernel": {
+                "kernel_ms": k_ms, "bound": "hbm", "achieved": E * kb / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": E * kb / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_element": kb,
+                "note": "131 072 elements = 2 048 waves on 1 024 SIMDs: launch latency and the tail weigh in at this size"}}
+        else:
+            out[tag]["fused_plan"] = {k: asm.fused_plan().stats()[k] for k in ("patches", "stage1_recompute", "stage2_lane_fill")}
         del asm
     return out
 
@@ -203,48 +263,6 @@ def measured_peaks(torch):
     del a, b
     torch.cuda.empty_cache()
     return res
-
-
-def c5_full_leg(torch, steps=5):
-    """configs[4]'s shell plate at its FULL size on ONE GPU: 3200 x 3125 = 10 M MITC4+ laminate elements, 60 M dofs,
-    nnz 3.24e9 (about 103 GB of device memory).  Step = element K kernel + CSR assembly, as in `value`; skipped
-    when less than 140 GB are free."""
-    from fem_shell_amd import meshes
-    from fem_shell_amd.assembler import MeshAssembler
-    from fem_shell_amd.elements import ElementFamily
-    torch.cuda.empty_cache()
-    free = torch.cuda.mem_get_info()[0]
-    if free < 140e9:
-        return {"skipped": f"{free / 1e9:.0f} GB of device memory free"}
-    lams = c5_laminates()
-    mesh = meshes.jittered_plate(3200, 3125, cell=1e-3, seed=11, n_sets=16)
-    t0 = time.perf_counter()
-    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
-                                            "properties": {mesh.set_names[i]: lams[i] for i in range(16)}}})
-    torch.cuda.synchronize()
-    setup = time.perf_counter() - t0
-    asm.assemble_stiffness_matrix(recompute=True)
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    k_ms = a_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ev[0].record()
-        asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
-        ev[1].record()
-        K = asm.assemble_stiffness_matrix(recompute=False)
-        ev[2].record()
-        torch.cuda.synchronize()
-        k_ms += ev[0].elapsed_time(ev[1]) / steps
-        a_ms += ev[1].elapsed_time(ev[2]) / steps
-    wall = (time.perf_counter() - t0) / steps * 1e3
-    E = mesh.element_count
-    out = {"elements": E, "nnz": int(K.nnz), "element_kernel_ms": k_ms, "assembly_ms": a_ms, "ms_per_step_wall": wall,
-           "elements_per_s": E / (wall * 1e-3), "assembler_setup_s": setup,
-           "device_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
-    del asm, K
-    torch.cuda.empty_cache()
-    return out
 
 
 def c1_leg(torch, steps=50):
@@ -350,10 +368,12 @@ def c3_leg(torch, steps=10):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     E = mesh.element_count
+    st = asm.fused_plan().stats()
     return {"workload": f"tapered tube 128 x 512 = {E} MITC4+ laminate elements, {len(asm._prop_table)} property rows, "
                         f"{int((asm._prop_table['flags'] & 1).sum())} with membrane-bending coupling",
             "ms_per_step": ms, "elements_per_s": E / (ms * 1e-3), "nnz": int(K.nnz),
-            "what": "K and M (element kernels + CSR assembly), row-sum lumping, centrifugal nodal loads"}
+            "fused_plan": {k: st[k] for k in ("patches", "stage1_recompute", "stage2_lane_fill")},
+            "what": "K (fused kernel) and M (element kernel + CSR assembly), row-sum lumping, centrifugal nodal loads"}
 
 
 def newton_leg(torch, steps=10):
@@ -393,10 +413,151 @@ def newton_leg(torch, steps=10):
         E = mesh.element_count
         out[tag] = {"elements": E, "ms_per_reassembly": ms, "reassemblies_per_s": 1e3 / ms,
                     "elements_per_s": E / (ms * 1e-3), "ms_per_reassembly_hip_graph": gms}
+        if E > 1_000_000:      # per-kernel roofline of the two element kernels this leg and the mass path run
+            u = field * 1e-3
+            nl_ms = avg_ms(torch, lambda: asm._nl_pass(u, True, True), 5)
+            nb = 96 + 4 + 192 + 2880 + 2880 + 192        # coordinates, id, u_e, linear blocks in; K_T blocks, f_int out
+            m_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=False, want_M=True, check=False), 5)
+            mb = 96 + 4 + 4 + 2880
+            out["kernels"] = {
+                "mitc4_nl_tiled_kernel (+ fs_gather_dofs)": {
+                    "kernel_ms": nl_ms, "bound": "hbm", "achieved": E * nb / (nl_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": E * nb / (nl_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_element": nb},
+                "mitc4_m_tiled_kernel": {
+                    "kernel_ms": m_ms, "bound": "hbm", "achieved": E * mb / (m_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": E * mb / (m_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_element": mb}}
         del asm
     out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate: gather u_e, TL tangent / internal-force kernel on " \
                   "the cached linear blocks, CSR assembly, vector scatter"
     return out
+
+
+def git_commit_of(path):
+    try:
+        return subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True,
+                              text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed):
+    """Build the assembler for an nx x ny piece of the plate (x offset rank * nx), run warmup + `steps` timed steps of
+    assemble_stiffness_matrix(recompute=True) bracketed by barrier + synchronize, return the measurements."""
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    lams = c5_laminates()
+    log(f"plate {nx}x{ny}: mesh")
+    t0 = time.perf_counter()
+    # x-bands of 25 columns cycling through the 16 laminates: every rank's strip sees all 16
+    mesh = meshes.jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=rank * nx)
+    names = mesh.set_names
+    model = {"elements": {"element_family": ElementFamily.SHELL, "properties": {names[i]: lams[i] for i in range(16)}}}
+    t1 = time.perf_counter()
+    log(f"plate {nx}x{ny}: assembler (symbolic phase, first K)")
+    if distributed:
+        from fem_shell_amd.dist import DistributedAssembler
+        asm = DistributedAssembler(mesh, model, strip=(rank, world, nx, ny),
+                                   overlap=os.environ.get("FEMSHELL_DIST_OVERLAP", "1") != "0")
+        local = asm.local
+    else:
+        asm = local = MeshAssembler(mesh, model)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    if not local.can_fuse:
+        raise SystemExit("bench: the plate must run through the fused kernel")
+    log(f"plate {nx}x{ny}: fused patch plan")
+    local.fused_plan()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    E = mesh.element_count
+    log(f"plate {nx}x{ny}: timing")
+
+    def barrier():
+        if distributed:
+            asm.finish()               # the last step's interface exchange (side stream) joins here
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    K = None
+    for _ in range(warmup):
+        K = asm.assemble_stiffness_matrix(recompute=True)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0s = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        K = asm.assemble_stiffness_matrix(recompute=True)
+    e1.record()
+    barrier()
+    dt = time.perf_counter() - t0s
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stream_ms = e0.elapsed_time(e1) / steps            # launch stream only: the fused kernel, back to back
+    # the kernel alone, HIP events on its stream, nothing else in flight (no exchange)
+    k_ms = avg_ms(torch, lambda: local.assemble_stiffness_fused(), max(3, min(steps, 10)))
+    res = {"E": E, "dt": dt, "kernel_ms": k_ms, "launch_stream_ms_per_step": stream_ms, "nnz": int(K.nnz),
+           "coupled_frac": float(np.mean((local._prop_table["flags"][local._prop_id] & 1) != 0)),
+           "setup_s": {"mesh": t1 - t0, "assembler_symbolic_and_first_K": t2 - t1, "fused_plan": t3 - t2},
+           "plan": local.fused_plan().stats(),
+           "device_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
+    if distributed:
+        # the exchange on its own (pack -> grouped send/recv -> add), every rank at the same time
+        barrier()
+        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x0.record()
+        for _ in range(5):
+            asm._exchange_on_current_stream(K)
+        x1.record()
+        torch.cuda.synchronize()
+        res["exchange_ms"] = x0.elapsed_time(x1) / 5
+        res["interface_exchange_MB"] = sum(b.numel() for b in list(asm._sbuf.values()) + list(asm._rbuf.values())) * 8 / 1e6
+        res["overlap"] = asm.overlap
+        res["setup_s"]["distributed_plan"] = asm.setup_s
+    del K, asm, local
+    torch.cuda.empty_cache()
+    return res
+
+
+def roofline_objects(r, ms_per_step):
+    """`roofline` for the dominant (only) kernel of the step and `roofline_step` for the whole step, both priced with the
+    ALGORITHMIC bytes (SURVEY.md 8d fused path) and flops (bench/FLOPS.md) per element."""
+    E = r["E"]
+    flop = FLOP_PER_ELEM + r["coupled_frac"] * (FLOP_PER_ELEM_COUPLED - FLOP_PER_ELEM)
+    prof = None
+    try:
+        pj = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        pm = json.load(open(pj)).get("fused_quad_k_kernel")
+        if pm:
+            prof = {"hbm_bytes_per_launch": pm.get("hbm_bytes_per_launch"), "elements": pm.get("elements"),
+                    "file": "profiles/pmc_summary.json", "commit": git_commit_of("profiles/pmc_summary.json"),
+                    "note": "rocprofv3 --pmc passes of an earlier run of this kernel on the 1.25 M strip, NOT observed in this run"}
+    except Exception:
+        prof = None
+
+    def obj(ms):
+        gbs = E * BYTES_PER_ELEM / (ms * 1e-3) / 1e9
+        tfl = E * flop / (ms * 1e-3) / 1e12
+        return gbs, tfl
+
+    gbs, tfl = obj(r["kernel_ms"])
+    roof = {"kernel": "fused_quad_k_kernel", "kernel_ms": r["kernel_ms"], "bound": "hbm", "achieved": gbs,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+            "traffic_from_profiles": prof, "bytes_per_element": BYTES_PER_ELEM, "elements_per_launch": E,
+            "valu_fp64": {"achieved": tfl, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_TFLOPS,
+                          "flop_per_element": flop, "source": "bench/FLOPS.md"},
+            "note": "at 2 708 B and ~20 kflop per element the HBM roofline (0.34 us per 1 000 elements) lies above the fp64 "
+                    "VALU roofline (0.26 us), so HBM is the bound quoted; the kernel itself is limited by VALU issue and "
+                    "LDS latency (DESIGN.md 4.5)"}
+    sg, stf = obj(ms_per_step)
+    step = {"ms_per_step": ms_per_step, "bytes_per_element": BYTES_PER_ELEM, "flop_per_element": flop,
+            "hbm": {"achieved": sg, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sg / PEAK_HBM_GBS},
+            "valu_fp64": {"achieved": stf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": stf / PEAK_FP64_TFLOPS}}
+    return roof, step
 
 
 def main():
@@ -405,6 +566,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[0..3] / HEXA8 legs")
+    ap.add_argument("--strip-only", action="store_true", help="N = 1: time the 1.25 M strip instead of the 10 M plate")
     args = ap.parse_args()
 
     import torch
@@ -426,122 +589,78 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import fem_shell_amd as fsa
-    from fem_shell_amd import meshes
-    from fem_shell_amd.assembler import MeshAssembler
-    from fem_shell_amd.elements import ElementFamily
-
-    lams = c5_laminates()
-    # x-bands of 25 columns cycling through the 16 laminates: every rank's strip sees all 16
-    mesh = meshes.jittered_plate(STRIP_NX, STRIP_NY, cell=1e-3, seed=11, n_sets=16,
-                                 x_offset_cells=rank * STRIP_NX)
-    names = mesh.set_names
-    model = {"elements": {"element_family": ElementFamily.SHELL,
-                          "properties": {names[i]: lams[i] for i in range(16)}}}
+    strip = None
     if world > 1:
-        from fem_shell_amd.dist import DistributedAssembler
-        asm = DistributedAssembler(mesh, model, strip=(rank, world, STRIP_NX, STRIP_NY),
-                                   overlap=os.environ.get("FEMSHELL_DIST_OVERLAP", "1") != "0")
+        r = plate_run(torch, dist, rank, world, STRIP_NX, STRIP_NY, args.steps, args.warmup, True)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "kernel_ms": r["kernel_ms"], "exchange_ms": r["exchange_ms"],
+                                          "launch_stream_ms_per_step": r["launch_stream_ms_per_step"],
+                                          "setup_s": r["setup_s"], "interface_exchange_MB": r["interface_exchange_MB"]})
+        workload = (f"C5 synthetic jittered MITC4+ laminate plate, {STRIP_NX}x{STRIP_NY}={r['E']} elements per GPU "
+                    f"({r['E'] * world} total; the 10 M plate at 8 GPUs), 16 laminates striped by x-band, "
+                    f"{r['coupled_frac']:.0%} of this rank's elements coupled; step = fused evaluate-and-assemble kernel "
+                    "+ RCCL interface-row exchange")
     else:
-        asm = MeshAssembler(mesh, model)
-    E = mesh.element_count
-    coupled_frac = float(np.mean((asm._prop_table["flags"][asm._prop_id] & 1) != 0))
-
-    def barrier():
-        if world > 1:
-            asm.finish()               # the last step's interface exchange (side stream) joins here
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        asm.assemble_stiffness_matrix(recompute=True)
-    barrier()
-    evs = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        asm.refresh_element_matrices(want_K=True, want_M=False, check=False)
-        ev[1].record()
-        K = asm.assemble_stiffness_matrix(recompute=False)
-        ev[2].record()
-        evs.append(ev)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    a_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+        free = torch.cuda.mem_get_info()[0]
+        full = not args.strip_only and free >= 120e9
+        if not args.strip_only:
+            strip = plate_run(torch, dist, 0, 1, STRIP_NX, STRIP_NY, args.steps, args.warmup, False)
+        if full:
+            r = plate_run(torch, dist, 0, 1, FULL_NX, FULL_NY, args.steps, args.warmup, False)
+        else:
+            r = strip or plate_run(torch, dist, 0, 1, STRIP_NX, STRIP_NY, args.steps, args.warmup, False)
+        nx, ny = (FULL_NX, FULL_NY) if full else (STRIP_NX, STRIP_NY)
+        workload = (f"C5 synthetic jittered MITC4+ laminate plate, {nx}x{ny}={r['E']} elements on one GPU"
+                    + (" (configs[4]'s full shell plate)" if full else f" (one x-strip: {free / 1e9:.0f} GB free or --strip-only)")
+                    + f", 16 laminates striped by x-band, {r['coupled_frac']:.0%} of the elements coupled; "
+                    "step = one launch of the fused evaluate-and-assemble kernel")
+        per_rank = None
 
     if rank == 0:
+        E = r["E"]
         total_E = E * world
-        value = total_E * args.steps / dt
-        flop = FLOP_PER_ELEM + coupled_frac * FLOP_PER_ELEM_COUPLING
-        tflops = E * flop / (k_ms * 1e-3) / 1e12
-        # algorithmic bytes per element (DESIGN.md "Kernels"): K kernel reads 12 coords + prop id and
-        # writes the 10 symmetric 6x6 blocks; the assembly kernel reads those blocks once and writes
-        # the amortised 324 CSR values (block descriptors are overhead, not counted).
-        k_bytes = 96 + 4 + 2880
-        # every source block read once (its transposed re-use as block (J,I) is served by the XCD's
-        # L2 thanks to the XCD-aware block order; PMC fetch = 3.3 kB/element incl. descriptors)
-        a_bytes = 2880 + 2592
-        k_gbs = E * k_bytes / (k_ms * 1e-3) / 1e9
-        a_gbs = E * a_bytes / (a_ms * 1e-3) / 1e9
-        pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
-        except Exception:
-            pmc = {}
-        k_obj = {"kernel": "mitc4_k_kernel", "kernel_ms": k_ms, "bound": "mfma", "achieved": tflops,
-                 "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
-                 "traffic": pmc.get("mitc4_k_kernel", {}).get("hbm_bytes_per_launch"),
-                 "flop_per_element": flop,
-                 "note": "fp64 VALU kernel priced against the fp64 peak (vector == matrix peak on "
-                         f"MI355X); HBM view of the same launch: {k_gbs:.0f} GB/s of {PEAK_HBM_GBS:.0f}"}
-        a_obj = {"kernel": "csr_numeric_desc6_lds_kernel", "kernel_ms": a_ms, "bound": "hbm",
-                 "achieved": a_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBS,
-                 "traffic": pmc.get("csr_numeric_desc6_lds_kernel", {}).get("hbm_bytes_per_launch"),
-                 "bytes_per_element": a_bytes}
-        dominant, other = (k_obj, a_obj) if k_ms >= a_ms else (a_obj, k_obj)
+        ms_per_step = r["dt"] / args.steps * 1e3
+        value = total_E * args.steps / r["dt"]
+        roof, roof_step = roofline_objects(r, ms_per_step)
         line = {
             "metric": "MITC4+ element stiffness matrices assembled into CSR per second (fp64)",
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C5 synthetic jittered MITC4+ laminate plate, {STRIP_NX}x{STRIP_NY}="
-                                   f"{E} elements per GPU ({total_E} total; 10M at 8 GPUs), 16 laminates "
-                                   f"striped by x-band, {coupled_frac:.0%} of this rank's elements coupled; "
-                                   "step = element K kernel + CSR assembly"
-                                   + (" + RCCL interface-row exchange" if world > 1 else ""),
-                       "elements_per_gpu": E, "nnz_per_gpu": int(K.nnz), "partition": f"x-strips x{world}",
-                       "interface_exchange_MB_rank0": (sum(b.numel() for b in list(asm._sbuf.values()) + list(asm._rbuf.values()))
-                                                       * 8 / 1e6) if world > 1 else 0.0,
-                       "exchange": ("RCCL grouped send/recv on a side stream, overlapped with the next element kernel"
-                                    if world > 1 and asm.overlap else ("RCCL grouped send/recv" if world > 1 else "none"))},
-            "roofline": dominant,          # the kernel with the longer average launch
-            "roofline_other_kernel": other,
+            "config": {"workload": workload, "elements_per_gpu": E, "nnz_per_gpu": r["nnz"],
+                       "partition": f"x-strips x{world}" if world > 1 else "none",
+                       "setup_s_rank0": r["setup_s"], "device_memory_GB_rank0": r["device_memory_GB"],
+                       "fused_plan": {k: r["plan"][k] for k in ("patches", "elements_per_patch", "stage1_recompute",
+                                                                 "stage2_lane_fill", "record_bytes_per_element")},
+                       "exchange": ("RCCL grouped send/recv on a side stream, overlapped with the next step's kernel"
+                                    if world > 1 and r["overlap"] else ("RCCL grouped send/recv" if world > 1 else "none"))},
+            "roofline": roof,
+            "roofline_step": roof_step,
         }
-        if not args.no_cpu_baseline and world == 1:
-            nt = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(nt)
-            mp = measured_peaks(torch)
-            line["measured_peaks"] = mp
-            k_obj["frac_of_measured_peak"] = k_obj["achieved"] / mp["fp64_fma_4_waves_per_simd_TFLOPs"]
-            k_obj["frac_of_measured_one_wave_per_simd"] = k_obj["achieved"] / mp["fp64_fma_1_wave_per_simd_TFLOPs"]
-            a_obj["frac_of_measured_peak"] = a_obj["achieved"] / mp["hbm_copy_GBs"]
-            line["hex8"] = hex8_leg(torch)
-            line["newton"] = newton_leg(torch)
-            line["c1_scordelis_lo"] = c1_leg(torch)
-            line["c2_hemisphere"] = c2_leg(torch)
-            line["c3_blade_like"] = c3_leg(torch)
-            del asm, K
-            line["c5_full_one_gpu"] = c5_full_leg(torch)
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+        if strip is not None and strip is not r:
+            sms = strip["dt"] / args.steps * 1e3
+            sroof, sstep = roofline_objects(strip, sms)
+            line["weak_scaling_point"] = {"workload": f"{STRIP_NX}x{STRIP_NY}={strip['E']} element x-strip (one rank's share at N = 8)",
+                                          "value": strip["E"] * args.steps / strip["dt"], "unit": "elements/s",
+                                          "ms_per_step": sms, "kernel_ms": strip["kernel_ms"], "nnz": strip["nnz"],
+                                          "roofline_frac_hbm": sroof["frac"], "setup_s": strip["setup_s"]}
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline")
+            line["cpu_baseline"] = cpu_baseline()
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_legs:
+            log("measured peaks")
+            mp = measured_peaks(torch)
+            line["measured_peaks"] = mp
+            roof["frac_of_measured_hbm_copy"] = roof["achieved"] / mp["hbm_copy_GBs"]
+            roof["valu_fp64"]["frac_of_measured_fma_rate"] = roof["valu_fp64"]["achieved"] / mp["fp64_fma_4_waves_per_simd_TFLOPs"]
+            for key, leg in (("hex8", hex8_leg), ("newton", newton_leg), ("c1_scordelis_lo", c1_leg),
+                             ("c2_hemisphere", c2_leg), ("c3_blade_like", c3_leg)):
+                log(f"leg {key}")
+                line[key] = leg(torch)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -12,8 +12,11 @@ The pattern of owned interface rows is completed once, at symbolic time, with th
 neighbours contribute (exchange of (I,J) global node pairs), so the numeric exchange moves values
 only.  The reference has no counterpart: its assembler is serial (core/assembler.py:37,257-262).
 
-`DistributedPlan` is pure host/NumPy + torch.distributed and runs on CPU (gloo) -- that is what the
-world_size-2 tests exercise; `DistributedAssembler` adds the device buffers and HIP kernels.
+`DistributedPlan` finds the neighbours through bounding boxes (interface candidates only travel, and only between
+ranks whose boxes touch), collects the ghost-row node pairs from the interface elements alone and builds the final
+plan with fs_csr_symbolic_* on the GPU (DeviceBlockPlan with the ghost pairs as extra keys) -- or, without a device,
+with the host BlockPlan: that is what the gloo tests (world 2, 3, 4 and 8) exercise on CPU.  `DistributedAssembler`
+adds the device buffers and HIP kernels.  The RCCL transport itself is UNMEASURED ON HARDWARE (one-GPU boxes only).
 """
 from typing import Dict
 
@@ -95,37 +98,66 @@ class DistributedPlan:
       recv_idx[q]  indices into the local CSR values where the values received from q are added
     """
 
-    def __init__(self, conn, l2g, d):
+    def __init__(self, conn, l2g, d, coords=None, device=None):
+        """coords [Nloc,3] (optional): with coordinates the ranks find each other through bounding boxes -- one
+        all_gather of 6 numbers per rank, then node-id lists only between ranks whose boxes touch and only for the
+        nodes inside the other's box (interface candidates).  Without, every rank's node list goes to every rank.
+        device: build the final plan on the GPU (DeviceBlockPlan); None = host NumPy BlockPlan (CPU rehearsal)."""
+        import time
+        t_start = time.perf_counter()
         rank, world = dist.get_rank(), dist.get_world_size()
         self.rank, self.world, self.d = rank, world, int(d)
         conn = np.asarray(conn, dtype=np.int64)
         l2g = np.asarray(l2g, dtype=np.int64)
         pad = conn < 0                                     # mixed node counts: rows padded with trailing -1
         gconn = np.where(pad, -1, l2g[np.where(pad, 0, conn)])
-        mine = np.unique(gconn[~pad])
+        used = np.unique(conn[~pad])                       # local nodes some element references
+        srt = np.argsort(l2g[used], kind="stable")
+        mine = l2g[used][srt]                              # their global ids, ascending
+        if mine.shape[0] > 1 and (mine[1:] == mine[:-1]).any():
+            raise ValueError("l2g maps two local nodes to one global id")
         # --- who else holds my nodes?  owner = lowest rank holding the node
-        all_nodes = _allgather_arrays(mine)
+        if coords is not None:
+            xyz = np.asarray(coords, dtype=np.float64)[used][srt]
+            box = torch.tensor(np.concatenate([xyz.min(axis=0), xyz.max(axis=0)]), dtype=torch.float64,
+                               device=_comm_device())
+            boxes = [torch.zeros(6, dtype=torch.float64, device=box.device) for _ in range(world)]
+            dist.all_gather(boxes, box)
+            boxes = [b.cpu().numpy() for b in boxes]
+            lo, hi = boxes[rank][:3], boxes[rank][3:]
+            cand = {}
+            for q in range(world):                         # boxes touch: a symmetric relation, both sides see it
+                if q != rank and (boxes[q][:3] <= hi).all() and (boxes[q][3:] >= lo).all():
+                    cand[q] = mine[((xyz >= boxes[q][:3]) & (xyz <= boxes[q][3:])).all(axis=1)]
+            theirs = _exchange(cand, list(cand))
+            theirs = {q: theirs.get(q, np.zeros(0, dtype=np.int64)) for q in cand}
+            self.candidate_ids_sent = int(sum(v.shape[0] for v in cand.values()))
+        else:
+            allg = _allgather_arrays(mine)
+            theirs = {q: allg[q] for q in range(world) if q != rank}
+            self.candidate_ids_sent = int(mine.shape[0]) * (world - 1)
         owner = np.full(mine.shape[0], rank, dtype=np.int64)
-        sharers = {}
-        for q in range(world):
-            if q == rank:
-                continue
-            shared = np.isin(mine, all_nodes[q], assume_unique=True)
+        self.neighbors = []
+        for q in sorted(theirs):
+            shared = np.isin(mine, theirs[q], assume_unique=True)
             if shared.any():
-                sharers[q] = shared
+                self.neighbors.append(q)
                 owner = np.where(shared & (q < owner), q, owner)
-        self.neighbors = sorted(sharers)
-        # --- local node graph in global ids (provisional plan on the compact local numbering)
+        # --- (I,J) node pairs of the block rows I do not own, from the elements that touch such a node
         loc = np.where(pad, -1, np.searchsorted(mine, np.where(pad, mine[0], gconn)))
-        p0 = BlockPlan(loc, mine.shape[0], d)
-        gI, gJ = mine[p0.blk_row], mine[p0.nbr]
-        ghost_row = owner[p0.blk_row] != rank
-        # --- ship the (I,J) pairs of rows I do not own to their owners
+        ghost = owner != rank
+        gl = np.where(pad, False, ghost[np.where(pad, 0, loc)])
+        esel = np.flatnonzero(gl.any(axis=1))
+        le, ge, pe = loc[esel], gl[esel], pad[esel]
+        n_mine = np.int64(mine.shape[0])
+        keys = (le[:, :, None] * n_mine + le[:, None, :])[ge[:, :, None] & ~pe[:, None, :]]
+        keys = np.unique(keys)
+        pI, pJ = keys // n_mine, keys % n_mine             # sorted by (I,J); `mine` ascends, so by global (I,J) too
         send_pairs = {}
         for q in self.neighbors:
-            sel = ghost_row & (owner[p0.blk_row] == q)
+            sel = owner[pI] == q
             if sel.any():
-                send_pairs[q] = np.stack([gI[sel], gJ[sel]], 1).reshape(-1)   # sorted by (I,J)
+                send_pairs[q] = np.stack([mine[pI[sel]], mine[pJ[sel]]], 1).reshape(-1)
         recv_pairs = _exchange(send_pairs, self.neighbors)
         recv_pairs = {q: v.reshape(-1, 2) for q, v in recv_pairs.items()}
         # --- extended node set and final plan
@@ -134,15 +166,19 @@ class DistributedPlan:
         X = self.nodes_g
         self.conn_x = np.where(pad, -1, np.searchsorted(X, np.where(pad, X[0], gconn)))
         extra = [np.searchsorted(X, v) for v in recv_pairs.values()]
-        self.plan = BlockPlan(self.conn_x, X.shape[0], d, np.concatenate(extra) if extra else None,
-                              tiled=can_tile(self.conn_x, d))
+        extra = np.concatenate(extra) if extra else None
+        if device is not None:
+            from .symbolic import DeviceBlockPlan
+            self.plan = DeviceBlockPlan(self.conn_x, X.shape[0], d, device, extra, tiled=can_tile(self.conn_x, d))
+            P = self.plan.host()
+        else:
+            self.plan = P = BlockPlan(self.conn_x, X.shape[0], d, extra, tiled=can_tile(self.conn_x, d))
         own_x = np.zeros(X.shape[0], dtype=bool)
         own_x[np.searchsorted(X, mine[owner == rank])] = True
         self.owned = own_x
         self.local_of_ext = np.searchsorted(X, mine)        # compact local -> extended index
         # --- value-exchange index lists.  Message layout (both sides): rows sorted by global I,
         #     inside a row k-major, then the sender's neighbours sorted by global J, then l.
-        P = self.plan
         m = np.diff(P.nbr_ptr)
         self.send_idx, self.recv_idx = {}, {}
         kk, ll = np.meshgrid(np.arange(d), np.arange(d), indexing="ij")
@@ -157,6 +193,7 @@ class DistributedPlan:
                           for q, pr in send_pairs.items()}
         self.vrecv_idx = {q: (np.searchsorted(X, np.unique(pr[:, 0]))[:, None] * d + ar).reshape(-1)
                           for q, pr in recv_pairs.items()}
+        self.setup_s = time.perf_counter() - t_start
 
     @staticmethod
     def _value_index(pairs, _unused, X, P, m, kk, ll):
@@ -226,7 +263,9 @@ class DistributedAssembler:
             l2g = (gy[:, None] * (world * nx + 1) + gx[None, :]).reshape(-1)
         from .elements import ElementFamily
         d = 3 if model["elements"]["element_family"] == ElementFamily.SOLID else 6
-        self.dplan = DistributedPlan(mesh.conn, l2g, d)
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.dplan = DistributedPlan(mesh.conn, l2g, d, coords=mesh.coords, device=dev)
+        self.setup_s = self.dplan.setup_s
         # the local assembler works on the extended node set (ghost columns appended in id order)
         from .meshes import ArrayMesh
         X = self.dplan.nodes_g
@@ -309,12 +348,12 @@ class DistributedAssembler:
 
     def assemble_stiffness_matrix(self, recompute=False):
         """Owned rows of the returned CSR (see `owned_rows`) hold the globally assembled values;
-        column j of the local matrix is global DOF d*nodes_g[j//d] + j%d (d = 6 shells, 3 solids)."""
-        self.finish()
+        column j of the local matrix is global DOF d*nodes_g[j//d] + j%d (d = 6 shells, 3 solids).
+        With overlap=True the caller's stream does NOT wait for the previous matrix's exchange: every call writes a
+        fresh value array, and the exchanges queue up in order on the side stream (finish() joins the last one)."""
         return self._exchange(self.local.assemble_stiffness_matrix(recompute=recompute))
 
     def assemble_mass_matrix(self, recompute=False):
-        self.finish()
         return self._exchange(self.local.assemble_mass_matrix(recompute=recompute))
 
     # --- Newton re-assembly (SURVEY.md 8a "New", 8e: vectors use the same plan with d values per interface node) ---

@@ -1,4 +1,4 @@
-"""CPU rehearsal (gloo, world_size 2 and 3) of the multi-GPU path: partition, ghost-column pattern
+"""CPU rehearsal (gloo, world_size 2, 3, 4 and 8) of the multi-GPU path: partition, ghost-column pattern
 exchange and interface-row value exchange must reproduce the serial assembly on owned rows.
 Element matrices come from the oracle and the kernels are emulated in NumPy (test infrastructure);
 the exchanged index plans are exactly the ones DistributedAssembler uses on the GPU."""
@@ -47,7 +47,10 @@ def _worker(rank, world, port, nx, ny, q):
         assert np.array_equal(loc.coords, g.coords[l2g])
         ecol = (np.arange(nx) + rank * nx)
         eg = (np.arange(ny)[:, None] * (world * nx) + ecol[None, :]).reshape(-1)     # global element ids
-        dp = DistributedPlan(loc.conn, l2g, 6)
+        dp = DistributedPlan(loc.conn, l2g, 6, coords=loc.coords)
+        # bounding boxes: a strip only ever talks to the strips next to it, and only about its two edge columns
+        assert dp.neighbors == [r for r in (rank - 1, rank + 1) if 0 <= r < world]
+        assert dp.candidate_ids_sent <= 2 * len(dp.neighbors) * (ny + 1)
         Kl, _ = O.mitc4_K_batch(loc.coords[loc.conn], gpid[eg], props)
         assert dp.plan.tiled      # quad strips use the tiled element-matrix layout
         data = util.host_block_assemble(dp.plan, util.pack_symblk(Kl, tiled=dp.plan.tiled))
@@ -88,12 +91,13 @@ def _worker(rank, world, port, nx, ny, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_distributed_plan_matches_serial(world):
+    """world 8 = the C5 strip topology of bench.py --gpus 8: 8 x-strips, 7 interfaces."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 5, 4, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 5 if world < 8 else 3, 4, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -104,7 +108,7 @@ def test_distributed_plan_matches_serial(world):
         assert n > 0
 
 
-def _worker_quadrants(rank, world, port, nx, ny, q):
+def _worker_quadrants(rank, world, port, nx, ny, q, use_coords):
     """2 x 2 element quadrants: the centre node belongs to all four ranks, edge-interface nodes to two."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -129,7 +133,7 @@ def _worker_quadrants(rank, world, port, nx, ny, q):
         eg = np.flatnonzero(quadrant == rank)                               # global element ids, ascending
         l2g = np.unique(g.conn[eg])
         conn = np.searchsorted(l2g, g.conn[eg])
-        dp = DistributedPlan(conn, l2g, 6)
+        dp = DistributedPlan(conn, l2g, 6, coords=g.coords[l2g] if use_coords else None)
         assert len(dp.neighbors) == 3                                       # every quadrant touches the other three
         Kl, _ = O.mitc4_K_batch(g.coords[g.conn[eg]], gpid[eg], props)
         data = util.host_block_assemble(dp.plan, util.pack_symblk(Kl, tiled=dp.plan.tiled))
@@ -156,11 +160,13 @@ def _worker_quadrants(rank, world, port, nx, ny, q):
         dist.destroy_process_group()
 
 
-def test_distributed_plan_two_by_two_quadrants():
+@pytest.mark.parametrize("use_coords", [True, False])
+def test_distributed_plan_two_by_two_quadrants(use_coords):
+    """use_coords=False: the fallback without coordinates (every rank's node list to every rank)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_quadrants, args=(r, 4, port, 6, 6, q)) for r in range(4)]
+    procs = [ctx.Process(target=_worker_quadrants, args=(r, 4, port, 6, 6, q, use_coords)) for r in range(4)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
