@@ -61,14 +61,37 @@ def _numbering_axis(coords, used):
     return int(np.argmax(np.median(d, axis=0)))
 
 
+def _lattice(conn, N):
+    """(i, j) lattice indices of the nodes if the mesh is numbered like a structured grid (node index = j * L + i: the
+    element edges join indices that differ by 1 and by one row length L, whatever the geometry), else None.  Wrap-around
+    elements of closed tubes and a few irregular elements are tolerated (the bisection pass repairs their patches)."""
+    E = conn.shape[0]
+    if E < 4:
+        return None
+    d01, d32 = np.abs(conn[:, 1] - conn[:, 0]), np.abs(conn[:, 2] - conn[:, 3])
+    d03, d12 = np.abs(conn[:, 3] - conn[:, 0]), np.abs(conn[:, 2] - conn[:, 1])
+    lo, hi = np.minimum(d01, d03), np.maximum(d01, d03)
+    vals, cnts = np.unique(hi, return_counts=True)
+    L = int(vals[np.argmax(cnts)])
+    if L < 2:
+        return None
+    ok = (lo == 1) & (hi == L) & (d32 == d01) & (d12 == d03)
+    if ok.mean() < 0.9:
+        return None
+    idx = np.arange(N, dtype=np.int64)
+    return np.stack([idx % L, idx // L], axis=1).astype(np.float64)
+
+
 def partition_nodes(coords, conn, max_elems=64):
     """node -> patch id (int64 [N]); the elements touching any patch number <= max_elems.
 
-    Grid binning: cells of a x b nodes, a (<= GROUP_NODES) along the direction in which consecutive node indices run
+    Grid binning: cells of a x b nodes, a (<= GRID_NODES) along the direction in which consecutive node indices run
     and a b as large as (a + 1)(b + 1) <= max_elems allows (6 x 8 nodes / 63 elements for 64; patch ids follow the
     grid, so consecutive patches are spatial neighbours), then recursive median bisection, along the longest
-    extent, of the patches that still touch too many elements.  Any mesh works; compact patches recompute fewer
-    halo elements and rows of consecutively numbered nodes give the kernel's stores long contiguous runs."""
+    extent, of the patches that still touch too many elements.  The grid lives on the (i, j) lattice of the node
+    numbering when the mesh is numbered like a structured grid (curved shells: the patches follow the mesh lines),
+    otherwise on the coordinates with the mean element edge as spacing.  Any mesh works; compact patches recompute
+    fewer halo elements and rows of consecutively numbered nodes give the kernel's stores long contiguous runs."""
     coords = np.asarray(coords, dtype=np.float64)
     conn = np.asarray(conn, dtype=np.int64)
     N, E = coords.shape[0], conn.shape[0]
@@ -76,18 +99,22 @@ def partition_nodes(coords, conn, max_elems=64):
         return np.zeros(N, dtype=np.int64)
     used = np.zeros(N, dtype=bool)
     used[conn.reshape(-1)] = True
-    x = coords[conn]
-    e1, e2 = np.abs(x[:, 1] - x[:, 0]), np.abs(x[:, 3] - x[:, 0])
-    hk = np.maximum(np.maximum(e1, e2).mean(axis=0), 1e-300)          # node spacing seen along each global axis
-    hmax = float(hk.max())
-    hk = np.maximum(hk, 1e-3 * hmax)
+    lat = _lattice(conn, N)
+    if lat is not None:
+        coords, hk, ax = lat, np.ones(2), 0
+    else:
+        x = coords[conn]
+        e1, e2 = np.abs(x[:, 1] - x[:, 0]), np.abs(x[:, 3] - x[:, 0])
+        hk = np.maximum(np.maximum(e1, e2).mean(axis=0), 1e-300)          # node spacing seen along each global axis
+        hk = np.maximum(hk, 1e-3 * float(hk.max()))
+        ax = _numbering_axis(coords, used)
+    nd = coords.shape[1]
     best = (1, 1)
     for a in range(1, GRID_NODES + 1):
         for bb in range(1, 40):
             if (a + 1) * (bb + 1) <= max_elems and a * bb > best[0] * best[1]:
                 best = (a, bb)
-    ax = _numbering_axis(coords, used)
-    nodes_per_cell = np.full(3, float(best[1]))
+    nodes_per_cell = np.full(nd, float(best[1]))
     nodes_per_cell[ax] = float(best[0])
     side = nodes_per_cell * hk
     lo = coords[used].min(axis=0) - 0.5 * hk
@@ -95,8 +122,10 @@ def partition_nodes(coords, conn, max_elems=64):
     b = np.clip(np.floor((cc - lo) / side).astype(np.int64), 0, None)
     nb = b[used].max(axis=0) + 1
     b = np.minimum(b, nb - 1)
-    order_axes = [ax] + [k for k in range(3) if k != ax]              # numbering axis fastest
-    key = (b[:, order_axes[2]] * nb[order_axes[1]] + b[:, order_axes[1]]) * nb[ax] + b[:, ax]
+    order_axes = [ax] + [k for k in range(nd) if k != ax]             # numbering axis fastest
+    key = np.zeros(N, dtype=np.int64)
+    for k in reversed(order_axes):
+        key = key * nb[k] + b[:, k]
     _, patch = np.unique(key, return_inverse=True)
     patch = patch.astype(np.int64)
     earange = np.repeat(np.arange(E, dtype=np.int64), conn.shape[1])
