@@ -32,15 +32,15 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp]),
     "fs_solid2_table": (ctypes.c_int, [_i32, _vp, _vp, _vp, ctypes.POINTER(_i32)]),
     "fs_shell_kg_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _u32, _vp, _vp]),
+    "fs_shell_kt_sigma_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "fs_shell_rotate_local": (ctypes.c_int, [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_centrifugal_prestress": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, ctypes.c_double, _vp, _vp,
                                                 _i64, _vp, _vp]),
     "fs_shell_quad_geom": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_blk_expand": (ctypes.c_int, [_vp, _u32, _i64, _i32, _i32, _vp, _vp]),
     "fs_csr_numeric": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fs_vec_gather_sum": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "fs_csr_numeric_blk": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_numeric_desc": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
-    "fs_csr_numeric_sym": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "fs_csr_pattern_blk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "fs_csr_symbolic_begin": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _u32, _i64, _i64, _vp, _i64,
                                              ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),

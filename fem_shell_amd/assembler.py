@@ -88,8 +88,6 @@ class _LazyElementMap:
 
 
 class MeshAssembler:
-    use_descriptors = True   # fs_csr_numeric_desc (False: fs_csr_numeric_blk, same result)
-    use_symmetric = False    # fs_csr_numeric_sym: each source block read once (same result)
     reuse_linear_blocks = True   # K_T / f_int re-assembly reads the cached linear blocks (tiled quad meshes)
     use_fused = True             # uniform MITC4+ meshes: assemble_stiffness_matrix(recompute=True) is ONE fused
                                  # evaluate-and-assemble launch (fs_fused_assemble_quad), bitwise the two-kernel result
@@ -269,7 +267,6 @@ class MeshAssembler:
         self._conn_d, self._xyz_d, self._pid_d = g0["conn_d"], g0["xyz_d"], g0["pid_d"]
         self._plan_d = p.to_device(dev)
         self._desc_d = self._plan_d["desc"]
-        self._sdesc_d = None     # symmetric descriptors: built on first use (use_symmetric)
         # K of every element now (this is also the geometry check of the reference's constructor loop); M on first use
         # (assemble_mass_matrix / _me_array): the reference evaluates both up front, here that would only cost memory
         self.refresh_element_matrices(want_K=True, want_M=False)
@@ -390,22 +387,9 @@ class MeshAssembler:
     def _assemble(self, blk):
         lib, p, d = _lib.load(), self._plan, self._plan_d
         data = torch.empty(p.nnz, dtype=torch.float64, device=self.device)
-        if self.use_symmetric and self.use_descriptors:
-            if self._sdesc_d is None:
-                sd = p.sym_descriptors()
-                self._n_sym = sd.shape[0]
-                self._sdesc_d = torch.from_numpy(sd.view(np.uint8).reshape(-1)).to(self.device)
-            _lib.check(lib.fs_csr_numeric_sym(_lib.ptr(blk), _lib.ptr(self._sdesc_d), _lib.ptr(d["contrib"]),
-                                              self._n_sym, p.d, _lib.ptr(data), _lib.stream_ptr()),
-                       "fs_csr_numeric_sym")
-        elif self.use_descriptors:
-            _lib.check(lib.fs_csr_numeric_desc(_lib.ptr(blk), _lib.ptr(self._desc_d), _lib.ptr(d["contrib"]),
-                                               p.nblk, p.d, _lib.ptr(data), _lib.stream_ptr()),
-                       "fs_csr_numeric_desc")
-        else:
-            _lib.check(lib.fs_csr_numeric_blk(_lib.ptr(blk), _lib.ptr(d["nbr_ptr"]), _lib.ptr(d["blk_row"]),
-                                              _lib.ptr(d["blk_ptr"]), _lib.ptr(d["contrib"]), p.nblk, p.d,
-                                              _lib.ptr(data), _lib.stream_ptr()), "fs_csr_numeric_blk")
+        _lib.check(lib.fs_csr_numeric_desc(_lib.ptr(blk), _lib.ptr(self._desc_d), _lib.ptr(d["contrib"]),
+                                           p.nblk, p.d, _lib.ptr(data), _lib.stream_ptr()),
+                   "fs_csr_numeric_desc")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
 
     # ------------------------------------------------------------------ fused evaluate-and-assemble

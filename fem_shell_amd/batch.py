@@ -175,6 +175,48 @@ def shell_kg_batch(nn, xyz, prop_id, props_dev, n_props, sigma, dense=False, KG_
     return expand_blocks(KG, nn, 6, layout, E) if dense else KG
 
 
+def shell_kt_sigma_batch(nn, xyz, prop_id, props_dev, n_props, u_e, sigma):
+    """K_T with a given local membrane stress sigma [E,3] (fs_shell_kt_sigma_batch) -> dense [E,6nn,6nn], status."""
+    lib = _lib.load()
+    dev = _dev()
+    xyz, u_e, sigma = xyz.contiguous(), u_e.contiguous(), sigma.contiguous()
+    E = xyz.shape[0]
+    if nn not in (3, 4):
+        raise ValueError(f"unsupported shell element with {nn} nodes")
+    assert xyz.dtype == torch.float64 and xyz.shape[1:] == (nn, 3) and xyz.is_cuda
+    assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E
+    assert u_e.dtype == torch.float64 and u_e.shape == (E, 6 * nn) and u_e.is_cuda
+    assert sigma.dtype == torch.float64 and sigma.shape == (E, 3) and sigma.is_cuda
+    KT = _out_buf(None, E, nn * (nn + 1) // 2, dev)
+    status = torch.zeros(E, dtype=torch.int32, device=dev)
+    _lib.check(lib.fs_shell_kt_sigma_batch(nn, _lib.ptr(xyz), _lib.ptr(prop_id), _lib.ptr(props_dev), n_props,
+                                           _lib.ptr(u_e), _lib.ptr(sigma), E, _lib.ptr(KT), _lib.ptr(status),
+                                           _lib.stream_ptr()), "fs_shell_kt_sigma_batch")
+    return expand_blocks(KT, nn, 6, _lib.FS_LAYOUT_SYMBLK, E), status
+
+
+def shell_rotate_local(nn, xyz, K=None, f=None):
+    """Local-axes view (T K T^T, T f) of dense global-axes element results (fs_shell_rotate_local); the frame is the
+    kernels' geometry stage on xyz [E,nn,3]."""
+    lib = _lib.load()
+    dev = _dev()
+    xyz = xyz.contiguous()
+    E = xyz.shape[0]
+    assert xyz.dtype == torch.float64 and xyz.shape[1:] == (nn, 3) and xyz.is_cuda
+    Kl = fl = None
+    if K is not None:
+        K = K.contiguous()
+        assert K.dtype == torch.float64 and K.shape == (E, 6 * nn, 6 * nn) and K.is_cuda
+        Kl = torch.empty_like(K)
+    if f is not None:
+        f = f.contiguous()
+        assert f.dtype == torch.float64 and f.shape == (E, 6 * nn) and f.is_cuda
+        fl = torch.empty_like(f)
+    _lib.check(lib.fs_shell_rotate_local(nn, _lib.ptr(xyz), E, _lib.ptr(K), _lib.ptr(f), _lib.ptr(Kl), _lib.ptr(fl),
+                                         _lib.stream_ptr()), "fs_shell_rotate_local")
+    return Kl, fl
+
+
 def centrifugal_prestress(solid, nn, xyz, prop_id, props_dev, n_props, omega, rotation_axis, rotation_center):
     """compute_centrifugal_prestress of every element (fs_centrifugal_prestress): [E,3] local
     membrane stresses for MITC3, [E,6] global Voigt stresses for the linear solids."""

@@ -58,6 +58,12 @@ __device__ __forceinline__ double divr(double a, double b, double r) {
     return FMA(d, r, q);
 }
 
+// property row of an element: ids outside [0, n_props) never index the table (row 0 is used; the batch entry points
+// report them as FS_ST_BAD_PROP through their status array)
+__device__ __forceinline__ int32_t safe_pid(int32_t p, int32_t n_props) {
+    return (uint32_t)p < (uint32_t)n_props ? p : 0;
+}
+
 constexpr double kGP = 0.57735026918962584;  // 1.0/np.sqrt(3.0)  (MITC4.py:87)
 
 struct QuadGeom {

@@ -501,7 +501,7 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
 template <bool TILED>
 __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ xyz,
                                                      const int32_t *__restrict__ prop_id,
-                                                     const fs_shell_prop *__restrict__ props,
+                                                     const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                      int64_t E, double *__restrict__ out,
                                                      int32_t *__restrict__ status) {
     __shared__ double lds[TILED ? LDS_WAVE_T16 : LDS_WAVE];
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
             (&x[0][0])[2 * t + 1] = v.y;
         }
     }
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
     const bool any_coupled = __any(coupled);
 
@@ -901,16 +901,19 @@ __device__ __forceinline__ void membrane_W(const QuadGeom &geo, double xi, doubl
 
 __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
-                                                      const fs_shell_prop *__restrict__ props,
+                                                      const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                       const double *__restrict__ ue, int64_t E,
                                                       double *__restrict__ kt, int want_kt,
-                                                      double *__restrict__ fe, int tiled) {
+                                                      double *__restrict__ fe, int tiled,
+                                                      const double *__restrict__ sig_in) {
+    // sig_in: optional [E][3] local membrane stress replacing the one computed from u (the `sigma` argument of
+    // compute_tangent_stiffness, MITC4.py:1246-1262)
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     double x[4][3], u[4][6];
     for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
     for (int c = 0; c < 24; c++) (&u[0][0])[c] = ue[e * 24 + c];
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     QuadGeom geo;
     quad_geometry(x, geo);
     const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
@@ -966,6 +969,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__
             } else {
                 for (int a = 0; a < 3; a++) sig[a] = C[a][0] * eps[0] + C[a][1] * eps[1] + C[a][2] * eps[2];
             }
+            if (sig_in) { sig[0] = sig_in[e * 3]; sig[1] = sig_in[e * 3 + 1]; sig[2] = sig_in[e * 3 + 2]; }
             Sm00 = sig[0] * h; Sm11 = sig[1] * h; Sm01 = sig[2] * h;
         }
         // tying vectors (as in mitc4_k_kernel) for K_m u_loc
@@ -1132,7 +1136,7 @@ constexpr int NLT_LDS = NLT_F + 24 * 16;
 
 __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__restrict__ xyz,
                                                             const int32_t *__restrict__ prop_id,
-                                                            const fs_shell_prop *__restrict__ props,
+                                                            const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                             const double *__restrict__ ue, int64_t E,
                                                             const double *k0, double *kt, int want_kt,
                                                             double *__restrict__ fe) {
@@ -1150,7 +1154,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
         const double2 *q = reinterpret_cast<const double2 *>(ue + e * 24);
         for (int t = 0; t < 12; t++) { const double2 v = q[t]; (&u[0][0])[2 * t] = v.x; (&u[0][0])[2 * t + 1] = v.y; }
     }
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     QuadGeom geo;
     quad_geometry(x, geo);
     const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
@@ -1392,7 +1396,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
-                                                      const fs_shell_prop *__restrict__ props,
+                                                      const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                       int64_t E, double *__restrict__ out, int tiled) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E * 10) return;
@@ -1404,7 +1408,7 @@ __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__
     for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
     QuadGeom geo;
     quad_geometry(x, geo);
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     const double mt = pr->m_t, mr = pr->m_r;
     const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
     const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
@@ -1445,7 +1449,7 @@ __global__ __launch_bounds__(256) void mitc4_m_kernel(const double *__restrict__
 // block as mitc4_m_kernel (bitwise identical values).
 __global__ __launch_bounds__(64) void mitc4_m_tiled_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
-                                                           const fs_shell_prop *__restrict__ props,
+                                                           const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                            int64_t E, double *__restrict__ out) {
     __shared__ double lds[32 * STG_SLOT];
     const int lane = threadIdx.x;
@@ -1463,7 +1467,7 @@ __global__ __launch_bounds__(64) void mitc4_m_tiled_kernel(const double *__restr
     }
     QuadGeom geo;
     quad_geometry(x, geo);
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     const double mt = pr->m_t, mr = pr->m_r;
     double det[4];
     for (int q = 0; q < 4; q++) {
@@ -1639,138 +1643,10 @@ __device__ __forceinline__ void rotate_block6(const double (&L)[6][6], const dou
         }
 }
 
-__global__ __launch_bounds__(256) void mitc3_k_kernel(const double *__restrict__ xyz,
-                                                      const int32_t *__restrict__ prop_id,
-                                                      const fs_shell_prop *__restrict__ props,
-                                                      int64_t E, double *__restrict__ out,
-                                                      int32_t *__restrict__ status) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E * 6) return;
-    const int64_t e = t / 6;
-    const int p = (int)(t - e * 6);
-    const int ti = (p < 3) ? 0 : ((p < 5) ? 1 : 2);
-    const int tj = (p < 3) ? p : ((p < 5) ? p - 2 : 2);
-    double x[3][3];
-    for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
-    TriGeom geo;
-    tri_geometry(x, geo);
-    if (p == 0 && status) status[e] = geo.status;
-    const fs_shell_prop *pr = props + prop_id[e];
-    double L[6][6], G[6][6];
-    {
-#pragma clang fp contract(fast)
-        TriFn Fi, Fj, Fb;
-        tri_fn(geo, ti, Fi);
-        tri_fn(geo, tj, Fj);
-        tri_fn(geo, 3, Fb);
-        double D[9], A[9], Cs[4];
-        for (int c = 0; c < 9; c++) { D[c] = pr->D[c]; A[c] = pr->A[c]; }
-        for (int c = 0; c < 4; c++) Cs[c] = pr->Cs[c];
-        const double kd = pr->k_drill;
-        const bool coupled = (pr->flags & FS_PROP_COUPLED) != 0;
-        for (int a = 0; a < 6; a++)
-            for (int b = 0; b < 6; b++) L[a][b] = 0.0;
-        double Kij[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        double Ni[3][2] = {{0, 0}, {0, 0}, {0, 0}}, Nj[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-        double Kbb[2][2] = {{0, 0}, {0, 0}};
-        double dr[2][2] = {{0, 0}, {0, 0}}, drz[2] = {0, 0}, dzr[2] = {0, 0}, dzz = 0.0;
-        double cpl_ij[2][2] = {{0, 0}, {0, 0}}, cpl_ji[2][2] = {{0, 0}, {0, 0}};
-        const double bdi[2] = {-0.5 * Fi.dhy, 0.5 * Fi.dhx}, bdj[2] = {-0.5 * Fj.dhy, 0.5 * Fj.dhx};
-#pragma unroll
-        for (int g = 0; g < 3; g++) {
-            const double wA = (1.0 / 3.0) * geo.area;
-            TriCS cj, cb;
-            tri_cs(D, Cs, Fj, g, true, cj);
-            tri_cs(D, Cs, Fb, g, false, cb);
-            const double cjw[5] = {0.0, 0.0, 0.0, cj.w[0], cj.w[1]};
-            // bending + shear, nodal block (rows of i, columns of j)
-            Kij[0][0] += wA * tri_dot_w(Fi, cjw);      Kij[0][1] += wA * tri_dot_w(Fi, cj.x);      Kij[0][2] += wA * tri_dot_w(Fi, cj.y);
-            Kij[1][0] += wA * (Fi.gx[g][0] * cj.w[0] + Fi.gx[g][1] * cj.w[1]);
-            Kij[1][1] += wA * tri_dot_x(Fi, g, cj.x);  Kij[1][2] += wA * tri_dot_x(Fi, g, cj.y);
-            Kij[2][0] += wA * (Fi.gy[g][0] * cj.w[0] + Fi.gy[g][1] * cj.w[1]);
-            Kij[2][1] += wA * tri_dot_y(Fi, g, cj.x);  Kij[2][2] += wA * tri_dot_y(Fi, g, cj.y);
-            // bubble columns
-            Ni[0][0] += wA * tri_dot_w(Fi, cb.x);     Ni[0][1] += wA * tri_dot_w(Fi, cb.y);
-            Ni[1][0] += wA * tri_dot_x(Fi, g, cb.x);  Ni[1][1] += wA * tri_dot_x(Fi, g, cb.y);
-            Ni[2][0] += wA * tri_dot_y(Fi, g, cb.x);  Ni[2][1] += wA * tri_dot_y(Fi, g, cb.y);
-            Nj[0][0] += wA * tri_dot_w(Fj, cb.x);     Nj[0][1] += wA * tri_dot_w(Fj, cb.y);
-            Nj[1][0] += wA * tri_dot_x(Fj, g, cb.x);  Nj[1][1] += wA * tri_dot_x(Fj, g, cb.y);
-            Nj[2][0] += wA * tri_dot_y(Fj, g, cb.x);  Nj[2][1] += wA * tri_dot_y(Fj, g, cb.y);
-            Kbb[0][0] += wA * tri_dot_x(Fb, g, cb.x); Kbb[0][1] += wA * tri_dot_x(Fb, g, cb.y);
-            Kbb[1][0] += wA * tri_dot_y(Fb, g, cb.x); Kbb[1][1] += wA * tri_dot_y(Fb, g, cb.y);
-            // drilling (MITC3.py:1024-1035, row 5 of _compute_B_drill :1905-1939)
-            const double wk = wA * kd;
-            dr[0][0] += wk * bdi[0] * bdj[0]; dr[0][1] += wk * bdi[0] * bdj[1];
-            dr[1][0] += wk * bdi[1] * bdj[0]; dr[1][1] += wk * bdi[1] * bdj[1];
-            drz[0] += wk * bdi[0] * (-Fj.h[g]); drz[1] += wk * bdi[1] * (-Fj.h[g]);
-            dzr[0] += wk * (-Fi.h[g]) * bdj[0]; dzr[1] += wk * (-Fi.h[g]) * bdj[1];
-            dzz += wk * Fi.h[g] * Fj.h[g];
-            if (coupled) {  // MITC3_composite.py:204-240 (nodal-only form: the bubble block of K_qq is zero)
-                const double *B = pr->B;
-                {
-                    const double fx = Fj.fx[g], fy = Fj.fy[g];
-                    const double bx[3] = {-(B[1] * fy + B[2] * fx), -(B[4] * fy + B[5] * fx), -(B[7] * fy + B[8] * fx)};
-                    const double by[3] = {B[0] * fx + B[2] * fy, B[3] * fx + B[5] * fy, B[6] * fx + B[8] * fy};
-                    cpl_ij[0][0] += wA * (Fi.dhx * bx[0] + Fi.dhy * bx[2]); cpl_ij[0][1] += wA * (Fi.dhx * by[0] + Fi.dhy * by[2]);
-                    cpl_ij[1][0] += wA * (Fi.dhy * bx[1] + Fi.dhx * bx[2]); cpl_ij[1][1] += wA * (Fi.dhy * by[1] + Fi.dhx * by[2]);
-                }
-                {
-                    const double fx = Fi.fx[g], fy = Fi.fy[g];
-                    const double bx[3] = {-(B[1] * fy + B[2] * fx), -(B[4] * fy + B[5] * fx), -(B[7] * fy + B[8] * fx)};
-                    const double by[3] = {B[0] * fx + B[2] * fy, B[3] * fx + B[5] * fy, B[6] * fx + B[8] * fy};
-                    cpl_ji[0][0] += wA * (Fj.dhx * bx[0] + Fj.dhy * bx[2]); cpl_ji[0][1] += wA * (Fj.dhx * by[0] + Fj.dhy * by[2]);
-                    cpl_ji[1][0] += wA * (Fj.dhy * bx[1] + Fj.dhx * bx[2]); cpl_ji[1][1] += wA * (Fj.dhy * by[1] + Fj.dhx * by[2]);
-                }
-            }
-        }
-        // static condensation of the two bubble rotations (MITC3.py:958-1007)
-        const double det = Kbb[0][0] * Kbb[1][1] - Kbb[0][1] * Kbb[1][0];
-        const double i00 = Kbb[1][1] / det, i01 = -Kbb[0][1] / det, i10 = -Kbb[1][0] / det, i11 = Kbb[0][0] / det;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++)
-                Kij[a][b] -= Ni[a][0] * (i00 * Nj[b][0] + i01 * Nj[b][1]) + Ni[a][1] * (i10 * Nj[b][0] + i11 * Nj[b][1]);
-        if (ti == tj) {
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (Kij[a][b] + Kij[b][a]); Kij[a][b] = m; Kij[b][a] = m; }
-        }
-        // membrane CST (MITC3.py:1009-1022): area * Bm_i^T A Bm_j
-        {
-            const double ar = geo.area;
-            const double cu[3] = {A[0] * Fj.dhx + A[2] * Fj.dhy, A[3] * Fj.dhx + A[5] * Fj.dhy, A[6] * Fj.dhx + A[8] * Fj.dhy};
-            const double cv[3] = {A[1] * Fj.dhy + A[2] * Fj.dhx, A[4] * Fj.dhy + A[5] * Fj.dhx, A[7] * Fj.dhy + A[8] * Fj.dhx};
-            L[0][0] = ar * (Fi.dhx * cu[0] + Fi.dhy * cu[2]) + dr[0][0]; L[0][1] = ar * (Fi.dhx * cv[0] + Fi.dhy * cv[2]) + dr[0][1];
-            L[1][0] = ar * (Fi.dhy * cu[1] + Fi.dhx * cu[2]) + dr[1][0]; L[1][1] = ar * (Fi.dhy * cv[1] + Fi.dhx * cv[2]) + dr[1][1];
-        }
-        L[0][5] = drz[0]; L[1][5] = drz[1]; L[5][0] = dzr[0]; L[5][1] = dzr[1]; L[5][5] = dzz;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) L[2 + a][2 + b] = Kij[a][b];
-        if (coupled) {
-            L[0][3] = cpl_ij[0][0]; L[0][4] = cpl_ij[0][1]; L[1][3] = cpl_ij[1][0]; L[1][4] = cpl_ij[1][1];
-            L[3][0] = cpl_ji[0][0]; L[4][0] = cpl_ji[0][1]; L[3][1] = cpl_ji[1][0]; L[4][1] = cpl_ji[1][1];
-        }
-        const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
-        rotate_block6(L, R, G);
-        if (ti == tj) {
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = a + 1; b < 6; b++) { const double m = 0.5 * (G[a][b] + G[b][a]); G[a][b] = m; G[b][a] = m; }
-        }
-    }
-    double2 *dst = reinterpret_cast<double2 *>(out + t * 36);
-#pragma unroll
-    for (int c = 0; c < 18; c++) dst[c] = make_double2((&G[0][0])[2 * c], (&G[0][0])[2 * c + 1]);
-}
 
 // ------------------------------------------------------------------------------------------
-// MITC3+ stiffness, wave-per-10-elements form (the shipped one; mitc3_k_kernel above is the simple thread-per-pair
-// statement of the same arithmetic, kept for reference and for the A/B test).
+// MITC3+ stiffness, wave-per-10-elements form (the thread-per-pair statement of the same arithmetic it replaced is
+// parked in tools/exp/parked_kernels_r02.inc.txt).
 //   stage 1  lane = (element q, function f = node 0..2 or bubble 3), 40 lanes: triangle geometry and the shape /
 //            tying data of f at the 3 Hammer points -> LDS, 23 doubles per (q, f); frame and area per element
 //   stage 2  lane = (element q, node pair p), 60 lanes: the pair's 6 x 6 block from the LDS image, Gauss point by
@@ -1820,7 +1696,7 @@ __device__ __forceinline__ double tri_dy(const TriG &F, const double *c5) {
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mitc3_k_lds_kernel(const double *__restrict__ xyz,
                                                          const int32_t *__restrict__ prop_id,
-                                                         const fs_shell_prop *__restrict__ props,
+                                                         const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                          int64_t E, double *__restrict__ out,
                                                          int32_t *__restrict__ status) {
     __shared__ double lds[M3_LDS];
@@ -1872,7 +1748,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double G[6][6];
     {
 #pragma clang fp contract(fast)
-        const fs_shell_prop *pr = props + prop_id[e];
+        const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
         const int qi = qq * 4 + ti, qj = qq * 4 + tj, qb = qq * 4 + 3;
         const double area = lds[M3_GEO + qq];
         const double idhx = lds[M3_FN + 21 * 40 + qi], idhy = lds[M3_FN + 22 * 40 + qi];
@@ -2008,7 +1884,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // MITC3 consistent mass (MITC3.py:1105-1138): one thread per (element, pair)
 __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
-                                                      const fs_shell_prop *__restrict__ props,
+                                                      const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                       int64_t E, double *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E * 6) return;
@@ -2020,7 +1896,7 @@ __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__
     for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
     TriGeom geo;
     tri_geometry(x, geo);
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     const double mt = pr->m_t, mr = pr->m_r;
     double ct = 0.0, cr = 0.0;
     for (int g = 0; g < 3; g++) {
@@ -2050,7 +1926,7 @@ __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__
 
 // ------------------------------------------------------------------------------------------
 // MITC3 total-Lagrangian tangent and internal force (MITC3.py:1144-1832, composite overrides
-// MITC3_composite.py:246-265, 496-621).  One lane per element; runs AFTER mitc3_k_kernel has
+// MITC3_composite.py:246-265, 496-621).  One lane per element; runs AFTER mitc3_k_lds_kernel has
 // written the linear blocks K (global axes, INITIAL frame R0) into `kt` (FS_LAYOUT_SYMBLK, 6 pairs).
 // Reference quirk kept: T() is rebuilt from the CURRENT coordinates x + u (MITC3.py:471-494) while
 // K0, the derivatives and the area come from the initial geometry.  With Rc the current frame and
@@ -2061,17 +1937,19 @@ __global__ __launch_bounds__(256) void mitc3_m_kernel(const double *__restrict__
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
-                                                      const fs_shell_prop *__restrict__ props,
+                                                      const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                       const double *__restrict__ ue, int64_t E,
                                                       const double *k0, double *kt, int want_kt,
-                                                      double *__restrict__ fe) {
+                                                      double *__restrict__ fe,
+                                                      const double *__restrict__ sig_in) {
+    // sig_in: optional [E][3] local membrane stress replacing the computed one (MITC3.py:1717-1745)
     // k0: the linear blocks K (read); kt: K_T (written when want_kt); they may be the same buffer (in place)
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     double x[3][3], u[3][6];
     for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
     for (int c = 0; c < 18; c++) (&u[0][0])[c] = ue[e * 18 + c];
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     TriGeom geo;
     tri_geometry(x, geo);
     const double R0[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
@@ -2167,6 +2045,7 @@ __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__
             } else {
                 for (int a = 0; a < 3; a++) sig[a] = C[a][0] * eps[0] + C[a][1] * eps[1] + C[a][2] * eps[2];
             }
+            if (sig_in) { sig[0] = sig_in[e * 3]; sig[1] = sig_in[e * 3 + 1]; sig[2] = sig_in[e * 3 + 2]; }
             Sm00 = sig[0] * h; Sm11 = sig[1] * h; Sm01 = sig[2] * h;
             // K_m,CST u_loc (MITC3.py:1018-1024), subtracted from f: A eps * area
             if (fe) {
@@ -2261,7 +2140,7 @@ __global__ __launch_bounds__(64) void mitc3_nl_kernel(const double *__restrict__
 template <int NN>
 __global__ __launch_bounds__(256) void shell_kg_kernel(const double *__restrict__ xyz,
                                                        const int32_t *__restrict__ prop_id,
-                                                       const fs_shell_prop *__restrict__ props,
+                                                       const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                        const double *__restrict__ sigma, int64_t E,
                                                        double *__restrict__ out, int tiled) {
     constexpr int NP = NN * (NN + 1) / 2;
@@ -2273,7 +2152,7 @@ __global__ __launch_bounds__(256) void shell_kg_kernel(const double *__restrict_
     while (rem >= NN - ti) { rem -= NN - ti; ti++; }
     const int tj = ti + rem;
     const double s0 = sigma[e * 3], s1 = sigma[e * 3 + 1], s2 = sigma[e * 3 + 2];
-    const double h = props[prop_id[e]].h;
+    const double h = props[safe_pid(prop_id[e], n_props)].h;
     const bool skip = __builtin_fmax(__builtin_fabs(s0), __builtin_fmax(__builtin_fabs(s1), __builtin_fabs(s2))) < 1e-20;
     double g = 0.0, R[3][3];
     if constexpr (NN == 3) {
@@ -2345,7 +2224,7 @@ __device__ __forceinline__ bool radial_dir(const double *x, const Vec3 &ax, cons
 
 __global__ __launch_bounds__(256) void centrifugal_tri_kernel(const double *__restrict__ xyz,
                                                               const int32_t *__restrict__ prop_id,
-                                                              const fs_shell_prop *__restrict__ props,
+                                                              const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                               double omega, Vec3 ax, Vec3 ce, int64_t E,
                                                               double *__restrict__ sigma) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2356,7 +2235,7 @@ __global__ __launch_bounds__(256) void centrifugal_tri_kernel(const double *__re
     tri_geometry(x, geo);
     double rd[3], rr, s0 = 0.0, s1 = 0.0, s2 = 0.0;
     if (radial_dir<3>(&x[0][0], ax, ce, rd, rr)) {
-        const double rho = props[prop_id[e]].rho;
+        const double rho = props[safe_pid(prop_id[e], n_props)].rho;
         const double sm = rho * (omega * omega) * rr * __builtin_sqrt(geo.area);
         const double c = dot3(geo.e1, rd), sn = dot3(geo.e2, rd);
         s0 = sm * (c * c); s1 = sm * (sn * sn); s2 = sm * c * sn;
@@ -2367,7 +2246,7 @@ __global__ __launch_bounds__(256) void centrifugal_tri_kernel(const double *__re
 template <int NN>
 __global__ __launch_bounds__(256) void centrifugal_solid_kernel(const double *__restrict__ xyz,
                                                                 const int32_t *__restrict__ prop_id,
-                                                                const double *__restrict__ props,
+                                                                const double *__restrict__ props, int32_t n_props,
                                                                 double omega, Vec3 ax, Vec3 ce, int64_t E,
                                                                 double *__restrict__ sigma) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2382,7 +2261,7 @@ __global__ __launch_bounds__(256) void centrifugal_solid_kernel(const double *__
             for (int i = 1; i < NN; i++) { mn = __builtin_fmin(mn, x[3 * i + k]); mx = __builtin_fmax(mx, x[3 * i + k]); }
             d[k] = mx - mn;
         }
-        const double rho = props[(int64_t)prop_id[e] * 37 + 36];
+        const double rho = props[(int64_t)safe_pid(prop_id[e], n_props) * 37 + 36];
         const double sm = rho * (omega * omega) * rr * (norm3(d) / 1.732);
         sg[0] = sm * rd[0] * rd[0]; sg[1] = sm * rd[1] * rd[1]; sg[2] = sm * rd[2] * rd[2];
         sg[3] = sm * rd[0] * rd[1]; sg[4] = sm * rd[1] * rd[2]; sg[5] = sm * rd[0] * rd[2];
@@ -2400,7 +2279,7 @@ __global__ __launch_bounds__(256) void centrifugal_solid_kernel(const double *__
 template <int NN, int NG, bool TAB>
 __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ xyz,
                                                     const int32_t *__restrict__ prop_id,
-                                                    const double *__restrict__ props, int64_t E,
+                                                    const double *__restrict__ props, int32_t n_props, int64_t E,
                                                     SolidRule rule, const double *__restrict__ tab, int ng_tab,
                                                     double bx, double by, double bz,
                                                     const double *__restrict__ sigma,
@@ -2473,7 +2352,7 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
         int ti = 0, rem = p;
         while (rem >= NN - ti) { rem -= NN - ti; ti++; }
         const int tj = ti + rem;
-        const double *pr = props + 37 * (int64_t)prop_id[e];
+        const double *pr = props + 37 * (int64_t)safe_pid(prop_id[e], n_props);
         const int64_t ob = (e * NPAIR + p) * 9;
         if (Ke) {
             double C[6][6];
@@ -2544,6 +2423,46 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
     }
 }
 
+// local-axes views of global-axes element results (the transform_to_global=False outputs of MITC4.py:1191-1341 and
+// MITC3.py:1501-1832: K_local = T K T^T, f_local = T f with T = blockdiag of the frame rows e1, e2, e3): one thread per
+// 3 x 3 sub-block of the dense [nd][nd] matrix, resp. per 3-vector.  The frame is the kernels' own geometry stage on
+// `xyz` (quads: the initial coordinates; triangles: whatever coordinates the caller's T() uses -- the reference takes
+// the CURRENT ones, MITC3.py:471-492).
+template <int NN>
+__global__ __launch_bounds__(256) void rotate_local_kernel(const double *__restrict__ xyz, int64_t E,
+                                                           const double *__restrict__ Kg, const double *__restrict__ fg,
+                                                           double *__restrict__ Kl, double *__restrict__ fl) {
+    constexpr int NB = 2 * NN, ND = 6 * NN;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * NB * NB) return;
+    const int64_t e = t / (NB * NB);
+    const int bi = (int)(t % (NB * NB)) / NB, bj = (int)(t % (NB * NB)) % NB;
+    double x[NN][3], R[3][3];
+    for (int c = 0; c < NN * 3; c++) (&x[0][0])[c] = xyz[e * NN * 3 + c];
+    if constexpr (NN == 4) {
+        QuadGeom g;
+        quad_geometry(x, g);
+        for (int k = 0; k < 3; k++) { R[0][k] = g.e1[k]; R[1][k] = g.e2[k]; R[2][k] = g.e3[k]; }
+    } else {
+        TriGeom g;
+        tri_geometry(x, g);
+        for (int k = 0; k < 3; k++) { R[0][k] = g.e1[k]; R[1][k] = g.e2[k]; R[2][k] = g.e3[k]; }
+    }
+    if (Kg) {
+        double B[3][3], Y[3][3];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) B[a][b] = Kg[(e * ND + 3 * bi + a) * ND + 3 * bj + b];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) Y[a][b] = R[a][0] * B[0][b] + R[a][1] * B[1][b] + R[a][2] * B[2][b];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+                Kl[(e * ND + 3 * bi + a) * ND + 3 * bj + b] = Y[a][0] * R[b][0] + Y[a][1] * R[b][1] + Y[a][2] * R[b][2];
+    }
+    if (fg && bj == 0)
+        for (int a = 0; a < 3; a++)
+            fl[e * ND + 3 * bi + a] = R[a][0] * fg[e * ND + 3 * bi] + R[a][1] * fg[e * ND + 3 * bi + 1] + R[a][2] * fg[e * ND + 3 * bi + 2];
+}
+
 // geometry probe for bit-exactness tests
 __global__ void mitc4_geom_kernel(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
                                   double *acoef) {
@@ -2598,114 +2517,8 @@ __global__ void seg_gather_sum_kernel(const double *__restrict__ vals, const int
     }
 }
 
-// node-pair block assembly: one thread per (block, k, l); blocks sorted by (I, J)
-template <int D>
-__global__ __launch_bounds__(256) void csr_numeric_blk_kernel(const double *__restrict__ vals,
-                                                              const int64_t *__restrict__ nbr_ptr,
-                                                              const int32_t *__restrict__ blk_row,
-                                                              const int64_t *__restrict__ blk_ptr,
-                                                              const int64_t *__restrict__ contrib,
-                                                              int64_t nblk, double *__restrict__ data) {
-    constexpr int DD = D * D;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblk * DD) return;
-    const int64_t b = t / DD;
-    const int kl = (int)(t - b * DD);
-    const int k = kl / D, l = kl - k * D;
-    const int lk = l * D + k;
-    const int64_t I = blk_row[b];
-    const int64_t r0 = nbr_ptr[I], m = nbr_ptr[I + 1] - r0;
-    const int64_t lo = blk_ptr[b], hi = blk_ptr[b + 1];
-    double v = 0.0;
-    for (int64_t q = lo; q < hi; q++) {
-        const int64_t c = contrib[q];
-        v = v + vals[(c >> 1) * DD + ((c & 1) ? lk : kl)];
-    }
-    data[DD * r0 + (int64_t)k * D * m + D * (b - r0) + l] = v;
-}
-
-
-// node-pair block assembly, descriptor form: one 48-byte descriptor per block carries the output
-// position and up to 4 inline contributions, so the dependent-load chain is descriptor -> values
-// (two round trips) and the value loads of a thread are independent of each other.
-template <int D>
-__global__ __launch_bounds__(256) void csr_numeric_desc_kernel(const double *__restrict__ vals,
-                                                               const fs_blk_desc *__restrict__ desc,
-                                                               const int64_t *__restrict__ contrib,
-                                                               int64_t nblk, double *__restrict__ data) {
-    constexpr int DD = D * D;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblk * DD) return;
-    const int64_t b = t / DD;
-    const int kl = (int)(t - b * DD);
-    const int k = kl / D, l = kl - k * D;
-    const int lk = l * D + k;
-    const fs_blk_desc dsc = desc[b];
-    double v;
-    if (dsc.cnt <= 4) {
-        double x[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int64_t cc = dsc.c[c];
-            x[c] = (c < dsc.cnt) ? vals[(cc >> 1) * DD + ((cc & 1) ? lk : kl)] : 0.0;
-        }
-        v = ((x[0] + x[1]) + x[2]) + x[3];  // element order == reference insertion order
-    } else {
-        v = 0.0;
-        const int64_t lo = dsc.c[0];
-        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
-            const int64_t cc = contrib[q];
-            v = v + vals[(cc >> 1) * DD + ((cc & 1) ? lk : kl)];
-        }
-    }
-    data[dsc.dst + (int64_t)k * dsc.stride + l] = v;
-}
-
-// 16-byte-per-lane variant for even D: thread = (block, k, pair of columns).  Non-transposed
-// contributions are one aligned double2 load; transposed ones two 8-byte loads.
-template <int D>
-__global__ __launch_bounds__(256) void csr_numeric_desc2_kernel(const double *__restrict__ vals,
-                                                                const fs_blk_desc *__restrict__ desc,
-                                                                const int64_t *__restrict__ contrib,
-                                                                int64_t nblk, double *__restrict__ data) {
-    static_assert(D % 2 == 0, "needs an even block size");
-    constexpr int DD = D * D, H = D / 2, TPB = D * H;
-    // XCD-aware order: workgroup w runs on XCD w % 8, so give each XCD one contiguous eighth of the
-    // (I,J)-sorted blocks.  Block (J,I) re-reads the sources of (I,J) one mesh row later; inside one
-    // XCD that distance fits its 4 MB L2, across XCDs it never would.
-    const int64_t per_xcd = (gridDim.x + 7) / 8;
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t t = wg * blockDim.x + threadIdx.x;
-    if (t >= nblk * TPB) return;
-    const int64_t b = t / TPB;
-    const int r = (int)(t - b * TPB);
-    const int k = r / H, l = 2 * (r - k * H);
-    const fs_blk_desc dsc = desc[b];
-    auto fetch = [&](int64_t cc) -> double2 {
-        const double *base = vals + (cc >> 1) * DD;
-        if (cc & 1) return make_double2(base[l * D + k], base[(l + 1) * D + k]);
-        return *reinterpret_cast<const double2 *>(base + k * D + l);
-    };
-    double2 v;
-    if (dsc.cnt <= 4) {
-        double2 x[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) x[c] = (c < dsc.cnt) ? fetch(dsc.c[c]) : make_double2(0.0, 0.0);
-        v.x = ((x[0].x + x[1].x) + x[2].x) + x[3].x;  // element order == reference insertion order
-        v.y = ((x[0].y + x[1].y) + x[2].y) + x[3].y;
-    } else {
-        v = make_double2(0.0, 0.0);
-        const int64_t lo = dsc.c[0];
-        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
-            const double2 x = fetch(contrib[q]);
-            v.x = v.x + x.x; v.y = v.y + x.y;
-        }
-    }
-    *reinterpret_cast<double2 *>(data + dsc.dst + (int64_t)k * dsc.stride + l) = v;
-}
-
 // d = 3 (solids): one thread per (block, row k): three entries per thread instead of one -- a third of the threads,
-// descriptor reads and address arithmetic of csr_numeric_desc_kernel<3>; same sums in the same element order.
+// descriptor reads and address arithmetic of a thread-per-entry kernel; same sums in the same element order.
 __global__ __launch_bounds__(256) void csr_numeric_desc3_row_kernel(const double *__restrict__ vals,
                                                                     const fs_blk_desc *__restrict__ desc,
                                                                     const int64_t *__restrict__ contrib,
@@ -2763,7 +2576,7 @@ __global__ __launch_bounds__(256) void csr_numeric_desc3_row_kernel(const double
 //   * every contribution is fetched as ONE coalesced 16-byte load per lane (the 288-byte source
 //     block is contiguous), transposed contributions are transposed through LDS -- no strided
 //     8-byte loads, so the vector-memory instruction count per wave drops from ~9 to ~4.
-// Same sums, same element order as csr_numeric_desc_kernel (bitwise identical output).
+// Sums in element order (the reference's ADD_VALUES insertion order), +0.0 pads below 4 contributions.
 __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double *__restrict__ vals,
                                                                     const fs_blk_desc *__restrict__ desc,
                                                                     const int64_t *__restrict__ contrib,
@@ -2772,7 +2585,9 @@ __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double
     __shared__ double2 s_desc[BPW * 3];
     __shared__ double2 s_val[4][BPW * TPB];
     const int tid = threadIdx.x;
-    // XCD-aware order (see csr_numeric_desc2_kernel)
+    // XCD-aware order: workgroup w runs on XCD w % 8, so each XCD gets one contiguous eighth of the blocks: a block
+    // (I,J) and its transposed partner (J,I) read the same source block a few thousand blocks apart -- inside one
+    // XCD that distance fits its 4 MB L2, across XCDs it never would
     const int64_t per_xcd = (gridDim.x + 7) / 8;
     const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int64_t b0 = wg * BPW;
@@ -2838,89 +2653,14 @@ __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double
 }
 
 
-// Symmetric form of the descriptor assembly: one descriptor per node-pair block with I <= J; the
-// summed block is stored to (I,J) and, transposed, to (J,I) (bitwise what the separate reduction of
-// (J,I) would give: same contributions, same element order), so every source block is read once.
-template <int D>
-__global__ __launch_bounds__(256) void csr_numeric_sym2_kernel(const double *__restrict__ vals,
-                                                               const fs_blk_desc_sym *__restrict__ desc,
-                                                               const int64_t *__restrict__ contrib,
-                                                               int64_t ndesc, double *__restrict__ data) {
-    static_assert(D % 2 == 0, "needs an even block size");
-    constexpr int DD = D * D, H = D / 2, TPB = D * H, BPW = 256 / TPB;   // blocks per workgroup
-    __shared__ double s_blk[BPW * DD];
-    const int bl = threadIdx.x / TPB;
-    const int r = threadIdx.x - bl * TPB;
-    const int64_t b = (int64_t)blockIdx.x * BPW + bl;
-    const bool active = bl < BPW && b < ndesc;
-    const int k = r / H, l = 2 * (r - k * H);
-    fs_blk_desc_sym dsc;
-    dsc.dst_t = -1;
-    if (active) {
-        dsc = desc[b];
-        auto fetch = [&](int64_t cc) -> double2 {
-            const double *base = vals + (cc >> 1) * DD;
-            if (cc & 1) return make_double2(base[l * D + k], base[(l + 1) * D + k]);
-            return *reinterpret_cast<const double2 *>(base + k * D + l);
-        };
-        double2 v;
-        if (dsc.cnt <= 4) {
-            double2 x[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) x[c] = (c < dsc.cnt) ? fetch(dsc.c[c]) : make_double2(0.0, 0.0);
-            v.x = ((x[0].x + x[1].x) + x[2].x) + x[3].x;  // element order == reference insertion order
-            v.y = ((x[0].y + x[1].y) + x[2].y) + x[3].y;
-        } else {
-            v = make_double2(0.0, 0.0);
-            const int64_t lo = dsc.c[0];
-            for (int64_t q = lo; q < lo + dsc.cnt; q++) {
-                const double2 x = fetch(contrib[q]);
-                v.x = v.x + x.x; v.y = v.y + x.y;
-            }
-        }
-        *reinterpret_cast<double2 *>(data + dsc.dst + (int64_t)k * dsc.stride + l) = v;
-        s_blk[bl * DD + k * D + l] = v.x;
-        s_blk[bl * DD + k * D + l + 1] = v.y;
-    }
-    __syncthreads();
-    if (active && dsc.dst_t >= 0) {   // transposed partner, again as 16-byte row-contiguous stores
-        const double2 w = make_double2(s_blk[bl * DD + l * D + k], s_blk[bl * DD + (l + 1) * D + k]);
-        *reinterpret_cast<double2 *>(data + dsc.dst_t + (int64_t)k * dsc.stride_t + l) = w;
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void csr_numeric_sym_kernel(const double *__restrict__ vals,
-                                                              const fs_blk_desc_sym *__restrict__ desc,
-                                                              const int64_t *__restrict__ contrib,
-                                                              int64_t ndesc, double *__restrict__ data) {
-    constexpr int DD = D * D;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ndesc * DD) return;
-    const int64_t b = t / DD;
-    const int kl = (int)(t - b * DD);
-    const int k = kl / D, l = kl - k * D;
-    const int lk = l * D + k;
-    const fs_blk_desc_sym dsc = desc[b];
-    double v;
-    if (dsc.cnt <= 4) {
-        double x[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int64_t cc = dsc.c[c];
-            x[c] = (c < dsc.cnt) ? vals[(cc >> 1) * DD + ((cc & 1) ? lk : kl)] : 0.0;
-        }
-        v = ((x[0] + x[1]) + x[2]) + x[3];
-    } else {
-        v = 0.0;
-        const int64_t lo = dsc.c[0];
-        for (int64_t q = lo; q < lo + dsc.cnt; q++) {
-            const int64_t cc = contrib[q];
-            v = v + vals[(cc >> 1) * DD + ((cc & 1) ? lk : kl)];
-        }
-    }
-    data[dsc.dst + (int64_t)k * dsc.stride + l] = v;
-    if (dsc.dst_t >= 0) data[dsc.dst_t + (int64_t)l * dsc.stride_t + k] = v;
+// prop_id outside [0, n_props): FS_ST_BAD_PROP into the status array (the element kernels used row 0 for it)
+__global__ void prop_check_kernel(const int32_t *__restrict__ prop_id, int64_t E, int32_t n_props,
+                                  int32_t *__restrict__ status, int assign) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const bool bad = (uint32_t)prop_id[e] >= (uint32_t)n_props;
+    if (assign) status[e] = bad ? FS_ST_BAD_PROP : 0;
+    else if (bad) status[e] |= FS_ST_BAD_PROP;
 }
 
 template <int D>
@@ -2993,6 +2733,16 @@ int fs_device_info(int device, char *name, int len, int *cu_count) {
     return FS_OK;
 }
 
+// FS_ST_BAD_PROP for ids outside the table, after the element kernels (which used row 0 for them); `assign`: no
+// kernel of this call wrote the status array
+static int check_props(const int32_t *prop_id, int64_t E, int32_t n_props, int32_t *status, int assign, hipStream_t s) {
+    if (!status || E <= 0) return FS_OK;
+    hipLaunchKernelGGL(prop_check_kernel, dim3(grid_for(E, 256, INT32_MAX)), dim3(256), 0, s, prop_id, E, n_props, status,
+                       assign);
+    FS_LAUNCH_CHECK("prop_check_kernel");
+    return FS_OK;
+}
+
 int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
                         int32_t n_props, const double *u_e, int64_t E, uint32_t want,
                         uint32_t layout, double *Ke, double *Me, double *KTe, double *fe,
@@ -3015,51 +2765,40 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_quad_batch: fe is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
         if (!k_cached) {
-            if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
-            else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, KTe, status);
+            if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, E, KTe, status);
+            else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, E, KTe, status);
             FS_LAUNCH_CHECK("mitc4_k_kernel");
         }
         if (tiled)
-            hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E,
+            hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E,
                                k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
         else
-            hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
-                               E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled);
+            hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e,
+                               E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled, nullptr);
         FS_LAUNCH_CHECK("mitc4_nl_kernel");
     }
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_quad_batch: Ke is null");
         const unsigned grid = (unsigned)((E + 15) / 16);
-        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
-        else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, Ke, status);
+        if (tiled) hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, E, Ke, status);
+        else hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, E, Ke, status);
         FS_LAUNCH_CHECK("mitc4_k_kernel");
     }
     if (want & FS_WANT_M) {
         if (!Me) return fail(FS_EINVAL, "fs_shell_quad_batch: Me is null");
         if (tiled)
-            hipLaunchKernelGGL(mitc4_m_tiled_kernel, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, s, xyz, prop_id, props, E, Me);
+            hipLaunchKernelGGL(mitc4_m_tiled_kernel, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, s, xyz, prop_id, props, n_props, E, Me);
         else
             hipLaunchKernelGGL(mitc4_m_kernel, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz,
-                               prop_id, props, E, Me, tiled);
+                               prop_id, props, n_props, E, Me, tiled);
         FS_LAUNCH_CHECK("mitc4_m_kernel");
     }
-    return FS_OK;
+    return check_props(prop_id, E, n_props, status, !(want & (FS_WANT_K | FS_WANT_KT | FS_WANT_FINT)) || ((want & (FS_WANT_KT | FS_WANT_FINT)) && !(want & FS_WANT_K) && tiled && Ke), s);
 }
 
-// FEMSHELL_M3_SIMPLE=1 in the environment selects the thread-per-pair statement of the MITC3+ kernel (A/B tests)
-static bool m3_simple() {
-    static const bool v = [] { const char *e = getenv("FEMSHELL_M3_SIMPLE"); return e && e[0] == '1'; }();
-    return v;
-}
 #define M3_LAUNCH(dst)                                                                                              \
-    do {                                                                                                            \
-        if (m3_simple())                                                                                            \
-            hipLaunchKernelGGL(mitc3_k_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id, \
-                               props, E, dst, status);                                                              \
-        else                                                                                                        \
-            hipLaunchKernelGGL(mitc3_k_lds_kernel, dim3((unsigned)((E + M3_EPW - 1) / M3_EPW)), dim3(64), 0, s, xyz,  \
-                               prop_id, props, E, dst, status);                                                     \
-    } while (0)
+    hipLaunchKernelGGL(mitc3_k_lds_kernel, dim3((unsigned)((E + M3_EPW - 1) / M3_EPW)), dim3(64), 0, s, xyz, prop_id,  \
+                       props, n_props, E, dst, status)
 
 int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
                        int32_t n_props, const double *u_e, int64_t E, uint32_t want, uint32_t layout,
@@ -3079,37 +2818,37 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
         if ((want & FS_WANT_FINT) && !fe) return fail(FS_EINVAL, "fs_shell_tri_batch: fe is null");
         if (!k_cached) {
             M3_LAUNCH(KTe);
-            FS_LAUNCH_CHECK("mitc3_k_kernel");
+            FS_LAUNCH_CHECK("mitc3_k_lds_kernel");
         }
-        hipLaunchKernelGGL(mitc3_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, u_e,
-                           E, k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+        hipLaunchKernelGGL(mitc3_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e,
+                           E, k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, nullptr);
         FS_LAUNCH_CHECK("mitc3_nl_kernel");
     }
     if (want & FS_WANT_K) {
         if (!Ke) return fail(FS_EINVAL, "fs_shell_tri_batch: Ke is null");
         M3_LAUNCH(Ke);
-        FS_LAUNCH_CHECK("mitc3_k_kernel");
+        FS_LAUNCH_CHECK("mitc3_k_lds_kernel");
     }
     if (want & FS_WANT_M) {
         if (!Me) return fail(FS_EINVAL, "fs_shell_tri_batch: Me is null");
         hipLaunchKernelGGL(mitc3_m_kernel, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, E, Me);
+                           props, n_props, E, Me);
         FS_LAUNCH_CHECK("mitc3_m_kernel");
     }
-    return FS_OK;
+    return check_props(prop_id, E, n_props, status, !(want & (FS_WANT_K | FS_WANT_KT | FS_WANT_FINT)) || ((want & (FS_WANT_KT | FS_WANT_FINT)) && !(want & FS_WANT_K) && Ke), s);
 }
 
 }  // extern "C" (reopened below)
 
 namespace {
 template <int NN, int NG, bool TAB>
-int launch_solid(const double *xyz, const int32_t *prop_id, const double *props, int64_t E, const SolidRule &rule,
+int launch_solid(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props, int64_t E, const SolidRule &rule,
                  const double *tab, int ng_tab, const double *b, const double *sigma, double *Ke, double *Me,
                  double *fe, double *KGe, int32_t *status, hipStream_t s) {
     constexpr int EPB = 256 / (NN * (NN + 1) / 2);
     static_assert(EPB >= 1 && EPB * NG <= 256, "phase 1 needs one thread per (element, Gauss point)");
     hipLaunchKernelGGL((solid_kernel<NN, NG, TAB>), dim3(grid_for((E + EPB - 1) / EPB, 1, INT32_MAX)), dim3(256), 0, s,
-                       xyz, prop_id, props, E, rule, tab, ng_tab, b[0], b[1], b[2], sigma, Ke, Me, fe, KGe, status);
+                       xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b[0], b[1], b[2], sigma, Ke, Me, fe, KGe, status);
     return 0;
 }
 
@@ -3181,16 +2920,16 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
         if (rc != FS_OK) return rc;
     }
     switch (nn) {
-        case 20: launch_solid<20, 27, true>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
-        case 15: launch_solid<15, 21, true>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
-        case 10: launch_solid<10, 4, true>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
-        case 8: launch_solid<8, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
-        case 6: launch_solid<6, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
-        case 5: launch_solid<5, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
-        default: launch_solid<4, 8, false>(xyz, prop_id, props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 20: launch_solid<20, 27, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 15: launch_solid<15, 21, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 10: launch_solid<10, 4, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 8: launch_solid<8, 8, false>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 6: launch_solid<6, 8, false>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 5: launch_solid<5, 8, false>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        default: launch_solid<4, 8, false>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
     }
     FS_LAUNCH_CHECK("solid_kernel");
-    return FS_OK;
+    return check_props(prop_id, E, n_props, status, 0, s);   // the solid kernel ORs into the caller-zeroed array
 }
 
 int fs_solid2_table(int32_t nn, double *pts, double *w, double *vals, int32_t *ng) {
@@ -3221,11 +2960,54 @@ int fs_shell_kg_batch(int32_t nn, const double *xyz, const int32_t *prop_id, con
     hipStream_t s = (hipStream_t)stream;
     if (nn == 3)
         hipLaunchKernelGGL(shell_kg_kernel<3>, dim3(grid_for(E * 6, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, sigma, E, KGe, 0);
+                           props, n_props, sigma, E, KGe, 0);
     else
         hipLaunchKernelGGL(shell_kg_kernel<4>, dim3(grid_for(E * 10, 256, INT32_MAX)), dim3(256), 0, s, xyz, prop_id,
-                           props, sigma, E, KGe, tiled);
+                           props, n_props, sigma, E, KGe, tiled);
     FS_LAUNCH_CHECK("shell_kg_kernel");
+    return FS_OK;
+}
+
+int fs_shell_kt_sigma_batch(int32_t nn, const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                            int32_t n_props, const double *u_e, const double *sigma, int64_t E, double *KTe,
+                            int32_t *status, void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_kt_sigma_batch: bad sizes");
+    if (nn != 3 && nn != 4) return fail(FS_EINVAL, "fs_shell_kt_sigma_batch: nn must be 3 (MITC3) or 4 (MITC4)");
+    if (E == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !u_e || !sigma || !KTe) return fail(FS_EINVAL, "fs_shell_kt_sigma_batch: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (nn == 4) {
+        hipLaunchKernelGGL(mitc4_k_kernel<false>, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, s, xyz, prop_id, props,
+                           n_props, E, KTe, status);
+        FS_LAUNCH_CHECK("mitc4_k_kernel");
+        hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, n_props,
+                           u_e, E, KTe, 1, (double *)nullptr, 0, sigma);
+        FS_LAUNCH_CHECK("mitc4_nl_kernel");
+    } else {
+        M3_LAUNCH(KTe);
+        FS_LAUNCH_CHECK("mitc3_k_lds_kernel");
+        hipLaunchKernelGGL(mitc3_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, n_props,
+                           u_e, E, KTe, KTe, 1, (double *)nullptr, sigma);
+        FS_LAUNCH_CHECK("mitc3_nl_kernel");
+    }
+    return check_props(prop_id, E, n_props, status, 0, s);
+}
+
+int fs_shell_rotate_local(int32_t nn, const double *xyz, int64_t E, const double *K_global, const double *f_global,
+                          double *K_local, double *f_local, void *stream) {
+    if (E < 0) return fail(FS_EINVAL, "fs_shell_rotate_local: E < 0");
+    if (nn != 3 && nn != 4) return fail(FS_EINVAL, "fs_shell_rotate_local: nn must be 3 (MITC3) or 4 (MITC4)");
+    if (E == 0) return FS_OK;
+    if (!xyz || (!K_global && !f_global) || (K_global && !K_local) || (f_global && !f_local))
+        return fail(FS_EINVAL, "fs_shell_rotate_local: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (nn == 4)
+        hipLaunchKernelGGL(rotate_local_kernel<4>, dim3(grid_for(E * 64, 256, INT32_MAX)), dim3(256), 0, s, xyz, E, K_global,
+                           f_global, K_local, f_local);
+    else
+        hipLaunchKernelGGL(rotate_local_kernel<3>, dim3(grid_for(E * 36, 256, INT32_MAX)), dim3(256), 0, s, xyz, E, K_global,
+                           f_global, K_local, f_local);
+    FS_LAUNCH_CHECK("rotate_local_kernel");
     return FS_OK;
 }
 
@@ -3247,18 +3029,18 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for(E, 256, INT32_MAX)), block(256);
     if (!solid) {
-        hipLaunchKernelGGL(centrifugal_tri_kernel, grid, block, 0, s, xyz, prop_id, (const fs_shell_prop *)props, omega,
+        hipLaunchKernelGGL(centrifugal_tri_kernel, grid, block, 0, s, xyz, prop_id, (const fs_shell_prop *)props, n_props, omega,
                            ax, ce, E, sigma);
     } else {
         const double *pp = (const double *)props;
         switch (nn) {
-            case 20: hipLaunchKernelGGL(centrifugal_solid_kernel<20>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
-            case 15: hipLaunchKernelGGL(centrifugal_solid_kernel<15>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
-            case 10: hipLaunchKernelGGL(centrifugal_solid_kernel<10>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
-            case 8: hipLaunchKernelGGL(centrifugal_solid_kernel<8>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
-            case 6: hipLaunchKernelGGL(centrifugal_solid_kernel<6>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
-            case 5: hipLaunchKernelGGL(centrifugal_solid_kernel<5>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
-            default: hipLaunchKernelGGL(centrifugal_solid_kernel<4>, grid, block, 0, s, xyz, prop_id, pp, omega, ax, ce, E, sigma); break;
+            case 20: hipLaunchKernelGGL(centrifugal_solid_kernel<20>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            case 15: hipLaunchKernelGGL(centrifugal_solid_kernel<15>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            case 10: hipLaunchKernelGGL(centrifugal_solid_kernel<10>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            case 8: hipLaunchKernelGGL(centrifugal_solid_kernel<8>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            case 6: hipLaunchKernelGGL(centrifugal_solid_kernel<6>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            case 5: hipLaunchKernelGGL(centrifugal_solid_kernel<5>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            default: hipLaunchKernelGGL(centrifugal_solid_kernel<4>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
         }
     }
     FS_LAUNCH_CHECK("centrifugal kernel");
@@ -3268,6 +3050,7 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
 int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
                        double *acoef, void *stream) {
     if (E <= 0) return E == 0 ? FS_OK : fail(FS_EINVAL, "fs_shell_quad_geom: E < 0");
+    if (!xyz || !frame || !xl || !detJ) return fail(FS_EINVAL, "fs_shell_quad_geom: null argument");
     hipLaunchKernelGGL(mitc4_geom_kernel, dim3(grid_for(E, 64, INT32_MAX)), dim3(64), 0, (hipStream_t)stream,
                        xyz, E, frame, xl, detJ, acoef);
     FS_LAUNCH_CHECK("mitc4_geom_kernel");
@@ -3278,6 +3061,7 @@ int fs_blk_expand(const double *packed, uint32_t layout, int64_t E, int32_t nn, 
                   void *stream) {
     if (E <= 0) return E == 0 ? FS_OK : fail(FS_EINVAL, "fs_blk_expand: E < 0");
     if (nn <= 0 || d <= 0) return fail(FS_EINVAL, "fs_blk_expand: bad nn/d");
+    if (!packed || !dense) return fail(FS_EINVAL, "fs_blk_expand: null argument");
     if (layout != FS_LAYOUT_SYMBLK && !(layout == FS_LAYOUT_SYMBLK_T16 && nn == 4 && d == 6))
         return fail(FS_EINVAL, "fs_blk_expand: layout must be FS_LAYOUT_SYMBLK, or FS_LAYOUT_SYMBLK_T16 for quads");
     hipLaunchKernelGGL(blk_expand_kernel, dim3(grid_for(E * nn * d * nn * d, 256, 65536)), dim3(256), 0,
@@ -3289,6 +3073,7 @@ int fs_blk_expand(const double *packed, uint32_t layout, int64_t E, int32_t nn, 
 int fs_csr_numeric(const double *vals, const int64_t *src, const int64_t *seg_ptr, int64_t nnz,
                    double *data, void *stream) {
     if (nnz <= 0) return nnz == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric: nnz < 0");
+    if (!vals || !src || !seg_ptr || !data) return fail(FS_EINVAL, "fs_csr_numeric: null argument");
     hipLaunchKernelGGL(seg_gather_sum_kernel, dim3(grid_for(nnz, 256, 1 << 16)), dim3(256), 0,
                        (hipStream_t)stream, vals, src, seg_ptr, nnz, data);
     FS_LAUNCH_CHECK("seg_gather_sum_kernel");
@@ -3300,27 +3085,10 @@ int fs_vec_gather_sum(const double *vals, const int64_t *src, const int64_t *seg
     return fs_csr_numeric(vals, src, seg_ptr, n, out, stream);
 }
 
-int fs_csr_numeric_blk(const double *vals, const int64_t *nbr_ptr, const int32_t *blk_row,
-                       const int64_t *blk_ptr, const int64_t *contrib, int64_t nblk, int32_t d,
-                       double *data, void *stream) {
-    if (nblk <= 0) return nblk == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric_blk: nblk < 0");
-    hipStream_t s = (hipStream_t)stream;
-    if (d == 6) {
-        hipLaunchKernelGGL(csr_numeric_blk_kernel<6>, dim3(grid_for(nblk * 36, 256, INT32_MAX)), dim3(256), 0, s,
-                           vals, nbr_ptr, blk_row, blk_ptr, contrib, nblk, data);
-    } else if (d == 3) {
-        hipLaunchKernelGGL(csr_numeric_blk_kernel<3>, dim3(grid_for(nblk * 9, 256, INT32_MAX)), dim3(256), 0, s,
-                           vals, nbr_ptr, blk_row, blk_ptr, contrib, nblk, data);
-    } else {
-        return fail(FS_EINVAL, "fs_csr_numeric_blk: d must be 3 or 6");
-    }
-    FS_LAUNCH_CHECK("csr_numeric_blk_kernel");
-    return FS_OK;
-}
-
 int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64_t *contrib,
                         int64_t nblk, int32_t d, double *data, void *stream) {
     if (nblk <= 0) return nblk == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric_desc: nblk < 0");
+    if (!vals || !desc || !contrib || !data) return fail(FS_EINVAL, "fs_csr_numeric_desc: null argument");
     hipStream_t s = (hipStream_t)stream;
     if (d == 6) {
         hipLaunchKernelGGL(csr_numeric_desc6_lds_kernel, dim3(8 * grid_for(nblk, 14 * 8, INT32_MAX / 8)), dim3(256), 0, s,
@@ -3335,27 +3103,12 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
     return FS_OK;
 }
 
-int fs_csr_numeric_sym(const double *vals, const fs_blk_desc_sym *desc, const int64_t *contrib,
-                       int64_t ndesc, int32_t d, double *data, void *stream) {
-    if (ndesc <= 0) return ndesc == 0 ? FS_OK : fail(FS_EINVAL, "fs_csr_numeric_sym: ndesc < 0");
-    hipStream_t s = (hipStream_t)stream;
-    if (d == 6) {
-        hipLaunchKernelGGL(csr_numeric_sym2_kernel<6>, dim3(grid_for(ndesc, 14, INT32_MAX)), dim3(256), 0, s,
-                           vals, desc, contrib, ndesc, data);
-    } else if (d == 3) {
-        hipLaunchKernelGGL(csr_numeric_sym_kernel<3>, dim3(grid_for(ndesc * 9, 256, INT32_MAX)), dim3(256), 0, s,
-                           vals, desc, contrib, ndesc, data);
-    } else {
-        return fail(FS_EINVAL, "fs_csr_numeric_sym: d must be 3 or 6");
-    }
-    FS_LAUNCH_CHECK("csr_numeric_sym_kernel");
-    return FS_OK;
-}
-
 int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int32_t *nbr,
                        int64_t n_nodes, int64_t nblk, int32_t d, int64_t *indptr, int32_t *indices,
                        void *stream) {
     if (n_nodes <= 0 || nblk < 0) return fail(FS_EINVAL, "fs_csr_pattern_blk: bad sizes");
+    if (!nbr_ptr || !indptr || (nblk > 0 && (!blk_row || !nbr || !indices)))
+        return fail(FS_EINVAL, "fs_csr_pattern_blk: null argument");
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (nblk * d * d > n_nodes * d) ? nblk * d * d : n_nodes * d;
     if (d == 6) {
@@ -3373,6 +3126,7 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
 
 int fs_halo_pack(const double *data, const int64_t *idx, int64_t n, double *buf, void *stream) {
     if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_halo_pack: n < 0");
+    if (!data || !idx || !buf) return fail(FS_EINVAL, "fs_halo_pack: null argument");
     hipLaunchKernelGGL(halo_pack_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, data,
                        idx, n, buf);
     FS_LAUNCH_CHECK("halo_pack_kernel");
@@ -3381,6 +3135,7 @@ int fs_halo_pack(const double *data, const int64_t *idx, int64_t n, double *buf,
 
 int fs_halo_add(const double *buf, const int64_t *idx, int64_t n, double *data, void *stream) {
     if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_halo_add: n < 0");
+    if (!data || !idx || !buf) return fail(FS_EINVAL, "fs_halo_add: null argument");
     hipLaunchKernelGGL(halo_add_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, buf,
                        idx, n, data);
     FS_LAUNCH_CHECK("halo_add_kernel");
@@ -3439,11 +3194,11 @@ int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const 
     const unsigned grid = (unsigned)((E + 15) / 16);
     // every block of every tile (the padding of a ragged last tile included) is rewritten by the stiffness kernel
     // before the force kernel reads it, so nothing of the previous call's contents has to be cleared
-    hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, E, ws, status);
+    hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, E, ws, status);
     FS_LAUNCH_CHECK("mitc4_k_kernel");
-    hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, u_e, E, ws, ws, 0, fe);
+    hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E, ws, ws, 0, fe);
     FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
-    return FS_OK;
+    return check_props(prop_id, E, n_props, status, 0, s);
 }
 
 int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,

@@ -42,7 +42,7 @@ struct StressPts { double r[4], s[4]; int n; };
 template <int NN>
 __global__ __launch_bounds__(256) void shell_stress_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
-                                                           const fs_shell_prop *__restrict__ props,
+                                                           const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                            const double *__restrict__ u_e, int64_t E,
                                                            StressPts pts, int location, uint32_t parts,
                                                            int strain, double *__restrict__ out,
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void shell_stress_kernel(const double *__restr
     const int p = (int)(t - e * pts.n);
     double r = 0.0, s = 0.0;
     for (int k = 0; k < 4; k++) { r = (k == p) ? pts.r[k] : r; s = (k == p) ? pts.s[k] : s; }
-    const fs_shell_prop *pr = props + prop_id[e];
+    const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     double dNx[NN], dNy[NN], area = 0.0;
     if constexpr (NN == 4) {
         double x[4][3];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void shell_stress_kernel(const double *__restr
 template <int NN, int NG, bool TAB>
 __global__ __launch_bounds__(256) void solid_stress_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
-                                                           const double *__restrict__ props,
+                                                           const double *__restrict__ props, int32_t n_props,
                                                            const double *__restrict__ u_e, int64_t E,
                                                            SolidRule rule, const double *__restrict__ tab, int ng_tab,
                                                            const double *__restrict__ extrap,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void solid_stress_kernel(const double *__restr
             ep[0] += gx * ux; ep[1] += gy * uy; ep[2] += gz * uz;
             ep[3] += gy * ux + gx * uy; ep[4] += gz * uy + gy * uz; ep[5] += gz * ux + gx * uz;
         }
-        const double *C = props + 37 * (int64_t)prop_id[e];
+        const double *C = props + 37 * (int64_t)safe_pid(prop_id[e], n_props);
 #pragma unroll
         for (int a = 0; a < 6; a++) {
             double v = 0.0;
@@ -301,11 +301,11 @@ __global__ __launch_bounds__(256) void strain_invariants_kernel(const double *__
 }
 
 template <int NN, int NG, bool TAB>
-void launch_solid_stress(const double *xyz, const int32_t *prop_id, const double *props, const double *u_e, int64_t E,
+void launch_solid_stress(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props, const double *u_e, int64_t E,
                          const SolidRule &rule, const double *tab, int ng_tab, const double *extrap, int mode,
                          double *sig, double *eps, double *w, hipStream_t s) {
     constexpr int EPB = 256 / ((NG > NN) ? NG : NN);
-    hipLaunchKernelGGL((solid_stress_kernel<NN, NG, TAB>), dim3(grid_of(E, EPB)), dim3(256), 0, s, xyz, prop_id, props,
+    hipLaunchKernelGGL((solid_stress_kernel<NN, NG, TAB>), dim3(grid_of(E, EPB)), dim3(256), 0, s, xyz, prop_id, props, n_props,
                        u_e, E, rule, tab, ng_tab, extrap, mode, sig, eps, w);
 }
 
@@ -330,10 +330,10 @@ int fs_shell_stress_batch(int32_t nn, const double *xyz, const int32_t *prop_id,
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_of(E * npts, 256)), block(256);
     if (nn == 4)
-        hipLaunchKernelGGL(shell_stress_kernel<4>, grid, block, 0, s, xyz, prop_id, props, u_e, E, pts, location, parts,
+        hipLaunchKernelGGL(shell_stress_kernel<4>, grid, block, 0, s, xyz, prop_id, props, n_props, u_e, E, pts, location, parts,
                            strain, out, weight);
     else
-        hipLaunchKernelGGL(shell_stress_kernel<3>, grid, block, 0, s, xyz, prop_id, props, u_e, E, pts, location, parts,
+        hipLaunchKernelGGL(shell_stress_kernel<3>, grid, block, 0, s, xyz, prop_id, props, n_props, u_e, E, pts, location, parts,
                            strain, out, weight);
     ST_LAUNCH_CHECK("shell_stress_kernel");
     return FS_OK;
@@ -363,13 +363,13 @@ int fs_solid_stress_batch(int32_t nn, int32_t reduced, const double *xyz, const 
     }
     hipStream_t s = (hipStream_t)stream;
     switch (nn) {
-        case 20: launch_solid_stress<20, 27, true>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
-        case 15: launch_solid_stress<15, 21, true>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
-        case 10: launch_solid_stress<10, 4, true>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
-        case 8: launch_solid_stress<8, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
-        case 6: launch_solid_stress<6, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
-        case 5: launch_solid_stress<5, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
-        default: launch_solid_stress<4, 8, false>(xyz, prop_id, props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 20: launch_solid_stress<20, 27, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 15: launch_solid_stress<15, 21, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 10: launch_solid_stress<10, 4, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 8: launch_solid_stress<8, 8, false>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 6: launch_solid_stress<6, 8, false>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 5: launch_solid_stress<5, 8, false>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        default: launch_solid_stress<4, 8, false>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
     }
     ST_LAUNCH_CHECK("solid_stress_kernel");
     return FS_OK;

@@ -109,35 +109,62 @@ class ShellElement(FemElement):
         u = torch.from_numpy(self._current_displacements[None].copy()).to(batch._dev())
         return self._run(want_K=False, u_e=u, want_KT=want_KT, want_F=want_F)
 
+    def _frame_coords(self):
+        """Coordinates the reference's T() builds its frame from: the initial ones for MITC4 (MITC4.py:634-640 reads the
+        frame of __init__), the CURRENT ones for MITC3 (MITC3.py:471-492)."""
+        import torch
+        from . import batch
+        c = self._initial_coords if self._NN == 4 else self._current_coords
+        return torch.from_numpy(np.ascontiguousarray(c[None])).to(batch._dev())
+
+    def _to_local(self, K=None, f=None):
+        from . import batch
+        Kl, fl = batch.shell_rotate_local(self._NN, self._frame_coords(), K, f)
+        return (None if Kl is None else np.ascontiguousarray(Kl[0].cpu().numpy()),
+                None if fl is None else np.ascontiguousarray(fl[0].cpu().numpy()))
+
     def compute_tangent_stiffness(self, sigma=None, transform_to_global=True):
-        """K_T = T^T sym(K0 + K_L + K_sigma) T (elements/MITC4.py:1246-1298, MITC3.py:1717-1777,
-        composite overrides); global axes only."""
-        if sigma is not None or not transform_to_global:
-            raise NotImplementedError("only sigma=None, transform_to_global=True are on the GPU path")
-        return np.ascontiguousarray(self._run_nl(True, False)["KT"][0].cpu().numpy())
+        """K_T = T^T sym(K0 + K_L + K_sigma) T (elements/MITC4.py:1246-1298, MITC3.py:1717-1777, composite overrides).
+        sigma: local membrane stress [sxx, syy, sxy] used for K_sigma instead of the one derived from the current
+        displacements; transform_to_global=False returns the local-axes matrix T K_T T^T."""
+        import torch
+        from . import batch
+        if sigma is None:
+            KT = self._run_nl(True, False)["KT"]
+        else:
+            xyz, pid, props, dev = self._device_inputs()
+            sg = torch.from_numpy(np.ascontiguousarray(np.asarray(sigma, dtype=np.float64).reshape(1, 3))).to(dev)
+            u = torch.from_numpy(self._current_displacements[None].copy()).to(dev)
+            KT, st = batch.shell_kt_sigma_batch(self._NN, xyz, pid, props, 1, u, sg)
+            _check_status(int(st[0]), self.name)
+        if not transform_to_global:
+            return self._to_local(K=KT)[0]
+        return np.ascontiguousarray(KT[0].cpu().numpy())
 
     def compute_internal_forces(self, transform_to_global=True):
-        """elements/MITC4.py:1300-1341, MITC3.py:1779-1832; global axes only."""
+        """elements/MITC4.py:1300-1341, MITC3.py:1779-1832; transform_to_global=False returns T f."""
+        f = self._run_nl(False, True)["f_int"]
         if not transform_to_global:
-            raise NotImplementedError("only transform_to_global=True is on the GPU path")
-        return np.ascontiguousarray(self._run_nl(False, True)["f_int"][0].cpu().numpy())
+            return self._to_local(f=f)[1]
+        return np.ascontiguousarray(f[0].cpu().numpy())
 
     def compute_residual(self, f_ext, transform_to_global=True):
         return f_ext - self.compute_internal_forces(transform_to_global=transform_to_global)
 
     def compute_geometric_stiffness(self, sigma_membrane, transform_to_global=True):
         """K_sigma from a LOCAL membrane stress [sxx, syy, sxy] (elements/MITC4.py:1191-1225,
-        MITC3.py:1501-1580); global axes only."""
+        MITC3.py:1501-1580); transform_to_global=False returns the local-axes matrix."""
         import torch
         from . import batch
-        if not transform_to_global:
-            raise NotImplementedError("only transform_to_global=True is on the GPU path")
         xyz, pid, props, dev = self._device_inputs()
         sg = np.asarray(sigma_membrane, dtype=np.float64)
         if sg.shape == (2, 2):
             sg = np.array([sg[0, 0], sg[1, 1], sg[0, 1]])
         sg = torch.from_numpy(np.ascontiguousarray(sg.reshape(1, 3))).to(dev)
-        return np.ascontiguousarray(batch.shell_kg_batch(self._NN, xyz, pid, props, 1, sg, dense=True)[0].cpu().numpy())
+        KG = batch.shell_kg_batch(self._NN, xyz, pid, props, 1, sg, dense=True)
+        if not transform_to_global:
+            return self._to_local(K=KG)[0]
+        return np.ascontiguousarray(KG[0].cpu().numpy())
 
 
 class MITC4(ShellElement):

@@ -14,9 +14,6 @@ Outputs (host NumPy; moved to the device by the assembler):
 import numpy as np
 
 
-BLK_DESC_SYM_DTYPE = np.dtype([("dst", "i8"), ("dst_t", "i8"), ("stride", "i4"), ("stride_t", "i4"),
-                               ("cnt", "i4"), ("pad_", "i4"), ("c", "i8", (4,))])
-assert BLK_DESC_SYM_DTYPE.itemsize == 64
 BLK_DESC_DTYPE = np.dtype([("dst", "i8"), ("stride", "i4"), ("cnt", "i4"), ("c", "i8", (4,))])
 assert BLK_DESC_DTYPE.itemsize == 48
 
@@ -169,28 +166,6 @@ class BlockPlan:
         desc["c"][big, 0] = start[big]
         return desc
 
-    def sym_descriptors(self):
-        """fs_blk_desc_sym rows: blocks with I <= J (plus pattern-only blocks I > J whose partner
-        (J,I) is absent), each carrying the output position of its transposed partner."""
-        full = self.descriptors()
-        I, J = self.blk_row.astype(np.int64), self.nbr.astype(np.int64)
-        key = I * self.n_nodes + J
-        tkey = J * self.n_nodes + I
-        pidx = np.searchsorted(key, tkey)
-        pidx_c = np.minimum(pidx, max(self.nblk - 1, 0))
-        has_partner = (key[pidx_c] == tkey) if self.nblk else np.zeros(0, dtype=bool)
-        keep = (I <= J) | ~has_partner
-        if np.any(~has_partner & (full["cnt"] > 0)):
-            raise ValueError("block with contributions but no transposed partner: connectivity is not symmetric")
-        sel = np.flatnonzero(keep)
-        out = np.zeros(sel.shape[0], dtype=BLK_DESC_SYM_DTYPE)
-        out["dst"], out["stride"], out["cnt"], out["c"] = full["dst"][sel], full["stride"][sel], full["cnt"][sel], full["c"][sel]
-        partner = pidx_c[sel]
-        off = (I[sel] < J[sel]) & has_partner[sel]
-        out["dst_t"] = np.where(off, full["dst"][partner], -1)
-        out["stride_t"] = np.where(off, full["stride"][partner], 0)
-        return out
-
     def row_nnz(self):
         """`_row_nnz` of the reference (core/assembler.py:241): int32 [n_nodes*d]."""
         m = np.diff(self.nbr_ptr)
@@ -296,9 +271,6 @@ class DeviceBlockPlan:
 
     def descriptors(self):
         return np.frombuffer(self.desc.cpu().numpy().tobytes(), dtype=BLK_DESC_DTYPE)
-
-    def sym_descriptors(self):
-        return self.host().sym_descriptors()
 
     def host_pattern(self):
         return self.host().host_pattern()

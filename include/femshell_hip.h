@@ -17,10 +17,14 @@
  */
 #ifndef FEMSHELL_HIP_H
 #define FEMSHELL_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
+#define FS_STATIC_ASSERT(cond, msg) static_assert(cond, msg)
 extern "C" {
+#else
+#define FS_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
 #endif
 
 #define FS_OK 0
@@ -54,8 +58,10 @@ extern "C" {
 #define FS_ST_NAN_FRAME 1   /* zero-area / zero-norm local frame (MITC4.py:436-476 silently NaNs) */
 #define FS_ST_BAD_COEFF 2   /* characteristic-vector solve failed (MITC4.py:186-193) */
 #define FS_ST_BAD_JAC 4     /* det J <= 0 at a Gauss point */
-#define FS_ST_BAD_PROP 8    /* prop_id outside [0, n_props) (row 0 was used instead), or a coupled property row in a
-                               call that declared the table free of them (fs_fused_assemble_quad) */
+#define FS_ST_BAD_PROP 8    /* prop_id outside [0, n_props): NO entry point ever indexes the table with it -- row 0 is
+                               used instead and the entry points that take a status array set this bit (those
+                               without one just compute with row 0); also: a coupled property row in a call that
+                               declared the table free of them (fs_fused_assemble_quad) */
 
 /* property-table flags */
 #define FS_PROP_COUPLED 1   /* add membrane-bending coupling (MITC4_composite.py:98-99,206-248) */
@@ -78,6 +84,10 @@ typedef struct fs_shell_prop {
     int32_t flags;    /* FS_PROP_*                    */
     int32_t nonlinear;
 } fs_shell_prop;      /* 368 bytes */
+FS_STATIC_ASSERT(sizeof(fs_shell_prop) == 368, "fs_shell_prop is 368 bytes");
+FS_STATIC_ASSERT(offsetof(fs_shell_prop, Cs) == 216 && offsetof(fs_shell_prop, h) == 248 &&
+                 offsetof(fs_shell_prop, C_raw) == 280 && offsetof(fs_shell_prop, rho) == 352 &&
+                 offsetof(fs_shell_prop, flags) == 360, "fs_shell_prop field offsets");
 
 const char *fs_last_error(void);
 /* library / device probe: returns FS_OK when a gfx950 device is usable; fills name (<=len). */
@@ -165,6 +175,29 @@ int fs_solid2_table(int32_t nn, double *pts, double *w, double *vals, int32_t *n
 int fs_shell_kg_batch(int32_t nn, const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
                       int32_t n_props, const double *sigma, int64_t E, uint32_t layout, double *KGe,
                       void *stream);
+
+/*
+ * Tangent stiffness with a GIVEN membrane stress: per element compute_tangent_stiffness(sigma=sigma)
+ * (MITC4.py:1246-1298, MITC3.py:1717-1777, composite overrides): K_T = T^T sym(K0 + K_L(u) + K_sigma(sigma)) T, where
+ * the default (sigma=None, FS_WANT_KT of fs_shell_quad_batch / _tri_batch) derives sigma from u.  Elements whose
+ * property row is not `nonlinear` return K (the reference ignores sigma there too).
+ *   nn 3 / 4;  xyz [E][nn][3];  u_e [E][6 nn];  sigma [E][3] = [sxx, syy, sxy] in the element's LOCAL axes
+ *   KTe     FS_LAYOUT_SYMBLK [E][nn(nn+1)/2][36];  status [E] FS_ST_* bits or NULL
+ */
+int fs_shell_kt_sigma_batch(int32_t nn, const double *xyz, const int32_t *prop_id, const fs_shell_prop *props,
+                            int32_t n_props, const double *u_e, const double *sigma, int64_t E, double *KTe,
+                            int32_t *status, void *stream);
+
+/*
+ * Local-axes views of global-axes element results: the transform_to_global=False outputs of
+ * compute_tangent_stiffness / compute_internal_forces / compute_geometric_stiffness (MITC4.py:1191-1341,
+ * MITC3.py:1501-1832): K_local = T K_global T^T, f_local = T f_global, T = blockdiag(e1; e2; e3) (MITC4.py:634-640,
+ * MITC3.py:471-492).  The frame is computed from `xyz` by the kernels' own geometry stage: pass the coordinates the
+ * reference's T() uses -- initial ones for quads, CURRENT ones for triangles.
+ *   K_global / K_local  FS_LAYOUT_DENSE [E][6 nn][6 nn] (either pair may be NULL);  f_global / f_local [E][6 nn]
+ */
+int fs_shell_rotate_local(int32_t nn, const double *xyz, int64_t E, const double *K_global, const double *f_global,
+                          double *K_local, double *f_local, void *stream);
 
 /*
  * Centrifugal prestress of every element (the `omega` mode of assemble_geometric_stiffness,
@@ -259,51 +292,26 @@ int fs_csr_numeric(const double *vals, const int64_t *src, const int64_t *seg_pt
 
 /*
  * Numeric CSR assembly, node-pair block form for meshes whose nodes all carry d dofs
- * (d = 6 shells, 3 solids) and whose element matrices are in FS_LAYOUT_SYMBLK.
- *   nbr_ptr [N+1]      node-graph row pointer (block rows)
- *   blk_row [nblk]     block-row (node I) of each node-pair block, blocks sorted by (I,J)
- *   blk_ptr [nblk+1]   contributions of each block
- *   contrib [ncontrib] (index of the d*d source block in `vals`) << 1 | transposed, sorted by
- *                      element index inside each block
- *   data               CSR values, rows = d*I+k, row-major, sorted columns:
- *                      data[d*d*nbr_ptr[I] + k*d*m_I + d*r + l], r = rank of J among I's neighbours
- */
-int fs_csr_numeric_blk(const double *vals, const int64_t *nbr_ptr, const int32_t *blk_row,
-                       const int64_t *blk_ptr, const int64_t *contrib, int64_t nblk, int32_t d,
-                       double *data, void *stream);
-
-/* Descriptor form of fs_csr_numeric_blk (same result, same summation order; shorter dependent
- * load chain).  One descriptor per node-pair block, blocks in any order:
- *   dst     index in `data` of entry (k=0,l=0) of the block
- *   stride  distance between consecutive rows k of the block in `data` (= d * m_I)
+ * (d = 6 shells, 3 solids) and whose element matrices are in FS_LAYOUT_SYMBLK / _T16.  Same replacement as
+ * fs_csr_numeric (core/assembler.py:287-336).  One descriptor per node-pair block (I,J), blocks in any order:
+ *   dst     index in `data` of entry (k=0,l=0) of the block: data is CSR with rows = d*I+k, row-major, sorted
+ *           columns, so dst = d*d*nbr_ptr[I] + d*r with r = rank of J among I's neighbours
+ *   stride  distance between consecutive rows k of the block in `data` (= d * m_I, m_I = neighbours of I)
  *   cnt     number of contributions; cnt <= 4: c[0..cnt) hold them inline
- *           ((source block index << 1) | transposed, element order); cnt > 4: c[0] is the offset
- *           of the cnt contributions in `contrib`. */
+ *           ((index of the d*d source block in `vals` << 1) | transposed, element order); cnt > 4: c[0] is the
+ *           offset of the cnt contributions in `contrib` (same encoding, sorted by element index)
+ * The sum runs in element order (== the reference's ADD_VALUES insertion order); blocks with fewer than 4
+ * contributions add +0.0 for the missing ones. */
 typedef struct fs_blk_desc {
     int64_t dst;
     int32_t stride;
     int32_t cnt;
     int64_t c[4];
 } fs_blk_desc; /* 48 bytes */
+FS_STATIC_ASSERT(sizeof(fs_blk_desc) == 48 && offsetof(fs_blk_desc, stride) == 8 && offsetof(fs_blk_desc, c) == 16,
+                 "fs_blk_desc layout (the d = 6 assembly kernel reads it as 3 x 16 bytes)");
 int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64_t *contrib,
                         int64_t nblk, int32_t d, double *data, void *stream);
-
-/* Symmetric form of fs_csr_numeric_desc (same result bit for bit): one descriptor per node-pair
- * block with I <= J; the summed block goes to (I,J) at dst/stride and, transposed, to (J,I) at
- * dst_t/stride_t (dst_t = -1: no transposed copy -- diagonal blocks, and pattern-only blocks whose
- * partner is absent).  K, M, K_T, K_G element matrices are symmetric by construction
- * (FS_LAYOUT_SYMBLK stores i <= j only), so each source block is read once. */
-typedef struct fs_blk_desc_sym {
-    int64_t dst;
-    int64_t dst_t;
-    int32_t stride;
-    int32_t stride_t;
-    int32_t cnt;
-    int32_t pad_;
-    int64_t c[4];
-} fs_blk_desc_sym; /* 64 bytes */
-int fs_csr_numeric_sym(const double *vals, const fs_blk_desc_sym *desc, const int64_t *contrib,
-                       int64_t ndesc, int32_t d, double *data, void *stream);
 
 /*
  * Fused evaluate-and-assemble for uniform MITC4+ quad meshes, gather form: the CSR values of K straight from the
@@ -348,6 +356,8 @@ typedef struct fs_fused_rec {
     uint32_t flags;
     uint32_t slots;
 } fs_fused_rec; /* 64 bytes */
+FS_STATIC_ASSERT(sizeof(fs_fused_rec) == 64 && offsetof(fs_fused_rec, stride) == 32 && offsetof(fs_fused_rec, ev) == 48 &&
+                 offsetof(fs_fused_rec, flags) == 56, "fs_fused_rec layout");
 #define FS_FL_CHAIN 1u
 #define FS_FL_OUT0 2u
 #define FS_FL_OUT1 4u
@@ -360,9 +370,10 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
                            const int64_t *pat_rptr, const fs_fused_rec *recs, int32_t max_patch_elems,
                            uint32_t flags, double *data, int32_t *status, void *stream);
 
-/* Symbolic companion of fs_csr_numeric_blk (pattern of core/assembler.py:222-241 for uniform-d
- * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph.
- * nbr[nblk] = neighbour node J of each block. */
+/* Symbolic companion of fs_csr_numeric_desc (pattern of core/assembler.py:222-241 for uniform-d
+ * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph:
+ *   nbr_ptr [N+1] row pointer of the node graph (block rows), blk_row [nblk] node I and nbr [nblk] node J of
+ *   every node-pair block, blocks sorted by (I,J). */
 int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int32_t *nbr,
                        int64_t n_nodes, int64_t nblk, int32_t d, int64_t *indptr,
                        int32_t *indices, void *stream);
@@ -386,7 +397,8 @@ int fs_csr_pattern_blk(const int64_t *nbr_ptr, const int32_t *blk_row, const int
  *              run), or NULL
  *   nblk, ncontrib (host, out): number of node-pair blocks / of contributions
  * fs_csr_symbolic_finish (consumes the handle): nbr_ptr [n_nodes+1], nbr [nblk], blk_row [nblk],
- *   blk_ptr [nblk+1], contrib [ncontrib] as documented at fs_csr_numeric_blk; desc [nblk] (may be NULL)
+ *   as documented at fs_csr_pattern_blk; blk_ptr [nblk+1] = range of each block's contributions in contrib
+ *   [ncontrib] ((source block index << 1) | transposed, element order inside a block); desc [nblk] (may be NULL)
  *   as documented at fs_blk_desc for d dofs per node.
  * fs_csr_symbolic_free: drop a handle without finishing.
  */

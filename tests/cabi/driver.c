@@ -119,6 +119,40 @@ int main(int argc, char **argv) {
                             NULL, NULL, s) != FS_EINVAL)
         return 6;
 
+    if (fs_csr_numeric_desc(NULL, d_desc, d_contrib, nblk, 6, d_K, s) != FS_EINVAL || !strstr(fs_last_error(), "null") ||
+        fs_halo_pack(NULL, NULL, 5, NULL, s) != FS_EINVAL || fs_blk_expand(NULL, FS_LAYOUT_SYMBLK, E, 4, 6, NULL, s) != FS_EINVAL ||
+        fs_csr_pattern_blk(NULL, d_blk_row, d_nbr, N, nblk, 6, d_indptr, d_indices, s) != FS_EINVAL ||
+        fs_shell_quad_geom(NULL, E, NULL, NULL, NULL, NULL, s) != FS_EINVAL)
+        return 6;
+    /* property ids outside the table: never an out-of-bounds read -- row 0 is used and FS_ST_BAD_PROP is reported */
+    if (E >= 3) {
+        int32_t *bad = malloc((size_t)E * 4), *st = malloc((size_t)E * 4);
+        double *k_ref = malloc(3 * 2880), *k_bad = malloc(3 * 2880);
+        void *d_bad, *d_st2, *d_K2;
+        memcpy(bad, pid, (size_t)E * 4);
+        bad[1] = (int32_t)P + 1000000;
+        bad[2] = -7;
+        const int32_t zero_id[3] = {pid[0], 0, 0};      /* what the library must have used instead */
+        void *d_zero;
+        if (to_dev(&d_bad, bad, (size_t)E * 4) || to_dev(&d_st2, NULL, (size_t)E * 4) || to_dev(&d_zero, zero_id, 12) ||
+            to_dev(&d_K2, NULL, (size_t)E * 2880))
+            return 2;
+        FSCHK(fs_shell_quad_batch(d_xyz, d_bad, d_props, (int32_t)P, NULL, E, FS_WANT_K, FS_LAYOUT_SYMBLK, d_K2, NULL,
+                                  NULL, NULL, d_st2, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(st, d_st2, (size_t)E * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(k_bad, d_K2, 3 * 2880, hipMemcpyDeviceToHost));
+        FSCHK(fs_shell_quad_batch(d_xyz, d_zero, d_props, (int32_t)P, NULL, 3, FS_WANT_K, FS_LAYOUT_SYMBLK, d_K2, NULL,
+                                  NULL, NULL, NULL, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(k_ref, d_K2, 3 * 2880, hipMemcpyDeviceToHost));
+        if (!(st[1] & FS_ST_BAD_PROP) || !(st[2] & FS_ST_BAD_PROP) || (st[0] & FS_ST_BAD_PROP) ||
+            memcmp(k_ref, k_bad, 3 * 2880) != 0)
+            return 7;
+        for (int64_t e = 3; e < E; e++)
+            if (st[e] & FS_ST_BAD_PROP) return 7;
+    }
+
     FILE *out = fopen(argv[2], "wb");
     if (!out) return 1;
     int64_t oh[3] = {nblk, nnz, ndof};

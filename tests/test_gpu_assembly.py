@@ -51,12 +51,9 @@ def test_assembled_K_M(case, oracle):
     a = asm.assemble_stiffness_matrix(recompute=True).data.clone()
     b = asm.assemble_stiffness_matrix(recompute=True).data
     assert bool((a == b).all())
-    # the three numeric kernels (symmetric read-once, descriptor, block) agree bit for bit
-    asm.use_symmetric = False
-    c = asm.assemble_stiffness_matrix().data.clone()
-    asm.use_descriptors = False
-    d = asm.assemble_stiffness_matrix().data
-    assert bool((a == c).all()) and bool((a == d).all())
+    # the cached-blocks route (element kernel ran earlier, assembly kernel alone) gives the same bits
+    c = asm.assemble_stiffness_matrix().data
+    assert bool((a == c).all())
 
 
 def test_element_classes_match_batch(oracle):

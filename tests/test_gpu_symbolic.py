@@ -17,7 +17,6 @@ def _same(dp, hp):
         assert a.dtype == b.dtype and np.array_equal(a, b), k
     assert np.array_equal(dp.descriptors(), hp.descriptors())
     assert np.array_equal(dp.row_nnz(), hp.row_nnz())
-    assert np.array_equal(dp.sym_descriptors(), hp.sym_descriptors())
 
 
 @pytest.mark.parametrize("case", ["quads", "quads_t16", "tris", "mixed", "hexa", "extra", "shuffled"])

@@ -18,7 +18,7 @@ T300 = dict(E=(181e9, 10.3e9, 10.3e9), G=(7.17e9, 3.0e9, 7.17e9), nu=(0.28, 0.28
 def test_header_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "femshell_hip.h")).read()
     names = set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", hdr))
-    assert {"fs_shell_quad_batch", "fs_csr_numeric_blk", "fs_csr_numeric", "fs_last_error"} <= names
+    assert {"fs_shell_quad_batch", "fs_csr_numeric_desc", "fs_fused_assemble_quad", "fs_csr_numeric", "fs_last_error"} <= names
     lib = ctypes.CDLL(os.path.join(ROOT, "fem_shell_amd", "csrc", "libfemshell_hip.so"))
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/femshell_hip.h but not exported"
@@ -102,7 +102,7 @@ def test_block_plan_matches_oracle_pattern(oracle, tri):
     for b in range(0, plan.nblk, 17):
         c = plan.contrib[plan.blk_ptr[b]:plan.blk_ptr[b + 1]] >> 1
         assert (np.diff(c // 10) > 0).all()
-    # numeric emulation of fs_csr_numeric_blk on the host == oracle element-order sum
+    # numeric emulation of fs_csr_numeric_desc on the host == oracle element-order sum
     vals = rng.standard_normal((conn.shape[0], 24, 24))
     vals = vals + vals.transpose(0, 2, 1)
     _, _, data = oracle.csr_assemble(dofs, mesh.node_count * 6, vals)
@@ -187,23 +187,6 @@ def test_mixed_group_plan_matches_set_union(oracle):
     assert np.array_equal(hp, ip) and np.array_equal(hx, ix)
     got = util.host_block_assemble(plan, packed)
     assert np.array_equal(got, data)      # same summation order -> bitwise equal
-
-
-def test_sym_descriptors_cover_every_block_once():
-    """fs_blk_desc_sym rows: every block is written exactly once, either directly or as the
-    transposed partner; pattern-only ghost blocks without a partner stay own descriptors."""
-    from fem_shell_amd import meshes, symbolic
-    conn = meshes.mixed_conn(6, 5)
-    n_nodes = 7 * 6
-    extra = np.array([[0, 40], [3, 41]])                       # ghost columns, no partner rows
-    plan = symbolic.BlockPlan(conn, n_nodes, 6, extra_pairs=extra)
-    full, sym = plan.descriptors(), plan.sym_descriptors()
-    written = np.concatenate([sym["dst"], sym["dst_t"][sym["dst_t"] >= 0]])
-    assert np.array_equal(np.sort(written), np.sort(full["dst"]))
-    assert sym.shape[0] < full.shape[0]
-    t = sym["dst_t"] >= 0
-    lookup = {int(d): int(s) for d, s in zip(full["dst"], full["stride"])}
-    assert all(lookup[int(d)] == int(st) for d, st in zip(sym["dst_t"][t], sym["stride_t"][t]))
 
 
 def test_csr_matrix_exports(monkeypatch):

@@ -334,6 +334,50 @@ def gen_elem_nl3():
     print("elem_nl3.npz", N)
 
 
+def gen_elem_nl_local():
+    """The sigma= and transform_to_global=False outputs of the shell elements' nonlinear methods (MITC4.py:1191-1341,
+    MITC3.py:1501-1832, composite overrides): K_T with a given membrane stress, and the local-axes K_T, f_int, K_sigma."""
+    from fem_shell.elements import MITC3, MITC3Composite
+    out = {}
+    for tag, nn, gen, seed, cls_iso, cls_lam in (("q", 4, quads, 21, MITC4, MITC4Composite),
+                                                 ("t", 3, tris, 23, MITC3, MITC3Composite)):
+        rng = np.random.default_rng(seed)
+        N = 16
+        xyz = gen(N + 7, rng)[7:]
+        rows, U, SG = [], [], []
+        res = {k: [] for k in ("KT_sigma", "KT_sigma_local", "KT_local", "f_local", "KG_local", "KG")}
+        for i in range(N):
+            size = np.linalg.norm(xyz[i, 1] - xyz[i, 0])
+            nl = (i % 4) != 3
+            if i % 2 == 0:
+                E, nu, rho = ISO[i % len(ISO)]
+                el = cls_iso(xyz[i], tuple(range(nn)), IsotropicMaterial("m", E, nu, rho), 0.05 * size, nonlinear=nl)
+                lam = None
+            else:
+                ang, t = LAYUPS[(i // 2) % len(LAYUPS)]
+                lam = create_laminate_from_angles(t300(), t * size, ang)
+                el = cls_lam(xyz[i], tuple(range(nn)), lam, nonlinear=nl)
+            u = rng.standard_normal(6 * nn) * (1e-3 if i % 3 else 2e-2) * size
+            u[3::6] /= size; u[4::6] /= size; u[5::6] /= size
+            el.update_configuration(u)
+            row = ref_prop_row(el, lam)
+            sg = rng.standard_normal(3) * float(np.abs(row["C_raw"]).max()) * 1e-3
+            rows.append(row); U.append(u); SG.append(sg)
+            res["KT_sigma"].append(el.compute_tangent_stiffness(sigma=sg))
+            res["KT_sigma_local"].append(el.compute_tangent_stiffness(sigma=sg, transform_to_global=False))
+            res["KT_local"].append(el.compute_tangent_stiffness(transform_to_global=False))
+            res["f_local"].append(el.compute_internal_forces(transform_to_global=False))
+            res["KG"].append(el.compute_geometric_stiffness(sg))
+            res["KG_local"].append(el.compute_geometric_stiffness(sg, transform_to_global=False))
+        out[tag + "_xyz"], out[tag + "_u"], out[tag + "_sigma"] = xyz, np.array(U), np.array(SG)
+        for k, v in res.items():
+            out[f"{tag}_{k}"] = np.array(v)
+        for k in rows[0]:
+            out[f"{tag}_prop_{k}"] = np.array([r[k] for r in rows])
+    np.savez_compressed(os.path.join(OUT, "elem_nl_local.npz"), **out)
+    print("elem_nl_local.npz", {k: v.shape for k, v in out.items() if "KT" in k})
+
+
 def gen_prestress():
     """compute_geometric_stiffness(sigma) of MITC4 / MITC3 (+ composites) (MITC4.py:1191-1225,
     MITC3.py:1501-1580) and compute_centrifugal_prestress of MITC3 (MITC3.py:1633-1715) and of the
@@ -471,6 +515,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ALL = dict(elem_mitc4=gen_elem_mitc4, elem_nl=gen_elem_nl, elem_mitc3=gen_elem_mitc3,
                elem_solid=gen_elem_solid, laminate=gen_laminate, scordelis=lambda: gen_scordelis(16),
-               elem_nl3=gen_elem_nl3, prestress=gen_prestress, elem_solid2=gen_elem_solid2)
+               elem_nl3=gen_elem_nl3, prestress=gen_prestress, elem_solid2=gen_elem_solid2,
+               elem_nl_local=gen_elem_nl_local)
     for name in (sys.argv[1:] or list(ALL)):      # python tools/gen_golden.py [fixture ...]
         ALL[name]()
