@@ -68,18 +68,47 @@ def _exchange(send: Dict[int, np.ndarray], peers, dtype=torch.int64):
     return {p: rbuf[p].cpu().numpy() for p in rbuf}
 
 
-def local_block(mesh, rank, world):
-    """Element-block partition of any ArrayMesh: rank r takes the r-th contiguous block of the mesh's
-    element order (structured meshes: strips; unstructured: blocks of whatever locality-preserving order the mesh
-    was numbered in, e.g. the reference's RCM ordering, core/mesh/model.py:229-321).  Returns (local ArrayMesh over
-    the nodes its elements touch, l2g = their global node indices) -- the inputs of DistributedAssembler."""
+def rcm_element_order(conn, n_nodes):
+    """Element order of the reference's RCM renumbering (core/mesh/model.py:229-321): reverse Cuthill-McKee on the
+    node graph (two nodes are adjacent when an element holds both; SciPy's reverse_cuthill_mckee, symmetric mode, as
+    the reference calls it), then the elements sorted -- stably -- by the smallest new index among their nodes.
+    Returns (element permutation, new index of every node).  Integer bookkeeping on the host."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    conn = np.asarray(conn, dtype=np.int64)
+    nn = conn.shape[1]
+    valid = conn >= 0
+    rows = np.repeat(conn, nn, axis=1).reshape(-1)
+    cols = np.tile(conn, (1, nn)).reshape(-1)
+    ok = (np.repeat(valid, nn, axis=1) & np.tile(valid, (1, nn))).reshape(-1) & (rows != cols)
+    adj = csr_matrix((np.ones(int(ok.sum()), dtype=np.int8), (rows[ok], cols[ok])), shape=(n_nodes, n_nodes))
+    perm = reverse_cuthill_mckee(adj, symmetric_mode=True)
+    new_of_old = np.empty(n_nodes, dtype=np.int64)
+    new_of_old[perm] = np.arange(n_nodes)
+    key = np.where(valid, new_of_old[np.where(valid, conn, 0)], n_nodes).min(axis=1)
+    return np.argsort(key, kind="stable"), new_of_old
+
+
+def local_block(mesh, rank, world, order=None):
+    """Element-block partition of any ArrayMesh: rank r takes the r-th contiguous block of an element
+    order: the mesh's own (order=None: strips of a structured mesh, or whatever locality-preserving order the mesh was
+    numbered in), the reference's RCM order (order="rcm": rcm_element_order, core/mesh/model.py:229-321 -- the
+    interface of an arbitrarily numbered mesh then has the size of a bandwidth front instead of whatever the input order
+    gives), or an explicit element permutation.  Returns (local ArrayMesh over the nodes its elements touch, l2g =
+    their global node indices) -- the inputs of DistributedAssembler.  Every rank must pass the same `order`."""
     from .meshes import ArrayMesh
     E = mesh.conn.shape[0]
     lo, hi = (E * rank) // world, (E * (rank + 1)) // world
-    conn = mesh.conn[lo:hi]
+    if order is None:
+        sel = slice(lo, hi)
+    else:
+        perm = rcm_element_order(mesh.conn, mesh.coords.shape[0])[0] if isinstance(order, str) and order == "rcm" \
+            else np.asarray(order, dtype=np.int64)
+        sel = np.sort(perm[lo:hi])            # inside a block the elements keep their global order (summation order)
+    conn = mesh.conn[sel]
     l2g = np.unique(conn[conn >= 0])
     loc = np.where(conn >= 0, np.searchsorted(l2g, np.where(conn >= 0, conn, l2g[0])), -1)
-    set_id = None if getattr(mesh, "set_id", None) is None else mesh.set_id[lo:hi]
+    set_id = None if getattr(mesh, "set_id", None) is None else mesh.set_id[sel]
     return ArrayMesh(mesh.coords[l2g], loc, set_id, getattr(mesh, "set_names", None)), l2g
 
 

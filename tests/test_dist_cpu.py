@@ -175,3 +175,100 @@ def test_distributed_plan_two_by_two_quadrants(use_coords):
     for rank, n, err in res:
         assert err is None, err
     assert sum(n for _, n, _ in res) == 6 * 49
+
+
+def test_rcm_element_order_cuts_the_interface():
+    """dist.local_block(order="rcm"): the reference's RCM renumbering (core/mesh/model.py:229-321) as the partition
+    order.  On a plate whose elements are numbered at random, contiguous blocks of the input order share almost every
+    node with every other block; blocks of the RCM order share a front."""
+    from fem_shell_amd import meshes
+    from fem_shell_amd.dist import local_block, rcm_element_order
+    g = meshes.jittered_plate(40, 30, n_sets=1)
+    rng = np.random.default_rng(0)
+    shuffled = meshes.ArrayMesh(g.coords, g.conn[rng.permutation(g.conn.shape[0])])
+    perm, new_of_old = rcm_element_order(shuffled.conn, shuffled.coords.shape[0])
+    assert np.array_equal(np.sort(perm), np.arange(shuffled.conn.shape[0]))
+    assert np.array_equal(np.sort(new_of_old), np.arange(shuffled.coords.shape[0]))
+    key = new_of_old[shuffled.conn].min(axis=1)[perm]
+    assert (np.diff(key) >= 0).all()                      # elements follow their smallest new node index
+
+    def shared_nodes(order):
+        parts = [local_block(shuffled, r, 4, order=order)[1] for r in range(4)]
+        allc = np.concatenate(parts)
+        return allc.shape[0] - np.unique(allc).shape[0], parts
+    n_in, _ = shared_nodes(None)
+    n_rcm, parts = shared_nodes("rcm")
+    print("nodes held by more than one rank: input order", n_in, "RCM order", n_rcm)
+    assert n_rcm * 8 < n_in and n_rcm < 4 * 3 * 45        # a few fronts of about one mesh line each
+    # every element lands in exactly one block, with its connectivity intact
+    tot = 0
+    for r in range(4):
+        loc, l2g = local_block(shuffled, r, 4, order="rcm")
+        tot += loc.conn.shape[0]
+        assert np.array_equal(np.sort(l2g), l2g)
+    assert tot == shuffled.conn.shape[0]
+
+
+def _worker_rcm(rank, world, port, q):
+    """Randomly numbered plate cut into RCM blocks: plan + exchange reproduce the serial assembly on owned rows."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fem_shell_amd as fsa
+        from fem_shell_amd import meshes
+        from fem_shell_amd.dist import DistributedPlan, local_block, rcm_element_order
+        from fem_shell_amd.symbolic import BlockPlan
+        from oracle import oracle as O
+        from tests import util
+        props = fsa.build_prop_table(util.standard_props())
+        g0 = meshes.jittered_plate(9, 7, n_sets=8)
+        perm0 = np.random.default_rng(4).permutation(g0.conn.shape[0])
+        g = meshes.ArrayMesh(g0.coords, g0.conn[perm0], g0.set_id[perm0], g0.set_names)
+        gpid = g.set_id.astype(np.int32)
+        Kg, _ = O.mitc4_K_batch(g.coords[g.conn], gpid, props)
+        gplan = BlockPlan(g.conn, g.node_count, 6)
+        gdata = util.host_block_assemble(gplan, util.pack_symblk(Kg))
+        gip, gix = gplan.host_pattern()
+        loc, l2g = local_block(g, rank, world, order="rcm")
+        perm = rcm_element_order(g.conn, g.node_count)[0]
+        E = g.conn.shape[0]
+        eg = np.sort(perm[(E * rank) // world:(E * (rank + 1)) // world])
+        assert np.array_equal(l2g[loc.conn], g.conn[eg])
+        dp = DistributedPlan(loc.conn, l2g, 6, coords=loc.coords)
+        Kl, _ = O.mitc4_K_batch(loc.coords[loc.conn], gpid[eg], props)
+        data = util.host_block_assemble(dp.plan, util.pack_symblk(Kl, tiled=dp.plan.tiled))
+        data = dp.exchange_host(data)
+        ip, ix = dp.plan.host_pattern()
+        X = dp.nodes_g
+        nchk = 0
+        for I in np.flatnonzero(dp.owned):
+            for k in range(6):
+                r, gr = 6 * I + k, 6 * X[I] + k
+                cols = 6 * X[ix[ip[r]:ip[r + 1]] // 6] + ix[ip[r]:ip[r + 1]] % 6
+                assert np.array_equal(cols, gix[gip[gr]:gip[gr + 1]]), (rank, I, k)
+                # interface rows sum the ranks' partial sums: same terms, another association -- tolerance, not bits
+                assert np.abs(data[ip[r]:ip[r + 1]] - gdata[gip[gr]:gip[gr + 1]]).max() <= 1e-13 * np.abs(gdata).max()
+                nchk += 1
+        q.put((rank, nchk, None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_plan_on_rcm_blocks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rcm, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 6 * 80
