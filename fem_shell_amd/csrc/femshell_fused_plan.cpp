@@ -1,0 +1,336 @@
+// femshell_fused_plan.cpp -- host side of fs_fused_assemble_quad: the per-mesh patch plan (include/femshell_hip.h,
+// "Fused evaluate-and-assemble").  Integer bookkeeping only: which elements a patch of nodes touches, which CSR
+// node-pair blocks it produces, which (element, local node pair) contributions every block is made of, in ELEMENT
+// ORDER (the reference's ADD_VALUES insertion order, core/assembler.py:295-300), and on which lane each contribution
+// is evaluated.  Host arrays in, host arrays out; the caller uploads them.  OpenMP over patches.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "femshell_hip.h"
+#include "femshell_internal.h"
+
+struct fs_fused_plan {
+    std::vector<int64_t> pat_eptr, pat_rptr;
+    std::vector<int32_t> pat_elems;
+    std::vector<fs_fused_rec> recs;
+    int64_t n_evals = 0;
+};
+
+namespace {
+
+struct Mesh {
+    const int64_t *conn;
+    int64_t E, N;
+    const int64_t *nbr_ptr;
+    const int32_t *nbr;
+    std::vector<int64_t> n2e_ptr;
+    std::vector<int32_t> n2e;   // elements of every node, ascending
+};
+
+struct Task {          // one CSR block (I, J) produced by a patch
+    int64_t I, J;
+    int64_t dst, dst_t;
+    int32_t stride, stride_t;
+    int n;             // contributions
+    uint32_t ev[32];   // slot | ti << 8 | tj << 10 | transposed << 12
+};
+
+// position of `key` in the sorted range [b, e) or -1
+inline int64_t find_sorted(const int32_t *b, const int32_t *e, int32_t key) {
+    const int32_t *p = std::lower_bound(b, e, key);
+    return (p != e && *p == key) ? (p - b) : -1;
+}
+
+// Enumerates the tasks of one patch in (I, J) order, i.e. in ascending dst.  Returns 0, or a negative code:
+// -1 a block has more than 32 contributions, -2 a contribution's element is missing from the patch list,
+// -3 a block with contributions has no transposed partner (connectivity not symmetric).
+template <class F>
+int patch_tasks(const Mesh &m, const int64_t *nodes, int64_t n_nodes, const int32_t *elems, int ne, F &&emit) {
+    Task t;
+    for (int64_t q = 0; q < n_nodes; q++) {
+        const int64_t I = nodes[q];
+        const int64_t r0 = m.nbr_ptr[I], r1 = m.nbr_ptr[I + 1];
+        const int32_t mI = (int32_t)(r1 - r0);
+        const int32_t *eI = m.n2e.data() + m.n2e_ptr[I], *eIe = m.n2e.data() + m.n2e_ptr[I + 1];
+        for (int64_t b = r0; b < r1; b++) {
+            const int64_t J = m.nbr[b];
+            const int32_t *rowJ = m.nbr + m.nbr_ptr[J], *rowJe = m.nbr + m.nbr_ptr[J + 1];
+            const int64_t posI = find_sorted(rowJ, rowJe, (int32_t)I);
+            const bool partner = posI >= 0;
+            if (I > J && partner) continue;            // written as the transposed copy of (J, I) by J's patch
+            t.I = I; t.J = J;
+            t.dst = 36 * r0 + 6 * (b - r0);
+            t.stride = 6 * mI;
+            t.dst_t = (I < J && partner) ? 36 * m.nbr_ptr[J] + 6 * posI : -1;
+            t.stride_t = 6 * (int32_t)(rowJe - rowJ);
+            t.n = 0;
+            // elements holding both I and J, ascending
+            const int32_t *eJ = m.n2e.data() + m.n2e_ptr[J], *eJe = m.n2e.data() + m.n2e_ptr[J + 1];
+            const int32_t *a = eI, *c = eJ;
+            while (a != eIe && c != eJe) {
+                if (*a < *c) a++;
+                else if (*c < *a) c++;
+                else {
+                    const int32_t e = *a;
+                    const int64_t *cn = m.conn + (int64_t)e * 4;
+                    int li = -1, lj = -1;
+                    for (int k = 0; k < 4; k++) { if (cn[k] == I && li < 0) li = k; if (cn[k] == J && lj < 0) lj = k; }
+                    const int64_t slot = find_sorted(elems, elems + ne, e);
+                    if (slot < 0) return -2;
+                    if (t.n >= 32) return -1;
+                    const int ti = li < lj ? li : lj, tj = li < lj ? lj : li;
+                    t.ev[t.n++] = (uint32_t)slot | ((uint32_t)ti << 8) | ((uint32_t)tj << 10) | ((li > lj ? 1u : 0u) << 12);
+                    a++; c++;
+                }
+            }
+            if (t.n > 0 && !partner) return -3;
+            emit(t);
+        }
+    }
+    return 0;
+}
+
+typedef Task TaskRec;
+
+// Layout of one patch in the record format of include/femshell_hip.h (two contributions per lane).  `tasks` arrive in
+// (I, J) order.  Returns the number of lanes (a multiple of 64); with rec != nullptr also fills the records, which
+// start at global lane index `base` (a multiple of 64: waves are numbered globally).
+int64_t layout_patch(std::vector<TaskRec> &tasks, fs_fused_rec *rec, std::vector<int> &scratch) {
+    const int nt = (int)tasks.size();
+    // leading nodes in ascending order -> normal groups of 12 nodes; long tasks (n > 4) -> extra groups, 4 per group
+    std::vector<int> &grp = scratch;
+    grp.assign(nt, 0);
+    int nlead = 0, nlong = 0;
+    {
+        int64_t prev = -1;
+        for (int t = 0; t < nt; t++) {
+            if (tasks[t].I != prev) { prev = tasks[t].I; nlead++; }
+            grp[t] = (nlead - 1) / 12;
+        }
+    }
+    const int gnorm = (nlead + 11) / 12;
+    for (int t = 0; t < nt; t++)
+        if (tasks[t].n > 4) { grp[t] = gnorm + nlong / 4; nlong++; }
+    const int ngroups = gnorm + (nlong + 3) / 4;
+    // order inside a group: long rows (already in (I, J) order), then 2-lane tasks, 1-lane tasks, half-lane tasks
+    auto hw_of = [](int n) { return n > 4 ? 32 : n >= 3 ? 4 : n == 2 ? 2 : 1; };
+    auto cls_of = [](int n) { return n > 4 ? 0 : n >= 3 ? 1 : n == 2 ? 2 : 3; };
+    std::vector<int> ord(nt);
+    for (int t = 0; t < nt; t++) ord[t] = t;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+        if (grp[a] != grp[b]) return grp[a] < grp[b];
+        return cls_of(tasks[a].n) < cls_of(tasks[b].n);
+    });
+    // half-lane position of every task
+    std::vector<int64_t> hbase(nt);
+    int64_t lanes = 0;
+    {
+        int i = 0;
+        for (int gidx = 0; gidx < ngroups; gidx++) {
+            int64_t half = 0;
+            for (; i < nt && grp[ord[i]] == gidx; i++) { hbase[ord[i]] = 2 * lanes + half; half += hw_of(tasks[ord[i]].n); }
+            lanes += ((half + 1) / 2 + 63) / 64 * 64;
+        }
+    }
+    if (!rec) return lanes;
+    struct Out { int64_t addr; int lane; int kind; int which; };
+    std::vector<Out> outs;
+    outs.reserve(2 * nt);
+    std::vector<uint32_t> mc(lanes / 64, 1u);
+    for (int t = 0; t < nt; t++) {
+        const TaskRec &k = tasks[t];
+        const int hw = hw_of(k.n);
+        const int64_t hb = hbase[t], lane0 = hb >> 1;
+        for (int c = 0; c < k.n; c++) rec[(hb + c) >> 1].ev[(hb + c) & 1] = k.ev[c] | (1u << 13);
+        const int nl = hw >= 2 ? ((k.n > 1 ? k.n : 1) + 1) / 2 : 1;
+        const int64_t last = lane0 + nl - 1;
+        const bool half_task = hw == 1;
+        const int which = half_task ? (int)(hb & 1) : 0;
+        rec[last].dst[which] = k.dst; rec[last].stride[which] = k.stride;
+        rec[last].dst_t[which] = k.dst_t; rec[last].stride_t[which] = k.dst_t >= 0 ? k.stride_t : 0;
+        rec[last].flags |= which == 0 ? FS_FL_OUT0 : FS_FL_OUT1;
+        if (half_task || k.n < 4) rec[last].flags |= FS_FL_PAD;
+        if (k.n > 4) rec[lane0].flags |= FS_FL_ZERO_START;
+        for (int c = 1; c < nl; c++) rec[lane0 + c].flags |= FS_FL_CHAIN | ((uint32_t)c << 16);
+        if ((uint32_t)nl > mc[lane0 >> 6]) mc[lane0 >> 6] = (uint32_t)nl;
+        outs.push_back({k.dst, (int)last, 0, which});
+        if (k.dst_t >= 0) outs.push_back({k.dst_t, (int)last, 1, which});
+    }
+    for (int64_t l = 0; l < lanes; l++) rec[l].flags |= mc[l >> 6] << 8;
+    // staging slots: the blocks a wave stores, numbered by (class, address)
+    std::sort(outs.begin(), outs.end(), [](const Out &a, const Out &b) {
+        const int wa = a.lane >> 6, wb = b.lane >> 6;
+        if (wa != wb) return wa < wb;
+        const int ca = a.which == 1 ? 2 : a.kind, cb = b.which == 1 ? 2 : b.kind;
+        if (ca != cb) return ca < cb;
+        return a.addr < b.addr;
+    });
+    int rank = 0;
+    for (size_t i = 0; i < outs.size(); i++) {
+        rank = (i > 0 && (outs[i].lane >> 6) == (outs[i - 1].lane >> 6)) ? rank + 1 : 0;
+        if (rank > 254) return -1;
+        const uint32_t shift = 8u * (2u * (uint32_t)outs[i].which + (uint32_t)outs[i].kind);
+        uint32_t &sl = rec[outs[i].lane].slots;
+        sl = (sl & ~(255u << shift)) | ((uint32_t)rank << shift);
+    }
+    return lanes;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                        const int64_t *node_patch, int32_t max_patch_elems, fs_fused_plan **plan, int64_t *n_patches,
+                        int64_t *n_elem_slots, int64_t *n_recs) {
+    if (!conn || !nbr_ptr || !nbr || !node_patch || !plan || !n_patches || !n_elem_slots || !n_recs)
+        return fs_fail_(FS_EINVAL, "fs_fused_plan_build: null argument", 0);
+    if (E < 0 || n_nodes <= 0 || E > INT32_MAX) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: bad sizes", 0);
+    if (max_patch_elems < 16 || max_patch_elems > FS_FUSED_MAX_PATCH_ELEMS)
+        return fs_fail_(FS_EINVAL, "fs_fused_plan_build: max_patch_elems must lie in [16, FS_FUSED_MAX_PATCH_ELEMS]", 0);
+    for (int64_t i = 0; i < E * 4; i++)
+        if (conn[i] < 0 || conn[i] >= n_nodes) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: connectivity out of range", 0);
+    fs_fused_plan *P = new (std::nothrow) fs_fused_plan;
+    if (!P) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: out of memory", 0);
+    try {
+        Mesh m{conn, E, n_nodes, nbr_ptr, nbr, {}, {}};
+        // node -> elements (element order)
+        m.n2e_ptr.assign(n_nodes + 1, 0);
+        for (int64_t i = 0; i < E * 4; i++) m.n2e_ptr[conn[i] + 1]++;
+        for (int64_t i = 0; i < n_nodes; i++) m.n2e_ptr[i + 1] += m.n2e_ptr[i];
+        m.n2e.resize(E * 4);
+        {
+            std::vector<int64_t> fill(m.n2e_ptr.begin(), m.n2e_ptr.end() - 1);
+            for (int64_t e = 0; e < E; e++)
+                for (int k = 0; k < 4; k++) {
+                    const int64_t nd = conn[e * 4 + k];
+                    // a node listed twice by one element counts once
+                    if (fill[nd] > m.n2e_ptr[nd] && m.n2e[fill[nd] - 1] == (int32_t)e) continue;
+                    m.n2e[fill[nd]++] = (int32_t)e;
+                }
+            // compact (duplicates skipped above leave holes at the row ends)
+            std::vector<int64_t> np(n_nodes + 1, 0);
+            for (int64_t i = 0; i < n_nodes; i++) np[i + 1] = np[i] + (fill[i] - m.n2e_ptr[i]);
+            if (np[n_nodes] != E * 4) {
+                std::vector<int32_t> c(np[n_nodes]);
+                for (int64_t i = 0; i < n_nodes; i++)
+                    std::copy(m.n2e.begin() + m.n2e_ptr[i], m.n2e.begin() + fill[i], c.begin() + np[i]);
+                m.n2e.swap(c);
+                m.n2e_ptr.swap(np);
+            }
+        }
+        // nodes that lead a block row, sorted by (patch, node)
+        std::vector<int64_t> order;
+        order.reserve(n_nodes);
+        for (int64_t i = 0; i < n_nodes; i++)
+            if (nbr_ptr[i + 1] > nbr_ptr[i]) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return node_patch[a] < node_patch[b]; });
+        std::vector<int64_t> pstart;        // ranges of `order`, one per patch
+        for (int64_t i = 0; i < (int64_t)order.size(); i++)
+            if (i == 0 || node_patch[order[i]] != node_patch[order[i - 1]]) pstart.push_back(i);
+        pstart.push_back((int64_t)order.size());
+        const int64_t np = (int64_t)pstart.size() - 1;
+        std::vector<int64_t> ne(np, 0), nl(np, 0), nev(np, 0);
+        int err = 0;
+        // pass 1: sizes
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t p = 0; p < np; p++) {
+            const int64_t *nodes = order.data() + pstart[p];
+            const int64_t nn = pstart[p + 1] - pstart[p];
+            std::vector<int32_t> el;
+            for (int64_t q = 0; q < nn; q++)
+                el.insert(el.end(), m.n2e.begin() + m.n2e_ptr[nodes[q]], m.n2e.begin() + m.n2e_ptr[nodes[q] + 1]);
+            std::sort(el.begin(), el.end());
+            el.erase(std::unique(el.begin(), el.end()), el.end());
+            ne[p] = (int64_t)el.size();
+            if ((int64_t)el.size() > max_patch_elems) {
+#pragma omp atomic write
+                err = -4;
+                continue;
+            }
+            std::vector<TaskRec> tasks;
+            std::vector<int> scratch;
+            int64_t evs = 0;
+            const int rc = patch_tasks(m, nodes, nn, el.data(), (int)el.size(), [&](const Task &t) { tasks.push_back(t); evs += t.n; });
+            if (rc) {
+#pragma omp atomic write
+                err = rc;
+                continue;
+            }
+            nl[p] = layout_patch(tasks, nullptr, scratch);
+            nev[p] = evs;
+        }
+        if (err) {
+            delete P;
+            const char *msg = err == -4 ? "fs_fused_plan_build: a patch touches more than max_patch_elems elements"
+                            : err == -1 ? "fs_fused_plan_build: a node pair is shared by more than 32 elements"
+                            : err == -3 ? "fs_fused_plan_build: block with contributions but no transposed partner (pattern not symmetric)"
+                                        : "fs_fused_plan_build: inconsistent connectivity";
+            return fs_fail_(FS_EINVAL, msg, 0);
+        }
+        P->pat_eptr.assign(np + 1, 0);
+        P->pat_rptr.assign(np + 1, 0);
+        for (int64_t p = 0; p < np; p++) {
+            P->pat_eptr[p + 1] = P->pat_eptr[p] + ne[p];
+            P->pat_rptr[p + 1] = P->pat_rptr[p] + nl[p];
+            P->n_evals += nev[p];
+        }
+        P->pat_elems.resize(P->pat_eptr[np]);
+        fs_fused_rec blank;
+        std::memset(&blank, 0, sizeof blank);
+        blank.dst[0] = blank.dst[1] = blank.dst_t[0] = blank.dst_t[1] = -1;
+        blank.slots = 0xFFFFFFFFu;
+        P->recs.assign(P->pat_rptr[np], blank);
+        // pass 2: fill
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t p = 0; p < np; p++) {
+            const int64_t *nodes = order.data() + pstart[p];
+            const int64_t nn = pstart[p + 1] - pstart[p];
+            std::vector<int32_t> el;
+            for (int64_t q = 0; q < nn; q++)
+                el.insert(el.end(), m.n2e.begin() + m.n2e_ptr[nodes[q]], m.n2e.begin() + m.n2e_ptr[nodes[q] + 1]);
+            std::sort(el.begin(), el.end());
+            el.erase(std::unique(el.begin(), el.end()), el.end());
+            std::copy(el.begin(), el.end(), P->pat_elems.begin() + P->pat_eptr[p]);
+            fs_fused_rec *rec = P->recs.data() + P->pat_rptr[p];
+            std::vector<TaskRec> tasks;
+            std::vector<int> scratch;
+            patch_tasks(m, nodes, nn, el.data(), (int)el.size(), [&](const Task &t) { tasks.push_back(t); });
+            if (layout_patch(tasks, rec, scratch) < 0) {
+#pragma omp atomic write
+                err = -5;
+            }
+        }
+        if (err) {
+            delete P;
+            return fs_fail_(FS_EINVAL, "fs_fused_plan_build: more than 255 blocks stored by one wave", 0);
+        }
+        *plan = P;
+        *n_patches = np;
+        *n_elem_slots = P->pat_eptr[np];
+        *n_recs = P->pat_rptr[np];
+        return FS_OK;
+    } catch (const std::bad_alloc &) {
+        delete P;
+        return fs_fail_(FS_EINVAL, "fs_fused_plan_build: out of memory", 0);
+    }
+}
+
+int fs_fused_plan_export(const fs_fused_plan *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_rptr,
+                         fs_fused_rec *recs, int64_t *n_evals) {
+    if (!plan || !pat_eptr || !pat_elems || !pat_rptr || !recs)
+        return fs_fail_(FS_EINVAL, "fs_fused_plan_export: null argument", 0);
+    std::copy(plan->pat_eptr.begin(), plan->pat_eptr.end(), pat_eptr);
+    std::copy(plan->pat_rptr.begin(), plan->pat_rptr.end(), pat_rptr);
+    std::copy(plan->pat_elems.begin(), plan->pat_elems.end(), pat_elems);
+    if (!plan->recs.empty()) std::memcpy(recs, plan->recs.data(), plan->recs.size() * sizeof(fs_fused_rec));
+    if (n_evals) *n_evals = plan->n_evals;
+    return FS_OK;
+}
+
+void fs_fused_plan_free(fs_fused_plan *plan) { delete plan; }
+
+}  // extern "C"

@@ -320,8 +320,9 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
  * cache (core/assembler.py:160-193 -> MITC4.K, elements/MITC4.py:1018-1036); bit-identical to
  * fs_shell_quad_batch(FS_WANT_K) followed by fs_csr_numeric_desc (same block values, same element-order sums).
  *
- * The mesh is cut into PATCHES of nodes (plan built once per mesh: fem_shell_amd/fused.py restates the rules below;
- * tests/cabi/driver.c builds a plan in plain C).  A workgroup evaluates the elements touching its patch into LDS and
+ * The mesh is cut into PATCHES of nodes (plan built once per mesh by fs_fused_plan_build below from a map node ->
+ * patch: fem_shell_amd/fused.py::partition_nodes, or any map whose patches touch at most max_patch_elems elements;
+ * tests/cabi/driver.c drives the whole path from plain C).  A workgroup evaluates the elements touching its patch into LDS and
  * forms every node-pair block (I, J), I in the patch and I <= J (plus pattern-only blocks without a transposed
  * partner), writing it to (I, J) and transposed to (J, I).
  *   pat_eptr  [n_patches+1]  ranges into pat_elems; a patch holds <= max_patch_elems <= FS_FUSED_MAX_PATCH_ELEMS
@@ -369,6 +370,26 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
                            int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
                            const int64_t *pat_rptr, const fs_fused_rec *recs, int32_t max_patch_elems,
                            uint32_t flags, double *data, int32_t *status, void *stream);
+
+/*
+ * The plan of fs_fused_assemble_quad, built on the HOST in native code (OpenMP over patches; all pointers of these
+ * three calls are host memory, the caller uploads the exported arrays).  No counterpart in the reference (its loops need
+ * no plan).
+ *   conn        [E][4] node indices;  nbr_ptr [n_nodes+1], nbr [nblk]: the node graph of the CSR pattern, neighbours
+ *               ascending (fs_csr_symbolic_finish's arrays copied to the host; ghost columns of a distributed run included)
+ *   node_patch  [n_nodes] patch id of every node (any integers; nodes without a block row are ignored)
+ * fs_fused_plan_build fails with FS_EINVAL when a patch touches more than max_patch_elems elements, when a node pair is
+ * shared by more than 32 elements, or when a block with contributions has no transposed partner in the pattern.
+ * fs_fused_plan_export copies the plan into caller buffers of n_patches+1, n_elem_slots, n_patches+1, n_recs entries
+ * (n_evals, optional: number of contributions, for fill statistics).
+ */
+typedef struct fs_fused_plan fs_fused_plan;
+int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                        const int64_t *node_patch, int32_t max_patch_elems, fs_fused_plan **plan, int64_t *n_patches,
+                        int64_t *n_elem_slots, int64_t *n_recs);
+int fs_fused_plan_export(const fs_fused_plan *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_rptr,
+                         fs_fused_rec *recs, int64_t *n_evals);
+void fs_fused_plan_free(fs_fused_plan *plan);
 
 /* Symbolic companion of fs_csr_numeric_desc (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph:

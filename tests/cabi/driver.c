@@ -7,9 +7,11 @@
  *
  *   usage: cabi_driver in.bin out.bin
  *   in :  int64 E, n_nodes, n_props; f64 xyz[E][4][3]; i32 prop_id[E]; fs_shell_prop props[n_props];
- *         i64 conn[E][4]
+ *         i64 conn[E][4]; i64 node_patch[n_nodes] (the patch of every node, for the fused path)
  *   out:  int64 nblk, nnz, ndof; i64 indptr[ndof+1]; i32 indices[nnz]; f64 K[nnz]; f64 M[nnz];
  *         f64 lumped[ndof]; i32 status[E]
+ * Besides, the fused route (fs_fused_plan_build on the host, fs_fused_assemble_quad on the device) must reproduce the K of
+ * the two-kernel route bit for bit: exit code 8 otherwise.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -74,6 +76,7 @@ int main(int argc, char **argv) {
     int32_t *pid = rd(in, (size_t)E * 4);
     fs_shell_prop *props = rd(in, (size_t)P * sizeof(fs_shell_prop));
     int64_t *conn = rd(in, (size_t)E * 32);
+    int64_t *node_patch = rd(in, (size_t)N * 8);
     fclose(in);
 
     hipStream_t s;
@@ -110,6 +113,41 @@ int main(int argc, char **argv) {
     FSCHK(fs_csr_numeric_desc(d_Me, d_desc, d_contrib, nblk, 6, d_M, s));
     FSCHK(fs_csr_row_sums(d_indptr, d_M, ndof, d_lump, s));
     HIPCHK(hipStreamSynchronize(s));
+
+    /* the fused route: plan on the host from the pattern's node graph, one launch, no element matrices -- same bits */
+    {
+        int64_t *h_nbr_ptr = malloc((size_t)(N + 1) * 8);
+        int32_t *h_nbr = malloc((size_t)nblk * 4);
+        HIPCHK(hipMemcpy(h_nbr_ptr, d_nbr_ptr, (size_t)(N + 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_nbr, d_nbr, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+        fs_fused_plan *fp = NULL;
+        int64_t npat = 0, nslots = 0, nrecs = 0;
+        FSCHK(fs_fused_plan_build(conn, E, N, h_nbr_ptr, h_nbr, node_patch, FS_FUSED_MAX_PATCH_ELEMS, &fp, &npat, &nslots, &nrecs));
+        int64_t *h_eptr = malloc((size_t)(npat + 1) * 8), *h_rptr = malloc((size_t)(npat + 1) * 8);
+        int32_t *h_elems = malloc((size_t)nslots * 4 + 4);
+        fs_fused_rec *h_recs = malloc((size_t)nrecs * sizeof(fs_fused_rec) + 1);
+        FSCHK(fs_fused_plan_export(fp, h_eptr, h_elems, h_rptr, h_recs, NULL));
+        fs_fused_plan_free(fp);
+        void *d_eptr, *d_rptr, *d_elems, *d_recs, *d_Kf, *d_stf;
+        if (to_dev(&d_eptr, h_eptr, (size_t)(npat + 1) * 8) || to_dev(&d_rptr, h_rptr, (size_t)(npat + 1) * 8) ||
+            to_dev(&d_elems, h_elems, (size_t)nslots * 4) || to_dev(&d_recs, h_recs, (size_t)nrecs * sizeof(fs_fused_rec)) ||
+            to_dev(&d_Kf, NULL, (size_t)nnz * 8) || to_dev(&d_stf, NULL, (size_t)E * 4))
+            return 2;
+        uint32_t fl = 0;
+        for (int64_t i = 0; i < P; i++)
+            if (props[i].flags & FS_PROP_COUPLED) fl = FS_FUSED_HAS_COUPLED;
+        FSCHK(fs_fused_assemble_quad(d_xyz, d_pid, d_props, (int32_t)P, E, npat, d_eptr, d_elems, d_rptr, d_recs,
+                                     FS_FUSED_MAX_PATCH_ELEMS, fl, d_Kf, d_stf, s));
+        HIPCHK(hipStreamSynchronize(s));
+        double *k2 = malloc((size_t)nnz * 8), *kf = malloc((size_t)nnz * 8);
+        int32_t *st2 = malloc((size_t)E * 4), *stf = malloc((size_t)E * 4);
+        HIPCHK(hipMemcpy(k2, d_K, (size_t)nnz * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(kf, d_Kf, (size_t)nnz * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(st2, d_st, (size_t)E * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(stf, d_stf, (size_t)E * 4, hipMemcpyDeviceToHost));
+        if (memcmp(k2, kf, (size_t)nnz * 8) != 0 || memcmp(st2, stf, (size_t)E * 4) != 0) return 8;
+        if (fs_fused_plan_build(conn, E, N, h_nbr_ptr, h_nbr, NULL, 64, &fp, &npat, &nslots, &nrecs) != FS_EINVAL) return 6;
+    }
 
     /* error behaviour: bad arguments come back as codes + message, never as a crash */
     if (fs_shell_quad_batch(NULL, d_pid, d_props, (int32_t)P, NULL, E, FS_WANT_K, FS_LAYOUT_SYMBLK, d_Ke, NULL, NULL,

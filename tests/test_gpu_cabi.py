@@ -1,6 +1,6 @@
 """GPU: the C ABI driven by a plain-C host (tests/cabi/driver.c: no Python, no torch in that process; gcc-built
 against include/femshell_hip.h) -- element matrices, device symbolic phase, CSR assembly of K and M, lumped mass --
-checked against the oracle.  This is the calling sequence a cgo / JNI / ctypes binding of the reference would use
+checked against the oracle; the fused route (native plan builder + one launch) must give the same K bit for bit.  This is the calling sequence a cgo / JNI / ctypes binding of the reference would use
 (INTEGRATION.md)."""
 import os
 import subprocess
@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from fem_shell_amd import meshes
+from fem_shell_amd.fused import partition_nodes
 from fem_shell_amd.properties import build_prop_table
 from oracle import oracle as O
 from tests import util
@@ -29,6 +30,7 @@ def test_c_host_drives_the_whole_path(tmp_path):
     with open(fin, "wb") as f:
         np.array([E, N, props.shape[0]], dtype=np.int64).tofile(f)
         xyz.tofile(f); pid.tofile(f); f.write(props.tobytes()); mesh.conn.astype(np.int64).tofile(f)
+        partition_nodes(mesh.coords, mesh.conn, 64).astype(np.int64).tofile(f)      # node -> patch, for the fused route
     r = subprocess.run([DRIVER, str(fin), str(fout)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "cabi_driver ok" in r.stdout
