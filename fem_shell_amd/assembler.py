@@ -209,12 +209,10 @@ class MeshAssembler:
         coords, conn, elem_ids, thickness, set_lookup = self._extract()
         # Elements whose node count the family's factory does not know are skipped, like the reference
         # (ElementFactory returns False on the KeyError and the loop `continue`s: elements.py:258-259,
-        # core/assembler.py:163-164).  PYRAMID13 is known to the reference but not built here: loud error.
+        # core/assembler.py:163-164).
         self._mesh_pos = None              # position in mesh.elements of every kept element (None: all kept)
         counts = (conn >= 0).sum(axis=1)
-        known = (3, 4) if fam == ElementFamily.SHELL else (4, 5, 6, 8, 10, 15, 20)
-        if fam == ElementFamily.SOLID and (counts == 13).any():
-            raise NotImplementedError("SOLID elements with 13 nodes (PYRAMID13) are not on the GPU path")
+        known = (3, 4) if fam == ElementFamily.SHELL else (4, 5, 6, 8, 10, 13, 15, 20)
         keep = np.isin(counts, known)
         if not keep.all():
             self._mesh_pos = np.flatnonzero(keep)
@@ -242,7 +240,7 @@ class MeshAssembler:
             self._prop_id = np.zeros(E, dtype=np.int32)
             self._prop_objects = [self.model["material"]]
             self._props_d = batch.to_device_solid_props(self._prop_table)
-            allowed = (4, 5, 6, 8, 10, 15, 20)
+            allowed = (4, 5, 6, 8, 10, 13, 15, 20)
         # symbolic phase on the device (fs_csr_symbolic_*); a precomputed host BlockPlan is accepted too
         # (uniform quad meshes: element matrices in the tiled layout the stiffness kernel writes fastest)
         self._plan = self._given_plan or DeviceBlockPlan(conn, int(self.mesh.node_count), self.dofs_per_node, dev,

@@ -239,7 +239,7 @@ def centrifugal_prestress(solid, nn, xyz, prop_id, props_dev, n_props, omega, ro
 def solid_batch(nn, xyz, prop_id, props_dev, n_props, want_K=True, want_M=False, body=None,
                 sigma=None, reduced=False, dense=False, status=True, validate=True, K_out=None,
                 M_out=None):
-    """Solids (fs_solid_batch): nn = 4 TETRA4, 5 PYRAMID5, 6 WEDGE6, 8 HEXA8, 10 TETRA10, 15 WEDGE15, 20 HEXA20.
+    """Solids (fs_solid_batch): nn = 4 TETRA4, 5 PYRAMID5, 6 WEDGE6, 8 HEXA8, 10 TETRA10, 13 PYRAMID13, 15 WEDGE15, 20 HEXA20.
 
     xyz [E,nn,3] f64 device; props_dev [P,37] f64 device (properties.solid_row).  body: 3 floats
     (host) -> 'f' [E,3nn]; sigma [E,6] device -> 'KG'.  Matrices in FS_LAYOUT_SYMBLK
@@ -248,7 +248,7 @@ def solid_batch(nn, xyz, prop_id, props_dev, n_props, want_K=True, want_M=False,
     dev = _dev()
     xyz = xyz.contiguous()
     E = xyz.shape[0]
-    if nn not in (4, 5, 6, 8, 10, 15, 20):
+    if nn not in (4, 5, 6, 8, 10, 13, 15, 20):
         raise NotImplementedError(f"solid elements with {nn} nodes are not on the GPU path")
     assert xyz.dtype == torch.float64 and xyz.shape[1:] == (nn, 3) and xyz.is_cuda
     assert prop_id.dtype == torch.int32 and prop_id.is_cuda and prop_id.numel() == E

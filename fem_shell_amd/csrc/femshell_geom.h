@@ -294,7 +294,7 @@ inline void make_solid_rule(int nn, int reduced, SolidRule &rule) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Quadratic solids TETRA10 / WEDGE15 / HEXA20 (SOLID.py:832-1059, 1600-1708, 1821-1946).  Their shape
+// Quadratic solids TETRA10 / PYRAMID13 / WEDGE15 / HEXA20 (SOLID.py:832-1059, 1221-1537, 1600-1708, 1821-1946).  Their shape
 // data at the integration points do not depend on the element, so they are tabulated once on the HOST
 // with the reference's own operation order (this header is compiled with contraction off; `x**2` of a
 // NumPy float64 scalar is libm pow(x, 2.0)) and handed to the kernels as a device table.  This matters
@@ -355,6 +355,61 @@ inline int make_solid_table(int nn, SolidTable &t) {
                 t.v[q][i][0] = N0[i]; t.v[q][i][1] = (Na[i] - N0[i]) / h;
                 t.v[q][i][2] = (Nb[i] - N0[i]) / h; t.v[q][i][3] = (Nc[i] - N0[i]) / h;
             }
+        }
+        return 0;
+    }
+    if (nn == 13) {          // PYRAMID13, SOLID.py:1221-1537: 18-point Felippa rule, rational serendipity functions
+        const double ua = 0.35309846330877704481, za = 0.54415184401122528880;
+        const double ub = 0.67969709567986745790, zb = 0.12251482265544137787;
+        const double wa[3] = {0.023330065296255886709, 0.037328104474009418735, 0.059724967158415069975};
+        const double wb[3] = {0.053830428530904607120, 0.086128685649447371390, 0.137805897039115794220};
+        t.ng = 18;
+        for (int layer = 0; layer < 2; layer++)
+            for (int j = 0; j < 3; j++)
+                for (int i = 0; i < 3; i++) {
+                    const int q = 9 * layer + 3 * j + i;
+                    const double u = layer ? ub : ua;
+                    t.pt[q][0] = (i - 1) * u; t.pt[q][1] = (j - 1) * u; t.pt[q][2] = layer ? zb : za;
+                    const int kind = (i == 1) + (j == 1);          // corner, edge midpoint, centre of the 3 x 3 grid
+                    t.w[q] = layer ? wb[kind] : wa[kind];
+                }
+        for (int q = 0; q < 18; q++) {
+            const double xi = t.pt[q][0], eta = t.pt[q][1], zeta = t.pt[q][2];
+            double r = 1 - zeta;
+            if (r < 1e-14) r = 1e-14;
+            const double r2 = r * r;
+            double xs = xi / r, es = eta / r;
+            xs = xs < -1.0 ? -1.0 : (xs > 1.0 ? 1.0 : xs);
+            es = es < -1.0 ? -1.0 : (es > 1.0 ? 1.0 : es);
+            const double xs2 = pow(xs, 2.0), es2 = pow(es, 2.0);
+            const double f[4] = {((0.25 * (1 - xs)) * (1 - es)) * ((-xs - es) - 1), ((0.25 * (1 + xs)) * (1 - es)) * ((xs - es) - 1),
+                                 ((0.25 * (1 + xs)) * (1 + es)) * ((xs + es) - 1), ((0.25 * (1 - xs)) * (1 + es)) * ((-xs + es) - 1)};
+            const double dfx[4] = {(0.25 * (1 - es)) * (2 * xs + es), (0.25 * (1 - es)) * (2 * xs - es),
+                                   (0.25 * (1 + es)) * (2 * xs + es), (0.25 * (1 + es)) * (2 * xs - es)};
+            const double dfe[4] = {(0.25 * (1 - xs)) * (xs + 2 * es), (0.25 * (1 + xs)) * (-xs + 2 * es),
+                                   (0.25 * (1 + xs)) * (xs + 2 * es), (0.25 * (1 - xs)) * (-xs + 2 * es)};
+            // base edge midpoints 5 (0-1), 6 (0-3), 8 (1-2), 10 (2-3)
+            const double gv[4] = {(0.5 * (1 - xs2)) * (1 - es), (0.5 * (1 - xs)) * (1 - es2), (0.5 * (1 + xs)) * (1 - es2),
+                                  (0.5 * (1 - xs2)) * (1 + es)};
+            const double dgx[4] = {-xs * (1 - es), -0.5 * (1 - es2), 0.5 * (1 - es2), -xs * (1 + es)};
+            const double dge[4] = {-0.5 * (1 - xs2), -(1 - xs) * es, -(1 + xs) * es, 0.5 * (1 - xs2)};
+            const double ph[4] = {(0.25 * (1 - xs)) * (1 - es), (0.25 * (1 + xs)) * (1 - es), (0.25 * (1 + xs)) * (1 + es),
+                                  (0.25 * (1 - xs)) * (1 + es)};
+            const double dpx[4] = {-0.25 * (1 - es), 0.25 * (1 - es), 0.25 * (1 + es), -0.25 * (1 + es)};
+            const double dpe[4] = {-0.25 * (1 - xs), -0.25 * (1 + xs), 0.25 * (1 + xs), 0.25 * (1 - xs)};
+            const double one2z = 1 - 2 * zeta;
+            const double h_base = r * one2z, h_lat = (4 * zeta) * r, dh_base = -3 + 4 * zeta, dh_lat = 4 * one2z;
+            const double lat = (4 * zeta) * (1 - zeta);
+            double (*v)[4] = t.v[q];
+            auto put = [&](int n, double N, double fn, double a, double b, double h, double dh) {
+                v[n][0] = N; v[n][1] = (a * h) / r; v[n][2] = (b * h) / r;
+                v[n][3] = ((a * xi + b * eta) / r2) * h + fn * dh;
+            };
+            for (int i = 0; i < 4; i++) put(i, (f[i] * r) * one2z, f[i], dfx[i], dfe[i], h_base, dh_base);
+            v[4][0] = zeta * (2 * zeta - 1); v[4][1] = 0.0; v[4][2] = 0.0; v[4][3] = 4 * zeta - 1;
+            const int gn[4] = {5, 6, 8, 10}, ln[4] = {7, 9, 11, 12};
+            for (int i = 0; i < 4; i++) put(gn[i], (gv[i] * r) * one2z, gv[i], dgx[i], dge[i], h_base, dh_base);
+            for (int i = 0; i < 4; i++) put(ln[i], ph[i] * lat, ph[i], dpx[i], dpe[i], h_lat, dh_lat);
         }
         return 0;
     }

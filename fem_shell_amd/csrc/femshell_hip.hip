@@ -2855,14 +2855,14 @@ int launch_solid(const double *xyz, const int32_t *prop_id, const double *props,
 // device copies of the quadratic-solid shape tables: built once per (device, element type), kept for the
 // life of the process (17 KB at most each)
 std::mutex g_tab_mutex;
-double *g_tab_dev[16][3] = {};
-int g_tab_ng[3] = {};
+double *g_tab_dev[16][4] = {};
+int g_tab_ng[4] = {};
 int solid_table_device(int nn, const double **tab, int *ng) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return fail(FS_EHIP, "hipGetDevice", e);
     if (dev < 0 || dev >= 16) return fail(FS_EINVAL, "fs_solid_batch: device ordinal above 15");
-    const int slot = nn == 10 ? 0 : (nn == 15 ? 1 : 2);
+    const int slot = nn == 10 ? 0 : (nn == 15 ? 1 : (nn == 20 ? 2 : 3));
     std::lock_guard<std::mutex> lock(g_tab_mutex);
     if (!g_tab_dev[dev][slot]) {
         static SolidTable t;   // 18 KB: not on the stack
@@ -2896,8 +2896,8 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
                    const double *sigma, double *Ke, double *Me, double *fe, double *KGe, int32_t *status,
                    void *stream) {
     if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_solid_batch: bad sizes");
-    if (nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 15 && nn != 20)
-        return fail(FS_ENOSYS, "fs_solid_batch: TETRA4 / PYRAMID5 / WEDGE6 / HEXA8 / TETRA10 / WEDGE15 / HEXA20 (nn = 4, 5, 6, 8, 10, 15, 20)");
+    if (nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 13 && nn != 15 && nn != 20)
+        return fail(FS_ENOSYS, "fs_solid_batch: TETRA4 / PYRAMID5 / WEDGE6 / HEXA8 / TETRA10 / PYRAMID13 / WEDGE15 / HEXA20 (nn = 4, 5, 6, 8, 10, 13, 15, 20)");
     if (E == 0) return FS_OK;
     if (!xyz || !prop_id || !props) return fail(FS_EINVAL, "fs_solid_batch: null input");
     if (layout != FS_LAYOUT_SYMBLK)
@@ -2922,6 +2922,7 @@ int fs_solid_batch(int32_t nn, int32_t reduced, const double *xyz, const int32_t
     switch (nn) {
         case 20: launch_solid<20, 27, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
         case 15: launch_solid<15, 21, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
+        case 13: launch_solid<13, 18, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
         case 10: launch_solid<10, 4, true>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
         case 8: launch_solid<8, 8, false>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
         case 6: launch_solid<6, 8, false>(xyz, prop_id, props, n_props, E, rule, tab, ng_tab, b3, sigma, k, m, f, kg, status, s); break;
@@ -2936,7 +2937,7 @@ int fs_solid2_table(int32_t nn, double *pts, double *w, double *vals, int32_t *n
     static SolidTable t;
     static std::mutex m;
     std::lock_guard<std::mutex> lock(m);
-    if (make_solid_table(nn, t) != 0) return fail(FS_EINVAL, "fs_solid2_table: nn must be 10, 15 or 20");
+    if (make_solid_table(nn, t) != 0) return fail(FS_EINVAL, "fs_solid2_table: nn must be 10, 13, 15 or 20");
     if (ng) *ng = t.ng;
     for (int q = 0; q < t.ng; q++) {
         if (pts) for (int k = 0; k < 3; k++) pts[3 * q + k] = t.pt[q][k];
@@ -3018,7 +3019,7 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
     if (!axis_host || !center_host) return fail(FS_EINVAL, "fs_centrifugal_prestress: axis / center is null");
     if (!solid && nn == 4)   // 'MITC4' object has no attribute 'compute_centrifugal_prestress'
         return fail(FS_ENOSYS, "fs_centrifugal_prestress: the reference MITC4 has no compute_centrifugal_prestress");
-    if ((!solid && nn != 3) || (solid && nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 15 && nn != 20))
+    if ((!solid && nn != 3) || (solid && nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 13 && nn != 15 && nn != 20))
         return fail(FS_EINVAL, "fs_centrifugal_prestress: unsupported element");
     const double la = sqrt(axis_host[0] * axis_host[0] + axis_host[1] * axis_host[1] + axis_host[2] * axis_host[2]);
     if (!(la > 0.0)) return fail(FS_EINVAL, "fs_centrifugal_prestress: zero rotation axis");
@@ -3036,6 +3037,7 @@ int fs_centrifugal_prestress(int32_t solid, int32_t nn, const double *xyz, const
         switch (nn) {
             case 20: hipLaunchKernelGGL(centrifugal_solid_kernel<20>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
             case 15: hipLaunchKernelGGL(centrifugal_solid_kernel<15>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
+            case 13: hipLaunchKernelGGL(centrifugal_solid_kernel<13>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
             case 10: hipLaunchKernelGGL(centrifugal_solid_kernel<10>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
             case 8: hipLaunchKernelGGL(centrifugal_solid_kernel<8>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;
             case 6: hipLaunchKernelGGL(centrifugal_solid_kernel<6>, grid, block, 0, s, xyz, prop_id, pp, n_props, omega, ax, ce, E, sigma); break;

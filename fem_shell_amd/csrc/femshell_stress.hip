@@ -344,8 +344,8 @@ int fs_solid_stress_batch(int32_t nn, int32_t reduced, const double *xyz, const 
                           const double *extrap, int32_t mode, double *sigma, double *eps, double *weight,
                           void *stream) {
     if (E < 0 || n_props <= 0) return fs_fail_(FS_EINVAL, "fs_solid_stress_batch: bad sizes", 0);
-    if (nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 15 && nn != 20)
-        return fs_fail_(FS_ENOSYS, "fs_solid_stress_batch: nn must be 4, 5, 6, 8, 10, 15 or 20", 0);
+    if (nn != 4 && nn != 5 && nn != 6 && nn != 8 && nn != 10 && nn != 13 && nn != 15 && nn != 20)
+        return fs_fail_(FS_ENOSYS, "fs_solid_stress_batch: nn must be 4, 5, 6, 8, 10, 13, 15 or 20", 0);
     if (mode != FS_SOLID_STRESS_GP && mode != FS_SOLID_STRESS_MEAN && mode != FS_SOLID_STRESS_NODES)
         return fs_fail_(FS_EINVAL, "fs_solid_stress_batch: bad mode", 0);
     if (mode == FS_SOLID_STRESS_NODES && !extrap)
@@ -365,6 +365,7 @@ int fs_solid_stress_batch(int32_t nn, int32_t reduced, const double *xyz, const 
     switch (nn) {
         case 20: launch_solid_stress<20, 27, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
         case 15: launch_solid_stress<15, 21, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
+        case 13: launch_solid_stress<13, 18, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
         case 10: launch_solid_stress<10, 4, true>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
         case 8: launch_solid_stress<8, 8, false>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;
         case 6: launch_solid_stress<6, 8, false>(xyz, prop_id, props, n_props, u_e, E, rule, tab, ng_tab, extrap, mode, sigma, eps, weight, s); break;

@@ -387,6 +387,8 @@ PYRAMID5 = _solid_class("PYRAMID5", 5, "5-node pyramid, Felippa 8-point rule (el
 WEDGE6 = _solid_class("WEDGE6", 6, "6-node wedge, 3x2 rule with the reference's x2 weights (elements/SOLID.py:700-829).")
 HEXA8 = _solid_class("HEXA8", 8, "8-node brick, 2x2x2 (or 1-point reduced) rule (elements/SOLID.py:1716-1818).")
 TETRA10 = _solid_class("TETRA10", 10, "10-node tetrahedron (Gmsh order), 4-point rule (elements/SOLID.py:1600-1708).")
+PYRAMID13 = _solid_class("PYRAMID13", 13, "13-node quadratic pyramid (Gmsh order), 18-point Felippa rule, rational serendipity "
+                         "functions of the scaled base (elements/SOLID.py:1221-1537).")
 WEDGE15 = _solid_class("WEDGE15", 15, "15-node wedge (Gmsh order), 7x3 rule with the x2 weights (elements/SOLID.py:832-1059).")
 HEXA20 = _solid_class("HEXA20", 20, "20-node serendipity brick (Gmsh order), 3x3x3 rule; derivatives are the reference's "
                       "forward differences, h = 1e-8 (elements/SOLID.py:1821-1946).")
@@ -417,9 +419,8 @@ class ElementFactory:
                                                            laminate=laminate, **kwargs)
                 return shell_map[node_count](node_coords=node_coords, node_ids=node_ids, **kwargs)
             if element_family == ElementFamily.SOLID:
-                if node_count == 13:   # PYRAMID13: skipped by the reference's own tests
-                    raise NotImplementedError("PYRAMID13 is not on the GPU path")
-                solid_map = {4: TETRA4, 5: PYRAMID5, 6: WEDGE6, 8: HEXA8, 10: TETRA10, 15: WEDGE15, 20: HEXA20}
+                solid_map = {4: TETRA4, 5: PYRAMID5, 6: WEDGE6, 8: HEXA8, 10: TETRA10, 13: PYRAMID13, 15: WEDGE15,
+                             20: HEXA20}
                 kwargs.pop("thickness", None)
                 return solid_map[node_count](node_coords=node_coords, node_ids=node_ids, **kwargs)
             raise NotImplementedError(f"Element family {element_family} not implemented")

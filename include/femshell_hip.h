@@ -140,7 +140,7 @@ int fs_shell_tri_batch(const double *xyz, const int32_t *prop_id, const fs_shell
  * rules and shape functions of the concrete classes (:731-829, :1099-1218, :1575-1597, :1744-1818;
  * `reduced` != 0 selects HEXA8's 1-point rule).  Reference quirks kept: WEDGE6 weights sum to 2;
  * K_G uses inv_J.T where B uses inv_J.
- * nn = 10 / 15 / 20 (TETRA10 / WEDGE15 / HEXA20, SOLID.py:832-1059, 1600-1708, 1821-1946) run the same kernel
+ * nn = 10 / 13 / 15 / 20 (TETRA10 / PYRAMID13 / WEDGE15 / HEXA20, SOLID.py:832-1059, 1221-1537, 1600-1708, 1821-1946) run the same kernel
  * from a host-built shape table (fs_solid2_table); the first call per device uploads it (one hipMalloc).
  *   xyz     [E][nn][3]
  *   props   [n_props][37]  C (6x6, global axes, Voigt xx,yy,zz,xy,yz,zx; SOLID.py:377-541 evaluated
@@ -205,7 +205,7 @@ int fs_shell_rotate_local(int32_t nn, const double *xyz, int64_t E, const double
  * sigma [E][3] local [sxx,syy,sxy]) or of the linear solids (SOLID.py:268-320 -> sigma [E][6]
  * global Voigt [xx,yy,zz,xy,yz,zx]).
  *   solid   0: shells (nn = 3; nn = 4 returns FS_ENOSYS -- the reference MITC4 has no such method),
- *           1: solids (nn = 4, 5, 6, 8, 10, 15, 20)
+ *           1: solids (nn = 4, 5, 6, 8, 10, 13, 15, 20)
  *   props   fs_shell_prop rows (rho field) for shells, [n_props][37] rows for solids (rho = column 36)
  *   axis_host, center_host   3 doubles each in HOST memory; the axis is normalised here
  */

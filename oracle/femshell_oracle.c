@@ -1296,7 +1296,7 @@ int fso_mitc3_batch(const double *xyz, const int32_t *prop_id, const fso_shell_p
 }
 
 /* ====================================================================================
- * Solids (elements/SOLID.py): TETRA4, PYRAMID5, WEDGE6, HEXA8, TETRA10, WEDGE15, HEXA20.  type == node count.
+ * Solids (elements/SOLID.py): TETRA4, PYRAMID5, WEDGE6, HEXA8, TETRA10, PYRAMID13, WEDGE15, HEXA20.  type == node count.
  * ==================================================================================== */
 static int solid_rule(int nn, int reduced, double pts[][3], double *w) {
     const double gp = 1.0 / sqrt(3.0);
@@ -1331,6 +1331,20 @@ static int solid_rule(int nn, int reduced, double pts[][3], double *w) {
             pts[4 + q][0] = sx[q] * b; pts[4 + q][1] = sy[q] * b; pts[4 + q][2] = zb; w[4 + q] = wb;
         }
         return 8;
+    }
+    if (nn == 13) { /* SOLID.py:1268-1321: 18-point Felippa rule, two 3 x 3 layers */
+        const double u[2] = {0.35309846330877704481, 0.67969709567986745790};
+        const double z[2] = {0.54415184401122528880, 0.12251482265544137787};
+        const double ww[2][3] = {{0.023330065296255886709, 0.037328104474009418735, 0.059724967158415069975},
+                                 {0.053830428530904607120, 0.086128685649447371390, 0.137805897039115794220}};
+        int n = 0;
+        for (int l = 0; l < 2; l++)
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++) {
+                    pts[n][0] = i * u[l]; pts[n][1] = j * u[l]; pts[n][2] = z[l];
+                    w[n++] = ww[l][(i == 0) + (j == 0)];
+                }
+        return 18;
     }
     if (nn == 10) { /* SOLID.py:1642-1655 */
         const double a = (5 - sqrt(5.0)) / 20, b = (5 + 3 * sqrt(5.0)) / 20;
@@ -1400,6 +1414,38 @@ static void solid_shape(int nn, double xi, double eta, double zeta, double *N, d
         hexa20_shape(xi, eta + h, zeta, Nb);
         hexa20_shape(xi, eta, zeta + h, Nc);
         for (int i = 0; i < 20; i++) { dxi[i] = (Na[i] - N[i]) / h; deta[i] = (Nb[i] - N[i]) / h; dzeta[i] = (Nc[i] - N[i]) / h; }
+        return;
+    }
+    if (nn == 13) { /* PYRAMID13, SOLID.py:1323-1537: serendipity functions of the scaled base x vertical blends */
+        double r = 1 - zeta; if (r < 1e-14) r = 1e-14;
+        const double r2 = r * r;
+        double xs = xi / r, es = eta / r;
+        xs = xs < -1 ? -1 : (xs > 1 ? 1 : xs);
+        es = es < -1 ? -1 : (es > 1 ? 1 : es);
+        const double hb = r * (1 - 2 * zeta), hl = 4 * zeta * r, dhb = -3 + 4 * zeta, dhl = 4 * (1 - 2 * zeta);
+        /* function of (xs, es), its two derivatives, per node; blend h and dh/dzeta */
+        double fn[13], fx[13], fe[13];
+        const double sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+        for (int i = 0; i < 4; i++) { /* corners 0..3 and lateral mid-edges 7, 9, 11, 12 */
+            const double a = 1 + sx[i] * xs, b = 1 + sy[i] * es, c = sx[i] * xs + sy[i] * es - 1;
+            fn[i] = 0.25 * a * b * c;
+            fx[i] = 0.25 * b * (2 * xs + sx[i] * sy[i] * es);
+            fe[i] = 0.25 * a * (sx[i] * sy[i] * xs + 2 * es);
+            const int l = i == 0 ? 7 : (i == 1 ? 9 : (i == 2 ? 11 : 12));
+            fn[l] = 0.25 * a * b; fx[l] = 0.25 * sx[i] * b; fe[l] = 0.25 * sy[i] * a;
+        }
+        fn[5] = 0.5 * (1 - xs * xs) * (1 - es); fx[5] = -xs * (1 - es); fe[5] = -0.5 * (1 - xs * xs);
+        fn[6] = 0.5 * (1 - xs) * (1 - es * es); fx[6] = -0.5 * (1 - es * es); fe[6] = -(1 - xs) * es;
+        fn[8] = 0.5 * (1 + xs) * (1 - es * es); fx[8] = 0.5 * (1 - es * es); fe[8] = -(1 + xs) * es;
+        fn[10] = 0.5 * (1 - xs * xs) * (1 + es); fx[10] = -xs * (1 + es); fe[10] = 0.5 * (1 - xs * xs);
+        for (int n = 0; n < 13; n++) {
+            if (n == 4) { N[4] = zeta * (2 * zeta - 1); dxi[4] = deta[4] = 0; dzeta[4] = 4 * zeta - 1; continue; }
+            const int lat = n == 7 || n == 9 || n == 11 || n == 12;
+            const double h = lat ? hl : hb, dh = lat ? dhl : dhb;
+            N[n] = fn[n] * h;
+            dxi[n] = fx[n] * h / r; deta[n] = fe[n] * h / r;
+            dzeta[n] = (fx[n] * xi + fe[n] * eta) / r2 * h + fn[n] * dh;
+        }
         return;
     }
     if (nn == 10) { /* SOLID.py:1657-1708 (Gmsh edge order 0-1, 1-2, 0-2, 0-3, 2-3, 1-3) */

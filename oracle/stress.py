@@ -83,7 +83,7 @@ def shell_area(x):
 def solid_table(nn, reduced=False):
     """Integration points, weights and N / dN at them, SOLID.py (the linear rules as in fso_solid; the quadratic
     elements through the same formulas as the reference incl. HEXA20's forward differences)."""
-    if nn in (10, 15, 20):
+    if nn in (10, 13, 15, 20):
         return _quadratic_table(nn)
     if nn == 8:
         if reduced:
@@ -146,7 +146,38 @@ def _hexa20_N(xi, eta, zeta):
     return N
 
 
+def _pyramid13_table():
+    """SOLID.py:1268-1537: 18-point Felippa rule; serendipity functions of the scaled base times vertical blends."""
+    u, z = (0.35309846330877704481, 0.67969709567986745790), (0.54415184401122528880, 0.12251482265544137787)
+    ww = ((0.023330065296255886709, 0.037328104474009418735, 0.059724967158415069975),
+          (0.053830428530904607120, 0.086128685649447371390, 0.137805897039115794220))
+    pts = np.array([[i * u[l], j * u[l], z[l]] for l in range(2) for j in (-1, 0, 1) for i in (-1, 0, 1)])
+    w = np.array([ww[l][(i == 0) + (j == 0)] for l in range(2) for j in (-1, 0, 1) for i in (-1, 0, 1)])
+    vals = np.zeros((18, 13, 4))
+    sx, sy = (-1, 1, 1, -1), (-1, -1, 1, 1)
+    for q, (xi, eta, zeta) in enumerate(pts):
+        r = max(1 - zeta, 1e-14)
+        xs, es = np.clip(xi / r, -1, 1), np.clip(eta / r, -1, 1)
+        hb, hl, dhb, dhl = r * (1 - 2 * zeta), 4 * zeta * r, -3 + 4 * zeta, 4 * (1 - 2 * zeta)
+        fn = {}                                    # node -> (f, df/dxs, df/des, h, dh)
+        for i in range(4):
+            a, b = 1 + sx[i] * xs, 1 + sy[i] * es
+            fn[i] = (0.25 * a * b * (sx[i] * xs + sy[i] * es - 1), 0.25 * b * (2 * xs + sx[i] * sy[i] * es),
+                     0.25 * a * (sx[i] * sy[i] * xs + 2 * es), hb, dhb)
+            fn[(7, 9, 11, 12)[i]] = (0.25 * a * b, 0.25 * sx[i] * b, 0.25 * sy[i] * a, hl, dhl)
+        fn[5] = (0.5 * (1 - xs * xs) * (1 - es), -xs * (1 - es), -0.5 * (1 - xs * xs), hb, dhb)
+        fn[6] = (0.5 * (1 - xs) * (1 - es * es), -0.5 * (1 - es * es), -(1 - xs) * es, hb, dhb)
+        fn[8] = (0.5 * (1 + xs) * (1 - es * es), 0.5 * (1 - es * es), -(1 + xs) * es, hb, dhb)
+        fn[10] = (0.5 * (1 - xs * xs) * (1 + es), -xs * (1 + es), 0.5 * (1 - xs * xs), hb, dhb)
+        for n, (f, fx, fe, h, dh) in fn.items():
+            vals[q, n] = [f * h, fx * h / r, fe * h / r, (fx * xi + fe * eta) / (r * r) * h + f * dh]
+        vals[q, 4] = [zeta * (2 * zeta - 1), 0.0, 0.0, 4 * zeta - 1]
+    return pts, w, vals
+
+
 def _quadratic_table(nn):
+    if nn == 13:
+        return _pyramid13_table()
     if nn == 20:
         s35 = np.sqrt(3 / 5)
         p1, w1 = np.array([-s35, 0, s35]), np.array([5 / 9, 8 / 9, 5 / 9])

@@ -62,9 +62,9 @@ def _same_matrix(A, g, tag, n):
     return err
 
 
-@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex", "q2"])
+@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex", "q2", "p13"])
 def test_reference_assembler_golden(case):
-    g = golden("asm_ref")
+    g = golden("asm_p13" if case == "p13" else "asm_ref")      # p13: HEXA20 + PYRAMID13 (tools/gen_golden_pyr13.py)
     mesh, asm = build(case, g)
     pre = case + "_"
     assert asm.dofs_count == int(g[pre + "dofs_count"]) and asm.dofs_per_node == int(g[pre + "dofs_per_node"])
@@ -97,8 +97,8 @@ def test_reference_assembler_golden(case):
         e = _same_matrix(KG, g, "tri_KG", n)
         print("  K_G(omega)", e)
         assert e < TOL
-    if case in ("somix", "hex", "q2"):
-        body = g["somix_body"]
+    if case in ("somix", "hex", "q2", "p13"):
+        body = g["p13_body" if case == "p13" else "somix_body"]
         F = asm.assemble_load_vector(SimpleNamespace(value=body)).cpu().numpy()
         e = _rel(F, g[pre + "F"])
         print("  load vector", e)

@@ -84,7 +84,7 @@ def test_solid_bad_jacobian_and_empty():
     o = _run(4, np.zeros((0, 4, 3)), np.zeros(0, np.int32), props)
     assert o["K"].shape == (0, 12, 12)
     with pytest.raises(NotImplementedError):
-        _run(13, np.zeros((1, 13, 3)), np.zeros(1, np.int32), props)
+        _run(9, np.zeros((1, 9, 3)), np.zeros(1, np.int32), props)
 
 
 SOLID2_REF = {
@@ -95,13 +95,16 @@ SOLID2_REF = {
     20: np.array([(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1),
                   (0, -1, -1), (-1, 0, -1), (-1, -1, 0), (1, 0, -1), (1, -1, 0), (0, 1, -1), (1, 1, 0), (-1, 1, 0),
                   (0, -1, 1), (-1, 0, 1), (1, 0, 1), (0, 1, 1)], float),
+    13: np.array([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), (0, 0, 1), (0, -1, 0), (-1, 0, 0), (-.5, -.5, .5),
+                  (1, 0, 0), (.5, -.5, .5), (0, 1, 0), (.5, .5, .5), (-.5, .5, .5)], float),       # Gmsh type 19
 }
 
 
-@pytest.mark.parametrize("nn", [10, 15, 20])
+@pytest.mark.parametrize("nn", [10, 13, 15, 20])
 def test_quadratic_solids_vs_reference_goldens(nn):
-    """TETRA10 / WEDGE15 / HEXA20 (tests/golden/elem_solid2.npz) incl. the HEXA20 finite-difference quirk."""
-    g = golden("elem_solid2")
+    """TETRA10 / WEDGE15 / HEXA20 (tests/golden/elem_solid2.npz) incl. the HEXA20 finite-difference quirk, and
+    PYRAMID13 (tests/golden/elem_pyr13.npz, elements/SOLID.py:1221-1537)."""
+    g = golden("elem_pyr13" if nn == 13 else "elem_solid2")
     xyz, props = g[f"xyz{nn}"], g[f"props{nn}"]
     pid = np.arange(xyz.shape[0], dtype=np.int32)
     o = _run(nn, xyz, pid, props, want_K=True, want_M=True, body=g["body"], sigma=g[f"sigma{nn}"])
@@ -113,7 +116,7 @@ def test_quadratic_solids_vs_reference_goldens(nn):
     assert np.array_equal(o["K"], np.transpose(o["K"], (0, 2, 1)))
 
 
-@pytest.mark.parametrize("nn", [10, 15, 20])
+@pytest.mark.parametrize("nn", [10, 13, 15, 20])
 def test_quadratic_solids_vs_oracle_random(oracle, nn):
     import fem_shell_amd as fsa
     from fem_shell_amd.properties import solid_row

@@ -44,12 +44,14 @@ def _cmp(res, ref, tag, solid, worst):
         assert err < tol, (tag, k, err)
 
 
-@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex", "q2"])
+@pytest.mark.parametrize("case", ["smix", "quad", "tri", "somix", "hex", "q2", "p13"])
 def test_stress_recovery_golden(case):
     g, ref = golden("asm_ref"), golden("stress_ref")
+    if case == "p13":       # HEXA20 + PYRAMID13 (tools/gen_golden_pyr13.py)
+        g, ref = golden("asm_p13"), golden("stress_p13")
     mesh, asm = build(case, g)
     pre = case + "_"
-    solid = case in ("somix", "hex", "q2")
+    solid = case in ("somix", "hex", "q2", "p13")
     sr = StressRecovery(asm, ref[pre + "u"])
     assert sr.n_nodes == mesh.node_count and sr.n_elements == mesh.conn.shape[0]
     worst = {}

@@ -171,12 +171,12 @@ def test_solids_vs_reference(oracle, nn):
         assert abs(g["M6"][0][0::3, 0::3].sum() / (props[0, 36] * vol) - 2.0) < 1e-12
 
 
-@pytest.mark.parametrize("nn", [10, 15, 20])
+@pytest.mark.parametrize("nn", [10, 13, 15, 20])
 def test_quadratic_solids_vs_reference(oracle, nn):
-    """TETRA10 / WEDGE15 / HEXA20 K, M, body_load, K_G (elements/SOLID.py:832-1059, 1600-1708, 1821-1946).
-    HEXA20 uses the reference's forward-difference derivatives (h = 1e-8): parity needs bit-identical
+    """TETRA10 / PYRAMID13 / WEDGE15 / HEXA20 K, M, body_load, K_G (elements/SOLID.py:832-1059, 1221-1537, 1600-1708,
+    1821-1946).  HEXA20 uses the reference's forward-difference derivatives (h = 1e-8): parity needs bit-identical
     shape values, which the restatement reproduces (same operation order, libm pow)."""
-    g = golden("elem_solid2")
+    g = golden("elem_pyr13" if nn == 13 else "elem_solid2")
     xyz, props = g[f"xyz{nn}"], g[f"props{nn}"]
     pid = np.arange(xyz.shape[0], dtype=np.int32)
     o = oracle.solid_batch(nn, xyz, pid, props, want_K=True, want_M=True, body=g["body"], sigma=g[f"sigma{nn}"])
@@ -193,8 +193,8 @@ def test_quadratic_solid_tables_bitwise():
     import ctypes
     from fem_shell_amd import _lib
     lib = _lib.load()
-    g = golden("solid2_tables")
-    for nn in (10, 15, 20):
+    for nn in (10, 13, 15, 20):
+        g = golden("elem_pyr13" if nn == 13 else "solid2_tables")
         ng = ctypes.c_int32(0)
         pts, w, v = np.zeros((27, 3)), np.zeros(27), np.zeros(27 * nn * 4)
         assert lib.fs_solid2_table(nn, pts.ctypes.data, w.ctypes.data, v.ctypes.data, ctypes.byref(ng)) == 0
