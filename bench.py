@@ -190,7 +190,7 @@ def hex8_leg(torch, steps=5):
                 "solid_kernel<8>": {"kernel_ms": k_ms, "bound": "valu_fp64", "achieved": E * flop / (k_ms * 1e-3) / 1e12,
                                     "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                                     "frac": E * flop / (k_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "flop_per_element": flop},
-                "csr_numeric_desc3_row_kernel": {"kernel_ms": a_ms, "bound": "hbm", "achieved": E * a_bytes / (a_ms * 1e-3) / 1e9,
+                "csr_numeric_desc3_lds_kernel": {"kernel_ms": a_ms, "bound": "hbm", "achieved": E * a_bytes / (a_ms * 1e-3) / 1e9,
                                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                  "frac": E * a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                                  "bytes_per_element": a_bytes}}}

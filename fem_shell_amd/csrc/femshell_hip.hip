@@ -2517,58 +2517,58 @@ __global__ void seg_gather_sum_kernel(const double *__restrict__ vals, const int
     }
 }
 
-// d = 3 (solids): one thread per (block, row k): three entries per thread instead of one -- a third of the threads,
-// descriptor reads and address arithmetic of a thread-per-entry kernel; same sums in the same element order.
-__global__ __launch_bounds__(256) void csr_numeric_desc3_row_kernel(const double *__restrict__ vals,
+// d = 3 (solids), thread per ENTRY: workgroup = 28 node-pair blocks x 9 lanes.  The 28 descriptors reach the lanes
+// through LDS (84 lanes x 16 B instead of 48 B per lane); the 9 lanes of a block read the 72 contiguous bytes of a
+// source block with one instruction per contribution -- a transposed contribution is the same 72 bytes in another
+// lane order, so no strided pieces and no second pass -- and workgroups walk the blocks XCD by XCD like the d = 6
+// kernel.  Same sums in the same element order as the thread-per-row kernel it replaced
+// (tools/exp/parked_kernels_r02.inc.txt; 2.46 -> 2.23 ms on 1 048 576 HEXA8, bitwise equal).
+__global__ __launch_bounds__(256) void csr_numeric_desc3_lds_kernel(const double *__restrict__ vals,
                                                                     const fs_blk_desc *__restrict__ desc,
                                                                     const int64_t *__restrict__ contrib,
                                                                     int64_t nblk, double *__restrict__ data) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblk * 3) return;
-    const int64_t b = t / 3;
-    const int k = (int)(t - b * 3);
-    const fs_blk_desc dsc = desc[b];
-    double v0, v1, v2;
+    constexpr int TPB = 9, BPW = 28;
+    __shared__ double2 s_desc[BPW * 3];
+    const int tid = threadIdx.x;
+    const int64_t per_xcd = (gridDim.x + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t b0 = wg * BPW;
+    if (b0 >= nblk) return;
+    if (tid < BPW * 3 && b0 * 3 + tid < nblk * 3)
+        s_desc[tid] = reinterpret_cast<const double2 *>(desc)[b0 * 3 + tid];
+    __syncthreads();
+    const int bl = tid / TPB, r = tid - bl * TPB;
+    if (bl >= BPW || b0 + bl >= nblk) return;
+    const int k = r / 3, l = r - k * 3;
+    const int rt = l * 3 + k;                   // the entry this lane takes from a transposed contribution
+    const fs_blk_desc dsc = reinterpret_cast<const fs_blk_desc *>(s_desc)[bl];
+    double v;
     if (dsc.cnt <= 4) {
-        double x[4][3];
+        double x[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int64_t cc = dsc.c[c];
-            const double *src = vals + (cc >> 1) * 9;
-            const bool tr = cc & 1;
-            x[c][0] = (c < dsc.cnt) ? src[tr ? k : 3 * k] : 0.0;
-            x[c][1] = (c < dsc.cnt) ? src[tr ? 3 + k : 3 * k + 1] : 0.0;
-            x[c][2] = (c < dsc.cnt) ? src[tr ? 6 + k : 3 * k + 2] : 0.0;
+            x[c] = (c < dsc.cnt) ? vals[(cc >> 1) * 9 + ((cc & 1) ? rt : r)] : 0.0;
         }
-        v0 = ((x[0][0] + x[1][0]) + x[2][0]) + x[3][0];   // element order == reference insertion order
-        v1 = ((x[0][1] + x[1][1]) + x[2][1]) + x[3][1];
-        v2 = ((x[0][2] + x[1][2]) + x[2][2]) + x[3][2];
+        v = ((x[0] + x[1]) + x[2]) + x[3];      // element order == reference insertion order
     } else {
-        // more than 4 contributions (the diagonal block of a node shared by up to 8 hexahedra): batches of 8 with
-        // all index loads, then all value loads, in flight together -- two dependent round trips per batch instead
-        // of two per contribution; the sum still runs in element order
-        v0 = v1 = v2 = 0.0;
+        // more than 4 contributions (the diagonal block of a node shared by 8 hexahedra, tetrahedral meshes): batches
+        // of 8 with all index loads, then all value loads, in flight together; the sum still runs in element order
+        v = 0.0;
         const int64_t lo = dsc.c[0], hi = lo + dsc.cnt;
         for (int64_t q0 = lo; q0 < hi; q0 += 8) {
             int64_t cc[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) cc[u] = (q0 + u < hi) ? contrib[q0 + u] : 0;
-            double y[8][3];
+            double y[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const double *src = vals + (cc[u] >> 1) * 9;
-                const bool tr = cc[u] & 1, on = q0 + u < hi;
-                y[u][0] = on ? src[tr ? k : 3 * k] : 0.0;
-                y[u][1] = on ? src[tr ? 3 + k : 3 * k + 1] : 0.0;
-                y[u][2] = on ? src[tr ? 6 + k : 3 * k + 2] : 0.0;
-            }
+            for (int u = 0; u < 8; u++) y[u] = (q0 + u < hi) ? vals[(cc[u] >> 1) * 9 + ((cc[u] & 1) ? rt : r)] : 0.0;
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                if (q0 + u < hi) { v0 = v0 + y[u][0]; v1 = v1 + y[u][1]; v2 = v2 + y[u][2]; }
+                if (q0 + u < hi) v = v + y[u];
         }
     }
-    double *dst = data + dsc.dst + (int64_t)k * dsc.stride;
-    dst[0] = v0; dst[1] = v1; dst[2] = v2;
+    data[dsc.dst + (int64_t)k * dsc.stride + l] = v;
 }
 
 // LDS-staged descriptor assembly (d = 6): workgroup = 14 node-pair blocks x 18 lanes.
@@ -3096,7 +3096,7 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
         hipLaunchKernelGGL(csr_numeric_desc6_lds_kernel, dim3(8 * grid_for(nblk, 14 * 8, INT32_MAX / 8)), dim3(256), 0, s,
                            vals, desc, contrib, nblk, data);
     } else if (d == 3) {
-        hipLaunchKernelGGL(csr_numeric_desc3_row_kernel, dim3(grid_for(nblk * 3, 256, INT32_MAX)), dim3(256), 0, s,
+        hipLaunchKernelGGL(csr_numeric_desc3_lds_kernel, dim3(8 * grid_for(nblk, 28 * 8, INT32_MAX / 8)), dim3(256), 0, s,
                            vals, desc, contrib, nblk, data);
     } else {
         return fail(FS_EINVAL, "fs_csr_numeric_desc: d must be 3 or 6");
