@@ -129,7 +129,15 @@ struct QuadElem {       // per-element results of stage 1 that stage 2 needs bes
     double gt[6][3];    // tying tangents g_r(A), g_r(B), g_s(C), g_s(D), g_r(E), g_s(E) in the element frame
     double i00, i01, i11;   // Kbb^-1 (zero when singular: no condensation)
     int st;             // FS_ST_* bits
+#ifdef FS_FUSED_TIMING
+    unsigned long long tacc[8], tick;
+#endif
 };
+#ifdef FS_FUSED_TIMING
+#define FS_T1(ph) do { const unsigned long long t_ = __builtin_readcyclecounter(); el.tacc[ph] += t_ - el.tick; el.tick = t_; } while (0)
+#else
+#define FS_T1(ph) do { } while (0)
+#endif
 
 // Stage 1 for Gauss point g of the element held by the 4 lanes of a quad: bit-faithful geometry, then the data of this
 // Gauss point -> LDS image `lds` (layout IM_* above, element Q of the 16-element tile), bubble blocks and membrane
@@ -137,7 +145,9 @@ struct QuadElem {       // per-element results of stage 1 that stage 2 needs bes
 // All four lanes of every quad must be active.  any_coupled: uniform over the quad.
 __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_shell_prop *pr, bool coupled,
                                             bool any_coupled, int g, int Q, double *lds, QuadGeom &geo, QuadElem &el) {
+    FS_T1(7);
     quad_geometry(x, geo);
+    FS_T1(0);
     const double xi = (g == 1 || g == 2) ? kGP : -kGP;
     const double eta = (g >= 2) ? kGP : -kGP;
     double dxi[4], deta[4];
@@ -166,6 +176,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
     }
 
+    FS_T1(1);
     double *im = lds + Q;
     double (&S)[15] = el.S;
     double kbb00, kbb01, kbb11;
@@ -220,6 +231,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             for (int t = 0; t < 5; t++)
                 for (int u = t; u < 5; u++) S[n++] = W[0][t] * CW[0][u] + W[1][t] * CW[1][u] + W[2][t] * CW[2][u];
         }
+        FS_T1(2);
         // coupling cores U_j = detJ W^T (Bl Bk_j)  (MITC4_composite.py:210-248, nodal-only form)
         if (any_coupled) {
             double Bl[3][3];
@@ -238,6 +250,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
                     }
             }
         }
+        FS_T1(3);
         // ---- MITC4 edge-tied shear (MITC4.py:792-878) ----
         const auto &xl = geo.xl;
         double Ax, Bx, Cx, Ay, By, Cy;
@@ -280,6 +293,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         const double w0[4] = {me, me, pe, pe}, w1[4] = {mx, px, px, mx};
         const double h0[4] = {-0.5, 0.5, 0.5, -0.5};  // G row of eta-edges: w coefficient
         const double h1[4] = {-0.5, -0.5, 0.5, 0.5};  // G row of xi-edges: w coefficient
+        FS_T1(4);
         // ---- bubble enrichment (MITC4.py:214-222, 880-907): partial Knb, Kbb of this GP ----
         const double Cb00 = pr->D[0], Cb01 = pr->D[1], Cb02 = pr->D[2];
         const double Cb10 = pr->D[3], Cb11 = pr->D[4], Cb12 = pr->D[5];
@@ -322,6 +336,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
         kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
     }
+    FS_T1(5);
     for (int n = 0; n < 15; n++) S[n] = quad_sum(S[n]);
     kbb00 = quad_sum(kbb00); kbb01 = quad_sum(kbb01); kbb11 = quad_sum(kbb11);
     st |= __builtin_amdgcn_update_dpp(0, st, 0xB1, 0xF, 0xF, true);
@@ -335,6 +350,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
     el.i01 = cond_ok ? divr(-kbb01, kdet, rkdet) : 0.0;
     el.i11 = cond_ok ? divr(kbb00, kdet, rkdet) : 0.0;
     el.st = st;
+    FS_T1(6);
 }
 
 // Shape-function derivatives and edge-tied shear rows of node n at Gauss point (xg, yg), rebuilt from the compact
@@ -624,9 +640,14 @@ __device__ __forceinline__ double row_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// s_pid entry of an element slot: property row | FS_SLOT_COUPLED when the row has membrane-bending coupling
+constexpr int FS_SLOT_COUPLED = 1 << 30;
+
+// any_coupled: some contribution of the calling WAVE belongs to a coupled element (wave-uniform; the coupling terms of
+// the others add products with zero cores to +0.0, i.e. the same bits as skipping them)
 template <bool COUPLED>
 __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const int *s_pid,
-                                           const fs_shell_prop *__restrict__ props, double (&Y)[36]) {
+                                           const fs_shell_prop *__restrict__ props, bool any_coupled, double (&Y)[36]) {
     using LY = FusedLayout<COUPLED>;
     const int slot = FS_EV_SLOT(ev), ti = FS_EV_TI(ev), tj = FS_EV_TJ(ev);
     const int T = slot >> 4, Q = slot & 15;
@@ -641,17 +662,24 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
     for (int t = 0; t < 18; t++) (&gt[0][0])[t] = ex[(IM_GT + t) << 4];
     for (int t = 0; t < 9; t++) (&R[0][0])[t] = ex[(IM_R + t) << 4];
     const double i00 = ex[(IM_INV + 0) << 4], i01 = ex[(IM_INV + 1) << 4], i11 = ex[(IM_INV + 2) << 4];
-    const fs_shell_prop *pr = props + s_pid[slot];
+    const fs_shell_prop *pr = props + (s_pid[slot] & (FS_SLOT_COUPLED - 1));
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
     double G[6][6];
-    quad_pair_block(img, Q, ti, tj, ti == tj, Sf, gt, R, i00, i01, i11, Cb, Cs, kd, COUPLED, G);
+    quad_pair_block(img, Q, ti, tj, ti == tj, Sf, gt, R, i00, i01, i11, Cb, Cs, kd, COUPLED && any_coupled, G);
     const bool tr = FS_EV_TR(ev);
     for (int k = 0; k < 6; k++)
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
 }
 
+#ifdef FS_FUSED_TIMING
+__device__ unsigned long long g_fused_t[16];
+#define FS_TICK(ph) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    acc_[ph] += t_ - tick_; tick_ = t_; } while (0)
+#else
+#define FS_TICK(ph) do { } while (0)
+#endif
 template <bool COUPLED, int SP>
 __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
@@ -688,6 +716,13 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         for (int t = 0; t < 6; t++) { const double2 v = xp[t]; (&x[0][0])[2 * t] = v.x; (&x[0][0])[2 * t + 1] = v.y; }
         pid = prop_id[e];
     }
+    // flags of the element's property row: needed at the very start of stage 1 (wave-uniform coupling switch), so they
+    // travel one patch ahead like the coordinates
+    uint32_t pflags = props[safe_pid(pid, n_props)].flags;
+#ifdef FS_FUSED_TIMING
+    unsigned long long acc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
     for (;;) {
         // this lane's record of the first round: fetched now, used after stage 1
         int4 pa = make_int4(-1, -1, -1, -1), pb = pa, pc4 = make_int4(0, 0, 0, 0), pd = make_int4(0, 0, 0, -1);
@@ -701,16 +736,28 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             int bad = 0;
             if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
             const fs_shell_prop *pr = props + pid;
-            const bool flagged = (pr->flags & FS_PROP_COUPLED) != 0;
+            const bool flagged = (pflags & FS_PROP_COUPLED) != 0;
             if (!COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
             double *img = lds + wave * LY::TILE;
             QuadGeom geo;
             QuadElem el;
-            quad_stage1(x, pr, COUPLED && flagged, COUPLED, g, Q, img, geo, el);
+            // the coupling cores are formed only by waves that hold a coupled element; the others zero their part of the
+            // image (lane g owns the rows of node g, as in quad_stage1)
+            const bool wave_coupled = COUPLED && __any(flagged);
+#ifdef FS_FUSED_TIMING
+            for (int t = 0; t < 8; t++) el.tacc[t] = 0;
+            el.tick = __builtin_readcyclecounter();
+#endif
+            quad_stage1(x, pr, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
+#ifdef FS_FUSED_TIMING
+            for (int t = 0; t < 7; t++) acc_[7 + t] += el.tacc[t];
+#endif
             double *ex = img + Q;
+            if (COUPLED && !wave_coupled)
+                for (int t = 0; t < 10; t++) ex[(IM_U + t * 4 + g) << 4] = 0.0;
             if (g == 0) {
                 for (int n = 0; n < 15; n++) ex[(IM_S + n) << 4] = el.S[n];
-                s_pid[slot] = pid;
+                s_pid[slot] = pid | ((COUPLED && flagged) ? FS_SLOT_COUPLED : 0);
                 if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
             } else if (g == 1) {
                 for (int t = 0; t < 18; t++) ex[(IM_GT + t) << 4] = (&el.gt[0][0])[t];
@@ -722,7 +769,9 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 ex[(IM_INV + 0) << 4] = el.i00; ex[(IM_INV + 1) << 4] = el.i01; ex[(IM_INV + 2) << 4] = el.i11;
             }
         }
+        FS_TICK(0);
         __syncthreads();
+        FS_TICK(1);
 
         // header and element index of the next patch (its coordinates follow under the last round's stores)
         const int64_t pn = p + wpx;
@@ -737,6 +786,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         }
         double xn[12];
         int pidn = 0;
+        uint32_t pflagsn = 0;
 
         // ---------------- stage 2: two contributions per lane, chained lanes for blocks with more ----------------
         for (int64_t rb = r0; rb < r1; rb += 256) {
@@ -754,14 +804,20 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             // like the descriptor kernel's loop), Y = second one (-0.0 when absent: adds nothing)
             double X[36], Y[36];
             const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
+            const bool last_round = more && rb + 256 >= r1;
             const bool a0 = FS_EV_ACTIVE(ev0), a1 = FS_EV_ACTIVE(ev1);
-            if (a0) fused_eval<COUPLED>(ev0, lds, s_pid, props, Y);
+            const bool c0 = COUPLED && __any(a0 && (s_pid[FS_EV_SLOT(ev0)] & FS_SLOT_COUPLED));
+            const bool c1 = COUPLED && __any(a1 && (s_pid[FS_EV_SLOT(ev1)] & FS_SLOT_COUPLED));
+            if (a0) fused_eval<COUPLED>(ev0, lds, s_pid, props, c0, Y);
             else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
             for (int t = 0; t < 36; t++) X[t] = z0 + Y[t];
-            if (a1) fused_eval<COUPLED>(ev1, lds, s_pid, props, Y);
+            if (last_round) pidn = prop_id[en];      // under the second evaluation; its property flags are fetched after it
+            FS_TICK(2);
+            if (a1) fused_eval<COUPLED>(ev1, lds, s_pid, props, c1, Y);
             else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
+            FS_TICK(3);
             // sums in element order: one lane x0 + x1; a lane chained to its left neighbour (R_left + x2) + x3, ...
             // Lanes that carry two single-contribution blocks keep X and Y apart.
             const bool two = (fl & FS_FL_OUT1) != 0, chain = (fl & FS_FL_CHAIN) != 0;
@@ -783,11 +839,12 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             }
             // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
             // arrive while the stores below are issued
-            if (more && rb + 256 >= r1) {
+            if (last_round) {
                 const double2 *xp = reinterpret_cast<const double2 *>(xyz + en * 12);
                 for (int t = 0; t < 6; t++) { const double2 v = xp[t]; xn[2 * t] = v.x; xn[2 * t + 1] = v.y; }
-                pidn = prop_id[en];
+                pflagsn = props[safe_pid(pidn, n_props)].flags;
             }
+            FS_TICK(4);
             // ---- stores: through a wave-private LDS staging area, one block row at a time, so that the wave's store
             // instructions sweep the memory in address order -- the plan numbers the blocks a wave stores (direct and
             // transposed) by address (`slot`), neighbouring slots are neighbouring 48-byte row pieces of the CSR rows of
@@ -848,10 +905,16 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        FS_TICK(5);
+#ifdef FS_FUSED_TIMING
+        if (!more && lane == 0)
+            for (int ph = 0; ph < 14; ph++) atomicAdd(&g_fused_t[ph], acc_[ph]);
+#endif
         if (!more) break;
         __syncthreads();        // every wave is done with the image: stage 1 of the next patch may overwrite it
-        p = pn; ne = nen; e = en; pid = pidn; r0 = r0n; r1 = r1n;
+        p = pn; ne = nen; e = en; pid = pidn; pflags = pflagsn; r0 = r0n; r1 = r1n;
         for (int t = 0; t < 12; t++) (&x[0][0])[t] = xn[t];
+        FS_TICK(6);
     }
 }
 
@@ -3235,6 +3298,17 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
     FS_LAUNCH_CHECK("fused_quad_k_kernel");
     return FS_OK;
 }
+
+#ifdef FS_FUSED_TIMING
+int fs_debug_fused_timing(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_t), sizeof(unsigned long long) * 16) != hipSuccess) return FS_EHIP;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fused_t), z, sizeof z) != hipSuccess) return FS_EHIP;
+    }
+    return FS_OK;
+}
+#endif
 
 int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream) {
     if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_gather_dofs: n < 0");

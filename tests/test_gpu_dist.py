@@ -264,3 +264,44 @@ def test_distributed_element_blocks_of_any_mesh():
     for rank, n, err in res:
         assert err is None, err
     assert sum(n for _, n, _ in res) == 6 * 121
+
+
+def _worker_nccl(port, q):
+    """One rank, backend nccl (= RCCL): the process-group calls of the bench's N > 1 path on device tensors."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import bench
+        r = bench.plate_run(torch, dist, 0, 1, 48, 40, 3, 1, True)
+        tt = torch.tensor([r["dt"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        per_rank = [None]
+        dist.all_gather_object(per_rank, {"rank": 0, "exchange_ms": r["exchange_ms"]})
+        q.put((r["E"], r["nnz"], r["overlap"], per_rank[0]["rank"], None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((0, 0, None, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_backend_world_1():
+    """The RCCL transport needs one GPU per rank, so a one-GPU box can only run it with ONE rank: this covers the
+    process-group set-up of `bench.py --gpus N` (init with device_id, the bounding-box all_gather on device tensors,
+    all_reduce, barrier, all_gather_object, side-stream bookkeeping with no neighbour); the send / recv pairs themselves
+    stay unmeasured on hardware."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(port, q))
+    p.start()
+    E, nnz, overlap, rank, err = q.get(timeout=240)
+    p.join(30)
+    assert err is None, err
+    assert E == 48 * 40 and nnz == 36 * (3 * 49 - 2) * (3 * 41 - 2) and overlap is True and rank == 0
