@@ -160,17 +160,19 @@ int64_t layout_patch(std::vector<TaskRec> &tasks, fs_fused_rec *rec, std::vector
         if (k.dst_t >= 0) outs.push_back({k.dst_t, (int)last, 1, which});
     }
     for (int64_t l = 0; l < lanes; l++) rec[l].flags |= mc[l >> 6] << 8;
-    // staging slots: the blocks a wave stores, numbered by (class, address)
+    // staging slots: the blocks a wave emits get a slot each, numbered by (output 0 / 1, address of the direct copy);
+    // the transposed copies are read back from the same slot and get a rank of their own, by address of the copy
     std::sort(outs.begin(), outs.end(), [](const Out &a, const Out &b) {
         const int wa = a.lane >> 6, wb = b.lane >> 6;
         if (wa != wb) return wa < wb;
-        const int ca = a.which == 1 ? 2 : a.kind, cb = b.which == 1 ? 2 : b.kind;
+        if (a.kind != b.kind) return a.kind < b.kind;
+        const int ca = a.kind == 0 ? a.which : 0, cb = b.kind == 0 ? b.which : 0;
         if (ca != cb) return ca < cb;
         return a.addr < b.addr;
     });
     int rank = 0;
     for (size_t i = 0; i < outs.size(); i++) {
-        rank = (i > 0 && (outs[i].lane >> 6) == (outs[i - 1].lane >> 6)) ? rank + 1 : 0;
+        rank = (i > 0 && (outs[i].lane >> 6) == (outs[i - 1].lane >> 6) && outs[i].kind == outs[i - 1].kind) ? rank + 1 : 0;
         if (rank > 254) return -1;
         const uint32_t shift = 8u * (2u * (uint32_t)outs[i].which + (uint32_t)outs[i].kind);
         uint32_t &sl = rec[outs[i].lane].slots;

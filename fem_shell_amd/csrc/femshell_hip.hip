@@ -626,6 +626,8 @@ struct FusedLayout {
     static constexpr int TILE = (COUPLED ? IM_NC_COUPLED : IM_NC) * 16;     // doubles per 16-element tile
 };
 
+constexpr int FZ_SLOT = 21;               // staging slot of the fused kernel, in 16-byte pieces
+
 #define FS_EV_SLOT(ev) ((int)((ev) & 255u))
 #define FS_EV_TI(ev) ((int)(((ev) >> 8) & 3u))
 #define FS_EV_TJ(ev) ((int)(((ev) >> 10) & 3u))
@@ -674,7 +676,7 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
 }
 
 #ifdef FS_FUSED_TIMING
-__device__ unsigned long long g_fused_t[16];
+__device__ unsigned long long g_fused_t[24];
 #define FS_TICK(ph) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
     acc_[ph] += t_ - tick_; tick_ = t_; } while (0)
 #else
@@ -693,7 +695,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     constexpr int NT = 4;                       // 16-element tiles of the LDS image: one per wave
     __shared__ double lds[NT * LY::TILE];
     __shared__ int s_pid[NT * 16];
-    __shared__ double2 s_stage[4 * 19 * SP];    // per wave: SP staging slots of 19 x 16 bytes
+    __shared__ double2 s_stage[4 * FZ_SLOT * SP];   // per wave: SP staging slots of 21 x 16 bytes
+    __shared__ unsigned char s_tab[4 * 128];        // per wave: rank of a transposed copy -> staging slot of its block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Q = lane >> 2, g = lane & 3, slot = wave * 16 + Q;
     // PERSISTENT workgroups: workgroup w lives on XCD w & 7 (round-robin dispatch) and walks through that XCD's
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     // travel one patch ahead like the coordinates
     uint32_t pflags = props[safe_pid(pid, n_props)].flags;
 #ifdef FS_FUSED_TIMING
-    unsigned long long acc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc_[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -845,54 +848,57 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 pflagsn = props[safe_pid(pidn, n_props)].flags;
             }
             FS_TICK(4);
-            // ---- stores: through a wave-private LDS staging area, one block row at a time, so that the wave's store
-            // instructions sweep the memory in address order -- the plan numbers the blocks a wave stores (direct and
-            // transposed) by address (`slot`), neighbouring slots are neighbouring 48-byte row pieces of the CSR rows of
-            // consecutive nodes.  A lane that stores its own block touches 36 different lines with 36 instructions.
-            const int s0d = (fl & FS_FL_OUT0) ? (int)(slots & 255u) : 255;
-            const int s0t = (fl & FS_FL_OUT0) ? (int)((slots >> 8) & 255u) : 255;
-            const int s1d = two ? (int)((slots >> 16) & 255u) : 255;
-            const int s1t = two ? (int)((slots >> 24) & 255u) : 255;
-            const int ns = __popcll(__ballot(s0d != 255)) + __popcll(__ballot(s0t != 255)) +
-                           __popcll(__ballot(s1d != 255)) + __popcll(__ballot(s1t != 255));
-            // staging slot = 19 x 16 bytes: the block's 18 pieces (row k, piece c at 3 k + c) and (dst, stride); the
-            // odd slot size keeps the 8-lane groups of ds_write_b128 on distinct banks
-            double2 *stg = s_stage + wave * (19 * SP);
+            // ---- stores: through a wave-private LDS staging area.  Every block a lane emits goes to a slot (numbered by the
+            // plan in address order of the DIRECT copy) and is read back twice: as 48-byte row pieces of block (I,J), one
+            // store instruction per row k covering row k of 21 blocks with neighbouring lanes on neighbouring pieces, and
+            // -- through a rank table in address order of the TRANSPOSED copies -- as the row pieces of block (J,I), taken
+            // from the same slot with transposed indexing.  A lane that stored its own block from registers would touch
+            // 36 different lines with 36 instructions.
+            const bool out0 = (fl & FS_FL_OUT0) != 0;
             const int64_t dst0 = ((int64_t)(uint32_t)ra.x) | ((int64_t)ra.y << 32), dst1 = ((int64_t)(uint32_t)ra.z) | ((int64_t)ra.w << 32);
             const int64_t dst0t = ((int64_t)(uint32_t)rb4.x) | ((int64_t)rb4.y << 32), dst1t = ((int64_t)(uint32_t)rb4.z) | ((int64_t)rb4.w << 32);
-            for (int s0 = 0; s0 < ns; s0 += SP) {
-                const int q0d = s0d - s0, q0t = s0t - s0, q1d = s1d - s0, q1t = s1t - s0;
+            const int s0d = out0 ? (int)(slots & 255u) : 255;
+            const int s0t = (out0 && dst0t >= 0) ? (int)((slots >> 8) & 255u) : 255;
+            const int s1d = two ? (int)((slots >> 16) & 255u) : 255;
+            const int s1t = (two && dst1t >= 0) ? (int)((slots >> 24) & 255u) : 255;
+            const int nd = __popcll(__ballot(s0d != 255)) + __popcll(__ballot(s1d != 255));
+            const int ntr = __popcll(__ballot(s0t != 255)) + __popcll(__ballot(s1t != 255));
+            // staging slot = 21 x 16 bytes: the block's 18 pieces (row k, piece c at 3 k + c), (dst, stride), (dst_t,
+            // stride_t), one spare; the odd slot size keeps the 8-lane groups of ds_write_b128 on distinct banks
+            double2 *stg = s_stage + wave * (FZ_SLOT * SP);
+            unsigned char *tab = s_tab + wave * 128;
+            FS_TICK(14);
+            for (int s0 = 0; s0 < nd; s0 += SP) {
+                if (nd > SP) {      // several passes: ranks whose block is not staged in this pass must read as "none"
+                    tab[lane] = 255; tab[lane + 64] = 255;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const int q0d = s0d - s0, q1d = s1d - s0;
                 if (s0d != 255 && q0d >= 0 && q0d < SP) {
-                    double2 *sp = stg + q0d * 19;
+                    double2 *sp = stg + q0d * FZ_SLOT;
                     for (int t = 0; t < 18; t++) sp[t] = make_double2(X[2 * t], X[2 * t + 1]);
                     sp[18] = make_double2(__longlong_as_double(dst0), __longlong_as_double((long long)rc.x));
-                }
-                if (s0t != 255 && q0t >= 0 && q0t < SP) {
-                    double2 *sp = stg + q0t * 19;
-                    for (int k = 0; k < 6; k++)
-                        for (int m = 0; m < 3; m++) sp[k * 3 + m] = make_double2(X[(2 * m) * 6 + k], X[(2 * m + 1) * 6 + k]);
-                    sp[18] = make_double2(__longlong_as_double(dst0t), __longlong_as_double((long long)rc.z));
+                    sp[19] = make_double2(__longlong_as_double(dst0t), __longlong_as_double((long long)rc.z));
+                    if (s0t != 255) tab[s0t] = (unsigned char)q0d;
                 }
                 if (s1d != 255 && q1d >= 0 && q1d < SP) {
-                    double2 *sp = stg + q1d * 19;
+                    double2 *sp = stg + q1d * FZ_SLOT;
                     for (int t = 0; t < 18; t++) sp[t] = make_double2(Y[2 * t], Y[2 * t + 1]);
                     sp[18] = make_double2(__longlong_as_double(dst1), __longlong_as_double((long long)rc.y));
-                }
-                if (s1t != 255 && q1t >= 0 && q1t < SP) {
-                    double2 *sp = stg + q1t * 19;
-                    for (int k = 0; k < 6; k++)
-                        for (int m = 0; m < 3; m++) sp[k * 3 + m] = make_double2(Y[(2 * m) * 6 + k], Y[(2 * m + 1) * 6 + k]);
-                    sp[18] = make_double2(__longlong_as_double(dst1t), __longlong_as_double((long long)rc.w));
+                    sp[19] = make_double2(__longlong_as_double(dst1t), __longlong_as_double((long long)rc.w));
+                    if (s1t != 255) tab[s1t] = (unsigned char)q1d;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // piece pc -> (block pc / 3, piece pc % 3): one store instruction per row k covers row k of 21 blocks,
-                // neighbouring lanes on neighbouring 16-byte pieces
+                FS_TICK(15);
+                // direct copies: piece pc -> (block pc / 3, piece pc % 3)
+                const int nhere = (nd - s0 < SP) ? nd - s0 : SP;
                 for (int q = 0; q < (3 * SP + 63) / 64; q++) {
                     const int pc = q * 64 + lane;
                     const int bk = (pc * 21846) >> 16, cc = pc - 3 * bk;
-                    if (pc < 3 * SP && s0 + bk < ns) {
-                        const double2 *sp = stg + bk * 19;
+                    if (pc < 3 * nhere) {
+                        const double2 *sp = stg + bk * FZ_SLOT;
                         const double2 t = sp[18];
                         double *d = data + (int64_t)__double_as_longlong(t.x) + 2 * cc;
                         const int64_t str = (int64_t)__double_as_longlong(t.y);
@@ -901,14 +907,38 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                         for (int k = 0; k < 6; k++) *reinterpret_cast<double2 *>(d + k * str) = v[k];
                     }
                 }
+                // transposed copies, in address order of the copies: rank o -> slot tab[o]; piece (row k, columns 2 cc,
+                // 2 cc + 1) of the transpose = entries (2 cc, k), (2 cc + 1, k) of the staged block
+                int tslot[(3 * 128 + 63) / 64];
+                for (int q = 0; q < (3 * 128 + 63) / 64; q++) {
+                    const int pc = q * 64 + lane;
+                    const int o = (pc * 21846) >> 16;
+                    tslot[q] = (pc < 3 * ntr) ? (int)tab[o] : 255;
+                }
+                for (int q = 0; q < (3 * 128 + 63) / 64; q++) {
+                    if (q * 64 >= 3 * ntr) break;
+                    const int pc = q * 64 + lane;
+                    const int o = (pc * 21846) >> 16, cc = pc - 3 * o;
+                    if (tslot[q] != 255) {
+                        const double2 *sp = stg + tslot[q] * FZ_SLOT;
+                        const double2 t = sp[19];
+                        double *d = data + (int64_t)__double_as_longlong(t.x) + 2 * cc;
+                        const int64_t str = (int64_t)__double_as_longlong(t.y);
+                        const double *sd = reinterpret_cast<const double *>(sp) + 12 * cc;
+                        double2 v[6];
+                        for (int k = 0; k < 6; k++) v[k] = make_double2(sd[k], sd[6 + k]);
+                        for (int k = 0; k < 6; k++) *reinterpret_cast<double2 *>(d + k * str) = v[k];
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                FS_TICK(16);
             }
         }
         FS_TICK(5);
 #ifdef FS_FUSED_TIMING
         if (!more && lane == 0)
-            for (int ph = 0; ph < 14; ph++) atomicAdd(&g_fused_t[ph], acc_[ph]);
+            for (int ph = 0; ph < 17; ph++) atomicAdd(&g_fused_t[ph], acc_[ph]);
 #endif
         if (!more) break;
         __syncthreads();        // every wave is done with the image: stage 1 of the next patch may overwrite it
@@ -3291,7 +3321,7 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
     const unsigned grid = (unsigned)wgs;
 #define FS_FUSED_LAUNCH(C)                                                                                           \
-    hipLaunchKernelGGL((fused_quad_k_kernel<C, 63>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
+    hipLaunchKernelGGL((fused_quad_k_kernel<C, 64>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
                        n_patches, pat_eptr, pat_elems, pat_rptr, recs, data, status)
     if (flags & FS_FUSED_HAS_COUPLED) FS_FUSED_LAUNCH(true); else FS_FUSED_LAUNCH(false);
 #undef FS_FUSED_LAUNCH
@@ -3301,9 +3331,9 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
 
 #ifdef FS_FUSED_TIMING
 int fs_debug_fused_timing(unsigned long long *out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_t), sizeof(unsigned long long) * 16) != hipSuccess) return FS_EHIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_t), sizeof(unsigned long long) * 24) != hipSuccess) return FS_EHIP;
     if (reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[24] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_fused_t), z, sizeof z) != hipSuccess) return FS_EHIP;
     }
     return FS_OK;

@@ -342,8 +342,10 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
  *             (0,0) and row distance of block (I,J) in `data` (as in fs_blk_desc), dst_t / stride_t those of block
  *             (J,I) (-1: none).  flags bits 8..15: length of the longest chain of the lane's wave (uniform over the
  *             wave, >= 1), bits 16..19: position of the lane in its chain.  slots: four bytes (output 0 direct,
- *             output 0 transposed, output 1 direct, output 1 transposed; 255 = none) numbering the blocks a wave
- *             stores by ascending address -- the order in which the wave's staged stores sweep memory.
+ *             output 0 transposed, output 1 direct, output 1 transposed; 255 = none).  The "direct" bytes number the
+ *             blocks a wave emits (outputs 0 first, then outputs 1, each by ascending dst): the block's staging slot;
+ *             the "transposed" bytes rank the wave's transposed copies by ascending dst_t: the order in which they
+ *             are read back from those slots, so that both sweeps of the wave's stores run through memory in order.
  *   flags     FS_FUSED_HAS_COUPLED: some property row has FS_PROP_COUPLED (0 selects the kernel without the
  *             coupling terms; a coupled row met anyway is reported as FS_ST_BAD_PROP)
  *   status    [E] FS_ST_* bits or NULL

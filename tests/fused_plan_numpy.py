@@ -149,18 +149,18 @@ class NumpyFusedQuadPlan:
         np.maximum.at(mc, lane0 >> 6, nl.astype(np.uint32))
         fl |= mc[wave_of] << FL_MAXCHAIN_SHIFT
         rec["flags"] = fl
-        # ---- staging slots: the blocks a wave stores (direct and transposed), numbered by address, so that the
-        # wave's stores run through memory in order ----
+        # ---- staging slots and store order of the blocks a wave emits (direct and transposed copies run through memory
+        # in address order) ----
         tt = np.flatnonzero(dst_t >= 0)
         o_task = np.concatenate([np.arange(nt), tt])
         o_addr = np.concatenate([dst, dst_t[tt]])
         o_kind = np.concatenate([np.zeros(nt, dtype=np.int64), np.ones(tt.shape[0], dtype=np.int64)])
         o_wave = last[o_task] >> 6
-        # inside a wave: blocks of output 0 as (I,J), then output 0 transposed, then the second blocks of two-block lanes
-        # (a staging pass then writes from one register set with most lanes active), each class by address
-        o_class = np.where(which[o_task] == 1, 2, o_kind)
-        oo = np.lexsort((o_addr, o_class, o_wave))
-        ws = o_wave[oo]
+        # inside a wave: every emitted block gets a staging slot, numbered by (output 0 / 1, address of the direct copy);
+        # the transposed copies are read back from the same slot and are ranked on their own, by address of the copy
+        o_class = np.where(o_kind == 0, which[o_task], 0)
+        oo = np.lexsort((o_addr, o_class, o_kind, o_wave))
+        ws = o_wave[oo] * 2 + o_kind[oo]
         srank = np.arange(oo.shape[0], dtype=np.int64) - np.searchsorted(ws, ws)
         if srank.size and srank.max() > 254:
             raise ValueError("more than 255 blocks stored by one wave")

@@ -12,7 +12,7 @@ asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
                                         "properties": {mesh.set_names[i]: lams[i] for i in range(16)}}})
 asm.fused_plan()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 24)()
 for _ in range(3): asm.assemble_stiffness_fused()
 torch.cuda.synchronize()
 lib.fs_debug_fused_timing(None, 1)
@@ -20,6 +20,8 @@ ms = bench.avg_ms(torch, asm.assemble_stiffness_fused, 5)
 torch.cuda.synchronize()
 lib.fs_debug_fused_timing(out, 0)
 t = np.array(list(out)[:7], dtype=np.float64)
+t2 = np.array(list(out)[14:17], dtype=np.float64)
+t[5] += t2.sum()
 t1 = np.array(list(out)[7:14], dtype=np.float64)
 names = ["stage 1 (+ record fetch issue)", "barrier after stage 1", "header prefetch, record decode, evaluation 0", "evaluation 1",
          "element-order sums (DPP)", "staging + stores", "end-of-patch barrier + hand-over"]
@@ -29,4 +31,7 @@ for n, v in zip(names, t):
 names1 = ["geometry", "tying tangents", "Jacobian store, blend, W, S partial", "coupling cores", "shear constants", "bubble + Knb partials and sums", "S / Kbb sums, Kbb^-1"]
 print("inside stage 1:")
 for n, v in zip(names1, t1):
+    print(f"  {n:46s} {100 * v / t.sum():5.1f} %   {ms * v / t.sum():.3f} ms")
+print("inside staging + stores:")
+for n, v in zip(["slot bookkeeping before the passes", "staging writes (+ wave sync)", "read-back + global stores (+ wave sync)"], t2):
     print(f"  {n:46s} {100 * v / t.sum():5.1f} %   {ms * v / t.sum():.3f} ms")
