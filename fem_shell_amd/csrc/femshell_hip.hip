@@ -145,6 +145,10 @@ struct QuadElem {       // per-element results of stage 1 that stage 2 needs bes
 // All four lanes of every quad must be active.  any_coupled: uniform over the quad.
 __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_shell_prop *pr, bool coupled,
                                             bool any_coupled, int g, int Q, double *lds, QuadGeom &geo, QuadElem &el) {
+    double Bv[9];       // coupling matrix: fetched up front, in one batch, by every lane of a wave that needs it (a load at
+                        // the point of use, under the lane's own condition, is waited for on the spot)
+    if (any_coupled)
+        for (int t = 0; t < 9; t++) Bv[t] = pr->B[t];
     FS_T1(7);
     quad_geometry(x, geo);
     FS_T1(0);
@@ -236,7 +240,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         if (any_coupled) {
             double Bl[3][3];
             for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? detJ * pr->B[a * 3 + b] : 0.0;
+                for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? detJ * Bv[a * 3 + b] : 0.0;
             for (int j = 0; j < 4; j++) {
                 double LK[3][2];
                 for (int a = 0; a < 3; a++) {
@@ -722,11 +726,29 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     // flags of the element's property row: needed at the very start of stage 1 (wave-uniform coupling switch), so they
     // travel one patch ahead like the coordinates
     uint32_t pflags = props[safe_pid(pid, n_props)].flags;
+    // headers travel TWO patches ahead (uniform scalar loads) so that the element list of the next patch can be fetched
+    // at the top of the current one without waiting for its header
+    int64_t e0n = 0, r0n = 0, r1n = 0;
+    int nen = 0;
+    if (p + wpx < pend) {
+        e0n = pat_eptr[p + wpx];
+        nen = (int)(pat_eptr[p + wpx + 1] - e0n);
+        r0n = pat_rptr[p + wpx]; r1n = pat_rptr[p + wpx + 1];
+    }
 #ifdef FS_FUSED_TIMING
     unsigned long long acc_[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
     for (;;) {
+        // element of the next patch for this lane (header already here), header of the patch after it
+        const int64_t pn = p + wpx, pnn = pn + wpx;
+        const bool more = pn < pend;
+        // (unconditional loads from clamped indices: a load inside a branch is waited for at the end of the branch)
+        const int64_t en = pat_elems[more ? e0n + ((slot < nen) ? slot : nen - 1) : 0];
+        const int64_t pq = (pnn < pend) ? pnn : p;
+        const int64_t e0nn = pat_eptr[pq];
+        const int nenn = (int)(pat_eptr[pq + 1] - e0nn);
+        const int64_t r0nn = pat_rptr[pq], r1nn = pat_rptr[pq + 1];
         // this lane's record of the first round: fetched now, used after stage 1
         int4 pa = make_int4(-1, -1, -1, -1), pb = pa, pc4 = make_int4(0, 0, 0, 0), pd = make_int4(0, 0, 0, -1);
         if (r0 + tid < r1) {
@@ -772,23 +794,19 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 ex[(IM_INV + 0) << 4] = el.i00; ex[(IM_INV + 1) << 4] = el.i01; ex[(IM_INV + 2) << 4] = el.i11;
             }
         }
+        // property id of the next patch's element: `en` has arrived under stage 1 (the empty asm keeps the compiler from
+        // forming the address, and waiting for `en`, at the top of the loop); its flags follow under the evaluations, its
+        // coordinates under the last round's stores
+        int64_t en_use = en;
+        asm volatile("" : "+v"(en_use));
+        int pidn = prop_id[en_use];
         FS_TICK(0);
         __syncthreads();
         FS_TICK(1);
 
-        // header and element index of the next patch (its coordinates follow under the last round's stores)
-        const int64_t pn = p + wpx;
-        const bool more = pn < pend;
-        int nen = 0;
-        int64_t en = 0, r0n = 0, r1n = 0;
-        if (more) {
-            const int64_t e0n = pat_eptr[pn];
-            nen = (int)(pat_eptr[pn + 1] - e0n);
-            r0n = pat_rptr[pn]; r1n = pat_rptr[pn + 1];
-            en = pat_elems[e0n + ((slot < nen) ? slot : nen - 1)];
-        }
+        // property id of the next patch's element (its flags follow under the evaluations, its coordinates under the
+        // last round's stores)
         double xn[12];
-        int pidn = 0;
         uint32_t pflagsn = 0;
 
         // ---------------- stage 2: two contributions per lane, chained lanes for blocks with more ----------------
@@ -815,12 +833,14 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
             for (int t = 0; t < 36; t++) X[t] = z0 + Y[t];
-            if (last_round) pidn = prop_id[en];      // under the second evaluation; its property flags are fetched after it
+            asm volatile("" : "+v"(pidn));                     // (wait for pidn here, not right after its load)
+            pflagsn = props[safe_pid(pidn, n_props)].flags;     // (every round: see above)
             FS_TICK(2);
             if (a1) fused_eval<COUPLED>(ev1, lds, s_pid, props, c1, Y);
             else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
             FS_TICK(3);
+            asm volatile("" :: "v"(pflagsn));      // the flags load stays above this point (it would be sunk to its use)
             // sums in element order: one lane x0 + x1; a lane chained to its left neighbour (R_left + x2) + x3, ...
             // Lanes that carry two single-contribution blocks keep X and Y apart.
             const bool two = (fl & FS_FL_OUT1) != 0, chain = (fl & FS_FL_CHAIN) != 0;
@@ -843,9 +863,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
             // arrive while the stores below are issued
             if (last_round) {
-                const double2 *xp = reinterpret_cast<const double2 *>(xyz + en * 12);
+                const double2 *xp = reinterpret_cast<const double2 *>(xyz + en_use * 12);
                 for (int t = 0; t < 6; t++) { const double2 v = xp[t]; xn[2 * t] = v.x; xn[2 * t + 1] = v.y; }
-                pflagsn = props[safe_pid(pidn, n_props)].flags;
             }
             FS_TICK(4);
             // ---- stores: through a wave-private LDS staging area.  Every block a lane emits goes to a slot (numbered by the
@@ -942,7 +961,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
 #endif
         if (!more) break;
         __syncthreads();        // every wave is done with the image: stage 1 of the next patch may overwrite it
-        p = pn; ne = nen; e = en; pid = pidn; pflags = pflagsn; r0 = r0n; r1 = r1n;
+        p = pn; ne = nen; e = en_use; pid = pidn; pflags = pflagsn; r0 = r0n; r1 = r1n;
+        e0n = e0nn; nen = nenn; r0n = r0nn; r1n = r1nn;
         for (int t = 0; t < 12; t++) (&x[0][0])[t] = xn[t];
         FS_TICK(6);
     }
