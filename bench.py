@@ -373,7 +373,35 @@ def c3_leg(torch, steps=10):
                         f"{int((asm._prop_table['flags'] & 1).sum())} with membrane-bending coupling",
             "ms_per_step": ms, "elements_per_s": E / (ms * 1e-3), "nnz": int(K.nnz),
             "fused_plan": {k: st[k] for k in ("patches", "stage1_recompute", "stage2_lane_fill")},
-            "what": "K (fused kernel) and M (element kernel + CSR assembly), row-sum lumping, centrifugal nodal loads"}
+            "what": "K and M (fused kernel, two launches), row-sum lumping, centrifugal nodal loads"}
+
+
+def mass_leg(torch, steps=10):
+    """Consistent mass matrix of the 1.25 M-element strip: the fused kernel with FS_FUSED_MASS
+    (one launch, no element mass matrices in memory) beside element kernel + assembly kernel; bitwise the same values."""
+    from fem_shell_amd import meshes
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.elements import ElementFamily
+    lams = c5_laminates()
+    mesh = meshes.jittered_plate(STRIP_NX, STRIP_NY, cell=1e-3, seed=11, n_sets=16)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
+                                            "properties": {mesh.set_names[i]: lams[i] for i in range(16)}}})
+    asm.fused_plan()
+    E = mesh.element_count
+    f_ms = avg_ms(torch, asm.assemble_mass_fused, steps)
+
+    def two():
+        asm.refresh_element_matrices(want_K=False, want_M=True, check=False)
+        return asm.assemble_mass_matrix(recompute=False, fused=False)
+
+    t_ms = avg_ms(torch, two, steps)
+    Mf, M2 = asm.assemble_mass_fused(), two()
+    same = bool((Mf.data.view(torch.int64) == M2.data.view(torch.int64)).all())
+    gbs = E * BYTES_PER_ELEM / (f_ms * 1e-3) / 1e9
+    return {"workload": f"{STRIP_NX}x{STRIP_NY}={E} element strip, consistent mass matrix",
+            "fused_ms": f_ms, "two_kernel_ms": t_ms, "elements_per_s": E / (f_ms * 1e-3), "bitwise_equal_to_two_kernel_route": same,
+            "roofline": {"kernel": "fused_quad_k_kernel<FS_OP_M>", "kernel_ms": f_ms, "bound": "hbm", "achieved": gbs,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_element": BYTES_PER_ELEM}}
 
 
 def newton_leg(torch, steps=10):
@@ -657,7 +685,7 @@ def main():
             line["measured_peaks"] = mp
             roof["frac_of_measured_hbm_copy"] = roof["achieved"] / mp["hbm_copy_GBs"]
             roof["valu_fp64"]["frac_of_measured_fma_rate"] = roof["valu_fp64"]["achieved"] / mp["fp64_fma_4_waves_per_simd_TFLOPs"]
-            for key, leg in (("hex8", hex8_leg), ("newton", newton_leg), ("c1_scordelis_lo", c1_leg),
+            for key, leg in (("mass", mass_leg), ("hex8", hex8_leg), ("newton", newton_leg), ("c1_scordelis_lo", c1_leg),
                              ("c2_hemisphere", c2_leg), ("c3_blade_like", c3_leg)):
                 log(f"leg {key}")
                 line[key] = leg(torch)

@@ -13,6 +13,7 @@ FS_STRESS_MEMBRANE, FS_STRESS_BENDING = 1, 2
 FS_SOLID_STRESS_GP, FS_SOLID_STRESS_MEAN, FS_SOLID_STRESS_NODES = 0, 1, 2
 FS_INERTIAL_CENTRIFUGAL, FS_INERTIAL_CORIOLIS, FS_INERTIAL_EULER = 1, 2, 4
 FS_FUSED_HAS_COUPLED = 1
+FS_FUSED_MASS = 2
 FS_FUSED_MAX_PATCH_ELEMS = 64
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32

@@ -407,10 +407,11 @@ class MeshAssembler:
             self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
         return self._fplan
 
-    def assemble_stiffness_fused(self, status=None) -> CsrMatrix:
+    def assemble_stiffness_fused(self, status=None, mass=False) -> CsrMatrix:
         """K straight from the coordinates in one launch: element evaluation (core/assembler.py:160-193 ->
         MITC4.K) and the ADD_VALUES loop (:287-303) fused, no element matrices in memory.  Bit-identical to
-        refresh_element_matrices() + the descriptor assembly.  `status`: optional int32 [E] device tensor."""
+        refresh_element_matrices() + the descriptor assembly.  `status`: optional int32 [E] device tensor.
+        mass=True: the consistent mass matrix the same way (FS_FUSED_MASS; MITC4.M, core/assembler.py:305-336)."""
         if not self.can_fuse:
             raise NotImplementedError("the fused kernel covers uniform MITC4+ quad meshes")
         fp = self.fused_plan()
@@ -420,10 +421,13 @@ class MeshAssembler:
         _lib.check(lib.fs_fused_assemble_quad(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
                                               len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
                                               _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]),
-                                              fp.max_patch_elems, self._fused_flags,
+                                              fp.max_patch_elems, _lib.FS_FUSED_MASS if mass else self._fused_flags,
                                               _lib.ptr(data), _lib.ptr(status), _lib.stream_ptr()),
                    "fs_fused_assemble_quad")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
+
+    def assemble_mass_fused(self) -> CsrMatrix:
+        return self.assemble_stiffness_fused(mass=True)
 
     def assemble_stiffness_matrix(self, recompute=False, fused=None) -> CsrMatrix:
         """core/assembler.py:269-303.  recompute=True re-evaluates the element matrices: on uniform MITC4+ meshes
@@ -435,8 +439,13 @@ class MeshAssembler:
             self.refresh_element_matrices(want_K=True, want_M=False)
         return self._assemble(self._K_blk)
 
-    def assemble_mass_matrix(self, recompute=False) -> CsrMatrix:
-        """core/assembler.py:305-336."""
+    def assemble_mass_matrix(self, recompute=False, fused=None) -> CsrMatrix:
+        """core/assembler.py:305-336.  On uniform MITC4+ meshes a (re-)evaluation goes through the fused kernel (no element
+        mass matrices in memory; `_me_array` still materialises them on demand); fused=False forces element kernel +
+        assembly kernel (same bits)."""
+        fused = self.use_fused if fused is None else fused
+        if (recompute or self._M_blk is None) and fused and self.can_fuse:
+            return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True)
         return self._assemble(self._M_blk)

@@ -625,9 +625,13 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
 // The result is bitwise the CSR of mitc4_k_kernel + csr_numeric_desc6_lds_kernel; HBM traffic per element drops from
 // 2 880 (blocks out) + 2 880 (blocks in) + 2 592 (CSR out) + 432 (descriptors) to 2 592 + ~330 (plan records).
 // ------------------------------------------------------------------------------------------
-template <bool COUPLED>
+// operator of the fused kernel: stiffness K (image IM_*, quad_stage1 / quad_pair_block) or consistent mass M (image
+// IMM_*: frame and the four Jacobian determinants; block arithmetic of mitc4_m_tiled_kernel)
+constexpr int FS_OP_K = 0, FS_OP_M = 1;
+constexpr int IMM_R = 0, IMM_DET = 9, IMM_NC = 13;
+template <bool COUPLED, int OP = FS_OP_K>
 struct FusedLayout {
-    static constexpr int TILE = (COUPLED ? IM_NC_COUPLED : IM_NC) * 16;     // doubles per 16-element tile
+    static constexpr int TILE = (OP == FS_OP_M ? IMM_NC : (COUPLED ? IM_NC_COUPLED : IM_NC)) * 16;     // doubles per 16-element tile
 };
 
 constexpr int FZ_SLOT = 21;               // staging slot of the fused kernel, in 16-byte pieces
@@ -679,6 +683,45 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
 }
 
+// One contribution of the consistent mass matrix: block (ti <= tj) of the element in image slot FS_EV_SLOT(ev), the
+// arithmetic of mitc4_m_tiled_kernel statement for statement (MITC4.py:1038-1061), transposed when the record says so.
+__device__ __forceinline__ void fused_eval_mass(uint32_t ev, const double *lds, const int *s_pid,
+                                                const fs_shell_prop *__restrict__ props, double (&Y)[36]) {
+    const int slot = FS_EV_SLOT(ev), ti = FS_EV_TI(ev), tj = FS_EV_TJ(ev);
+    const double *ex = lds + (slot >> 4) * (IMM_NC * 16) + (slot & 15);
+    double R[3][3], det[4];
+    for (int t = 0; t < 9; t++) (&R[0][0])[t] = ex[(IMM_R + t) << 4];
+    for (int q = 0; q < 4; q++) det[q] = ex[(IMM_DET + q) << 4];
+    const fs_shell_prop *pr = props + s_pid[slot];
+    const double mt = pr->m_t, mr = pr->m_r;
+    const double sxi = (ti == 1 || ti == 2) ? 1.0 : -1.0, syi = (ti >= 2) ? 1.0 : -1.0;
+    const double sxj = (tj == 1 || tj == 2) ? 1.0 : -1.0, syj = (tj >= 2) ? 1.0 : -1.0;
+    double ct = 0.0, cr = 0.0;
+    for (int q = 0; q < 4; q++) {
+        const double xi = (q == 1 || q == 2) ? kGP : -kGP, eta = (q >= 2) ? kGP : -kGP;
+        const double Ni = 0.25 * (1.0 + sxi * xi) * (1.0 + syi * eta);
+        const double Nj = 0.25 * (1.0 + sxj * xi) * (1.0 + syj * eta);
+        ct = ct + Ni * Nj * mt * 1.0 * det[q];
+        cr = cr + Ni * Nj * mr * 1.0 * det[q];
+    }
+    double G[6][6];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) G[a][b] = 0.0;
+    for (int p3 = 0; p3 < 3; p3++)
+        for (int q = 0; q < 3; q++) {
+            double st = 0.0, sr = 0.0;
+            for (int k = 0; k < 3; k++) {
+                st = FMA(R[k][p3] * ct, R[k][q], st);
+                sr = FMA(R[k][p3] * cr, R[k][q], sr);
+            }
+            G[p3][q] = st;
+            G[3 + p3][3 + q] = sr;
+        }
+    const bool tr = FS_EV_TR(ev);
+    for (int k = 0; k < 6; k++)
+        for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
+}
+
 #ifdef FS_FUSED_TIMING
 __device__ unsigned long long g_fused_t[24];
 #define FS_TICK(ph) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
@@ -686,7 +729,7 @@ __device__ unsigned long long g_fused_t[24];
 #else
 #define FS_TICK(ph) do { } while (0)
 #endif
-template <bool COUPLED, int SP>
+template <bool COUPLED, int SP, int OP = FS_OP_K>
 __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restrict__ xyz,
                                                            const int32_t *__restrict__ prop_id,
                                                            const fs_shell_prop *__restrict__ props, int32_t n_props,
@@ -695,7 +738,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                                                            const int64_t *__restrict__ pat_rptr,
                                                            const fs_fused_rec *__restrict__ recs,
                                                            double *__restrict__ data, int32_t *__restrict__ status) {
-    using LY = FusedLayout<COUPLED>;
+    using LY = FusedLayout<COUPLED, OP>;
     constexpr int NT = 4;                       // 16-element tiles of the LDS image: one per wave
     __shared__ double lds[NT * LY::TILE];
     __shared__ int s_pid[NT * 16];
@@ -762,9 +805,25 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
             const fs_shell_prop *pr = props + pid;
             const bool flagged = (pflags & FS_PROP_COUPLED) != 0;
-            if (!COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
+            if (OP == FS_OP_K && !COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
             double *img = lds + wave * LY::TILE;
             QuadGeom geo;
+            if constexpr (OP == FS_OP_M) {
+                // mass: frame and the Jacobian determinant of Gauss point g (mitc4_m_tiled_kernel's stage)
+                quad_geometry(x, geo);
+                const double xi = (g == 1 || g == 2) ? kGP : -kGP, eta = (g >= 2) ? kGP : -kGP;
+                double dxi[4], deta[4], ia, ib, ic, id;
+                dshape(xi, eta, dxi, deta);
+                double *ex = img + Q;
+                ex[(IMM_DET + g) << 4] = jacobian(geo, dxi, deta, ia, ib, ic, id);
+                if (g == 0) {
+                    for (int k = 0; k < 3; k++) {
+                        ex[(IMM_R + k) << 4] = geo.e1[k]; ex[(IMM_R + 3 + k) << 4] = geo.e2[k]; ex[(IMM_R + 6 + k) << 4] = geo.e3[k];
+                    }
+                    s_pid[slot] = pid;
+                    if (status && valid) status[e] = geo.status | bad;
+                }
+            } else {
             QuadElem el;
             // the coupling cores are formed only by waves that hold a coupled element; the others zero their part of the
             // image (lane g owns the rows of node g, as in quad_stage1)
@@ -792,6 +851,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 }
             } else {
                 ex[(IM_INV + 0) << 4] = el.i00; ex[(IM_INV + 1) << 4] = el.i01; ex[(IM_INV + 2) << 4] = el.i11;
+            }
             }
         }
         // property id of the next patch's element: `en` has arrived under stage 1 (the empty asm keeps the compiler from
@@ -829,14 +889,20 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             const bool a0 = FS_EV_ACTIVE(ev0), a1 = FS_EV_ACTIVE(ev1);
             const bool c0 = COUPLED && __any(a0 && (s_pid[FS_EV_SLOT(ev0)] & FS_SLOT_COUPLED));
             const bool c1 = COUPLED && __any(a1 && (s_pid[FS_EV_SLOT(ev1)] & FS_SLOT_COUPLED));
-            if (a0) fused_eval<COUPLED>(ev0, lds, s_pid, props, c0, Y);
+            if (a0) {
+                if constexpr (OP == FS_OP_M) fused_eval_mass(ev0, lds, s_pid, props, Y);
+                else fused_eval<COUPLED>(ev0, lds, s_pid, props, c0, Y);
+            }
             else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
             for (int t = 0; t < 36; t++) X[t] = z0 + Y[t];
             asm volatile("" : "+v"(pidn));                     // (wait for pidn here, not right after its load)
             pflagsn = props[safe_pid(pidn, n_props)].flags;     // (every round: see above)
             FS_TICK(2);
-            if (a1) fused_eval<COUPLED>(ev1, lds, s_pid, props, c1, Y);
+            if (a1) {
+                if constexpr (OP == FS_OP_M) fused_eval_mass(ev1, lds, s_pid, props, Y);
+                else fused_eval<COUPLED>(ev1, lds, s_pid, props, c1, Y);
+            }
             else
                 for (int t = 0; t < 36; t++) Y[t] = -0.0;
             FS_TICK(3);
@@ -3343,7 +3409,10 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
 #define FS_FUSED_LAUNCH(C)                                                                                           \
     hipLaunchKernelGGL((fused_quad_k_kernel<C, 64>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,       \
                        n_patches, pat_eptr, pat_elems, pat_rptr, recs, data, status)
-    if (flags & FS_FUSED_HAS_COUPLED) FS_FUSED_LAUNCH(true); else FS_FUSED_LAUNCH(false);
+    if (flags & FS_FUSED_MASS)      // (two workgroups per CU with 32 staging slots: 136 B of spills per lane, 1.43 against 1.02 ms)
+        hipLaunchKernelGGL((fused_quad_k_kernel<false, 64, FS_OP_M>), dim3(grid), dim3(256), 0, s, xyz, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, data, status);
+    else if (flags & FS_FUSED_HAS_COUPLED) FS_FUSED_LAUNCH(true); else FS_FUSED_LAUNCH(false);
 #undef FS_FUSED_LAUNCH
     FS_LAUNCH_CHECK("fused_quad_k_kernel");
     return FS_OK;

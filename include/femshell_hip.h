@@ -348,6 +348,9 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
  *             are read back from those slots, so that both sweeps of the wave's stores run through memory in order.
  *   flags     FS_FUSED_HAS_COUPLED: some property row has FS_PROP_COUPLED (0 selects the kernel without the
  *             coupling terms; a coupled row met anyway is reported as FS_ST_BAD_PROP)
+ *             FS_FUSED_MASS: the same launch forms the consistent MASS matrix instead (MITC4.M, elements/MITC4.py:1038-1061,
+ *             summed by the loop of MeshAssembler.assemble_mass_matrix, core/assembler.py:305-336): bit-identical to
+ *             fs_shell_quad_batch(FS_WANT_M) followed by fs_csr_numeric_desc, same plan, no element matrices in memory
  *   status    [E] FS_ST_* bits or NULL
  */
 typedef struct fs_fused_rec {
@@ -368,6 +371,7 @@ FS_STATIC_ASSERT(sizeof(fs_fused_rec) == 64 && offsetof(fs_fused_rec, stride) ==
 #define FS_FL_PAD 16u
 #define FS_FUSED_MAX_PATCH_ELEMS 64
 #define FS_FUSED_HAS_COUPLED 1u
+#define FS_FUSED_MASS 2u   /* assemble the consistent mass matrix M instead of K (see above) */
 int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,
                            int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
                            const int64_t *pat_rptr, const fs_fused_rec *recs, int32_t max_patch_elems,

@@ -98,6 +98,12 @@ def test_fused_is_bitwise_the_two_kernel_path(oracle, name, max_elems):
     assert torch.equal(st, asm._status[0])
     again = asm.assemble_stiffness_matrix(recompute=True)            # default route == fused; repeatable
     assert bool((_bits(again.data) == _bits(Kf.data)).all())
+    # the mass matrix through the same kernel skeleton (FS_FUSED_MASS) against element kernel + assembly kernel
+    M2 = asm.assemble_mass_matrix(recompute=True, fused=False)
+    Mf = asm.assemble_mass_fused()
+    torch.cuda.synchronize()
+    assert bool((_bits(Mf.data) == _bits(M2.data)).all()), int((_bits(Mf.data) != _bits(M2.data)).sum())
+    assert bool((_bits(asm.assemble_mass_matrix(recompute=True).data) == _bits(M2.data)).all())     # default route
     # independent check of sampled rows against the oracle
     if name in ("plate_37x23_8props", "irregular_fans"):
         Ke, _ = oracle.mitc4_K_batch(mesh.coords[mesh.conn], asm._prop_id, asm._prop_table)

@@ -50,3 +50,12 @@ print(f"E={E} two-kernel {t2:.3f} ms  fused {tf:.3f} ms  ({E / tf * 1e3:.3e} el/
 print(f"fused step roofline: {E * 2708 / tf * 1e3 / 1e12:.2f} TB/s of 8 ({E * 2708 / tf * 1e3 / 8e12:.3f}), "
       f"{E * 27750 / tf * 1e3 / 1e12:.1f} TFLOP/s of 78.6 ({E * 27750 / tf * 1e3 / 78.6e12:.3f})")
 
+
+def two_m():
+    asm.refresh_element_matrices(want_K=False, want_M=True, check=False)
+    return asm.assemble_mass_matrix(recompute=False, fused=False)
+
+
+tm2, tmf = timed(two_m), timed(asm.assemble_mass_fused)
+M2, Mf = two_m(), asm.assemble_mass_fused()
+print(f"mass: two-kernel {tm2:.3f} ms  fused {tmf:.3f} ms  bitwise equal: {bool((M2.data.view(torch.int64) == Mf.data.view(torch.int64)).all())}")
