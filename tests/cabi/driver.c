@@ -146,6 +146,13 @@ int main(int argc, char **argv) {
         HIPCHK(hipMemcpy(st2, d_st, (size_t)E * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(stf, d_stf, (size_t)E * 4, hipMemcpyDeviceToHost));
         if (memcmp(k2, kf, (size_t)nnz * 8) != 0 || memcmp(st2, stf, (size_t)E * 4) != 0) return 8;
+        /* the mass matrix through the same plan (FS_FUSED_MASS): the bits of fs_shell_quad_batch(FS_WANT_M) + fs_csr_numeric_desc */
+        FSCHK(fs_fused_assemble_quad(d_xyz, d_pid, d_props, (int32_t)P, E, npat, d_eptr, d_elems, d_rptr, d_recs,
+                                     FS_FUSED_MAX_PATCH_ELEMS, FS_FUSED_MASS, d_Kf, NULL, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(k2, d_M, (size_t)nnz * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(kf, d_Kf, (size_t)nnz * 8, hipMemcpyDeviceToHost));
+        if (memcmp(k2, kf, (size_t)nnz * 8) != 0) return 9;
         if (fs_fused_plan_build(conn, E, N, h_nbr_ptr, h_nbr, NULL, 64, &fp, &npat, &nslots, &nrecs) != FS_EINVAL) return 6;
     }
 
