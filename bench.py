@@ -60,6 +60,47 @@ def avg_ms(torch, fn, steps):
     return a.elapsed_time(b) / steps
 
 
+def pmc_traffic(full):
+    """HBM bytes per launch of the fused kernel from the PMC counters, measured NOW (not quoted from profiles/): two
+    child runs of this file under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE each in a pass of its own, as
+    MI355X_MICROARCH.md (HBM, rocprofv3) prescribes -- on the same workload as `value` (children run `--pmc-child`:
+    that workload only, 2 timed launches).  gfx950 corrections of the guide: both counters in KiB, FETCH_SIZE tallies the
+    128-byte requests of wide coalesced reads at 64 B (x 2).  Returns (bytes per launch or None, details)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, {"error": "rocprofv3 not on PATH"}
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="femshell_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", "--steps", "2", "--warmup", "1"] + ([] if full else ["--strip-only"])
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "fused_quad_k_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, {"error": f"no {counter} rows for the fused kernel"}
+            vals.sort()
+            got[counter] = vals[len(vals) // 2]          # median over the child's launches (same workload each)
+            got[counter + "_launches"] = len(vals)
+        except Exception as ex:  # noqa: BLE001  (no profiler, no counters: the bench line says so instead of failing)
+            return None, {"error": f"{counter} pass failed: {type(ex).__name__}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = got["FETCH_SIZE"] * 1024 * 2, got["WRITE_SIZE"] * 1024
+    return rd + wr, {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "launches_sampled": got["FETCH_SIZE_launches"],
+                     "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child runs of this bench on the same workload, "
+                            "started by this run; KiB units, FETCH_SIZE x 2 (gfx950)"}
+
+
 def c5_laminates():
     """16 laminates of the synthetic plate: UD, cross-ply, biax, QI, sandwich-like thick stacks,
     ~25 % asymmetric (membrane-bending coupling active)."""
@@ -551,6 +592,12 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed):
     return res
 
 
+def full_workload_matches(args, r):
+    """The PMC children ran the plate unless --strip-only; if this process then fell back to the strip for lack of
+    memory, their figure is for another workload and is not reported as `traffic`."""
+    return r["E"] == (STRIP_NX * STRIP_NY if args.strip_only else FULL_NX * FULL_NY)
+
+
 def roofline_objects(r, ms_per_step):
     """`roofline` for the dominant (only) kernel of the step and `roofline_step` for the whole step, both priced with the
     ALGORITHMIC bytes (SURVEY.md 8d fused path) and flops (bench/FLOPS.md) per element."""
@@ -596,12 +643,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the configs[0..3] / HEXA8 legs")
     ap.add_argument("--strip-only", action="store_true", help="N = 1: time the 1.25 M strip instead of the 10 M plate")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    traffic = (None, None)
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    if world == 1 and not args.pmc_child and not args.no_pmc and not under_profiler:
+        # before this process touches the GPU: the children need the memory the parent is about to take
+        log("PMC traffic passes (rocprofv3 children)")
+        traffic = pmc_traffic(full=not args.strip_only)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -631,6 +687,10 @@ def main():
     else:
         free = torch.cuda.mem_get_info()[0]
         full = not args.strip_only and free >= 120e9
+        if args.pmc_child:      # under rocprofv3 --pmc: the workload of `value` only, nothing printed
+            nx, ny = (FULL_NX, FULL_NY) if full else (STRIP_NX, STRIP_NY)
+            plate_run(torch, dist, 0, 1, nx, ny, args.steps, args.warmup, False)
+            return
         if not args.strip_only:
             strip = plate_run(torch, dist, 0, 1, STRIP_NX, STRIP_NY, args.steps, args.warmup, False)
         if full:
@@ -650,6 +710,11 @@ def main():
         ms_per_step = r["dt"] / args.steps * 1e3
         value = total_E * args.steps / r["dt"]
         roof, roof_step = roofline_objects(r, ms_per_step)
+        if traffic[0] is not None and full_workload_matches(args, r):
+            roof["traffic"] = traffic[0]
+            roof["traffic_over_algorithmic"] = traffic[0] / (r["E"] * BYTES_PER_ELEM)
+        if traffic[1] is not None:
+            roof["traffic_measurement"] = traffic[1]
         line = {
             "metric": "MITC4+ element stiffness matrices assembled into CSR per second (fp64)",
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,
