@@ -80,7 +80,18 @@ def pmc_traffic(full):
                "--pmc-child", "--steps", "2", "--warmup", "1"] + ([] if full else ["--strip-only"])
         env = dict(os.environ, TMPDIR="/tmp")
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            # own process group: a pass that hangs is killed with everything it started (the profiled python included)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=180)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                raise
+            if rc != 0:
+                raise RuntimeError(f"rocprofv3 exit code {rc}")
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
