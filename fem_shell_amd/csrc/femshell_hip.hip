@@ -2721,20 +2721,34 @@ __global__ __launch_bounds__(256) void csr_numeric_desc3_lds_kernel(const double
     const int k = r / 3, l = r - k * 3;
     const int rt = l * 3 + k;                   // the entry this lane takes from a transposed contribution
     const fs_blk_desc dsc = reinterpret_cast<const fs_blk_desc *>(s_desc)[bl];
+    const int n = dsc.cnt & (FS_BLK_PACKED - 1);
     double v;
-    if (dsc.cnt <= 4) {
+    if (n <= 4) {
         double x[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int64_t cc = dsc.c[c];
-            x[c] = (c < dsc.cnt) ? vals[(cc >> 1) * 9 + ((cc & 1) ? rt : r)] : 0.0;
+            x[c] = (c < n) ? vals[(cc >> 1) * 9 + ((cc & 1) ? rt : r)] : 0.0;
         }
         v = ((x[0] + x[1]) + x[2]) + x[3];      // element order == reference insertion order
-    } else {
-        // more than 4 contributions (the diagonal block of a node shared by 8 hexahedra, tetrahedral meshes): batches
-        // of 8 with all index loads, then all value loads, in flight together; the sum still runs in element order
+    } else if (dsc.cnt & FS_BLK_PACKED) {
+        // 5..8 contributions with their codes inline (uint32[8]): the diagonal block of a node shared by 8 bricks --
+        // all value loads in flight together, no dependent read of the contribution list
+        double y[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t cc = (uint32_t)((uint64_t)dsc.c[u >> 1] >> (32 * (u & 1)));
+            y[u] = (u < n) ? vals[(int64_t)(cc >> 1) * 9 + ((cc & 1u) ? rt : r)] : 0.0;
+        }
         v = 0.0;
-        const int64_t lo = dsc.c[0], hi = lo + dsc.cnt;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (u < n) v = v + y[u];
+    } else {
+        // more than 8 contributions (tetrahedral meshes): batches of 8 with all index loads, then all value loads, in
+        // flight together; the sum still runs in element order
+        v = 0.0;
+        const int64_t lo = dsc.c[0], hi = lo + n;
         for (int64_t q0 = lo; q0 < hi; q0 += 8) {
             int64_t cc[8];
 #pragma unroll
@@ -2779,38 +2793,73 @@ __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double
     const int k = r / 3, l = 2 * (r - k * 3);
     fs_blk_desc dsc;
     dsc.cnt = 0;
+    if (active) dsc = reinterpret_cast<const fs_blk_desc *>(s_desc)[bl];
+    const int n = dsc.cnt & (FS_BLK_PACKED - 1);
+    const bool packed = (dsc.cnt & FS_BLK_PACKED) != 0;       // 5..8 contributions, codes inline as uint32[8]
+    const bool staged = active && (n <= 4 || packed);         // contributions go through the LDS transposition
+    // code of inline contribution u (u < 4: also the plain int64 form of n <= 4)
+    auto code = [&](int u) -> int64_t {
+        return packed ? (int64_t)(uint32_t)((uint64_t)dsc.c[u >> 1] >> (32 * (u & 1))) : dsc.c[u & 3];
+    };
+    const double *sv0 = reinterpret_cast<const double *>(&s_val[0][bl * TPB]);
+    constexpr int CS = BPW * TPB * 2;   // doubles between contribution slots
     double2 x[4];
-    if (active) {
-        dsc = reinterpret_cast<const fs_blk_desc *>(s_desc)[bl];
-        if (dsc.cnt <= 4) {
+    const int n0 = n < 4 ? n : 4;
+    if (staged) {
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                x[c] = (c < dsc.cnt) ? reinterpret_cast<const double2 *>(vals + (dsc.c[c] >> 1) * DD)[r]
-                                     : make_double2(0.0, 0.0);
+        for (int c = 0; c < 4; c++)
+            x[c] = (c < n0) ? reinterpret_cast<const double2 *>(vals + (code(c) >> 1) * DD)[r] : make_double2(0.0, 0.0);
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_val[c][tid] = x[c];
-        }
+        for (int c = 0; c < 4; c++) s_val[c][tid] = x[c];
     }
-    __syncthreads();
-    if (!active) return;
-    double2 v;
-    if (dsc.cnt <= 4) {
-        const double *sv0 = reinterpret_cast<const double *>(&s_val[0][bl * TPB]);
-        constexpr int CS = BPW * TPB * 2;   // doubles between contribution slots
+    // a second round of four for the packed blocks of this workgroup (triangle meshes: the diagonal block of a node
+    // shared by 6 elements); workgroups without one -- every workgroup of a quad mesh -- skip it
+    const int more = __syncthreads_or(active && packed);
+    double2 v = make_double2(0.0, 0.0);
+    if (staged) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (c < dsc.cnt && (dsc.c[c] & 1)) {
+            if (c < n0 && (code(c) & 1)) {
                 const double *sv = sv0 + c * CS;
                 x[c] = make_double2(sv[l * D + k], sv[(l + 1) * D + k]);
             }
         }
-        v.x = ((x[0].x + x[1].x) + x[2].x) + x[3].x;  // element order == reference insertion order
-        v.y = ((x[0].y + x[1].y) + x[2].y) + x[3].y;
-    } else {
-        // more than 4 contributions (triangle meshes: 6 around an interior node): batches of 8 with all index
-        // loads, then all value loads, in flight together; the sum still runs in element order
-        v = make_double2(0.0, 0.0);
-        const int64_t lo = dsc.c[0], hi = lo + dsc.cnt;
+        if (!packed) {
+            v.x = ((x[0].x + x[1].x) + x[2].x) + x[3].x;  // element order == reference insertion order
+            v.y = ((x[0].y + x[1].y) + x[2].y) + x[3].y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) { v.x = v.x + x[c].x; v.y = v.y + x[c].y; }     // 0.0 + x0 + x1 + ...
+        }
+    }
+    if (more) {
+        __syncthreads();        // every lane has read round one from s_val
+        if (active && packed) {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                x[c] = (4 + c < n) ? reinterpret_cast<const double2 *>(vals + (code(4 + c) >> 1) * DD)[r] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_val[c][tid] = x[c];
+        }
+        __syncthreads();
+        if (active && packed) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (4 + c < n && (code(4 + c) & 1)) {
+                    const double *sv = sv0 + c * CS;
+                    x[c] = make_double2(sv[l * D + k], sv[(l + 1) * D + k]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (4 + c < n) { v.x = v.x + x[c].x; v.y = v.y + x[c].y; }
+        }
+    }
+    if (!active) return;
+    if (!staged) {
+        // more than 8 contributions: batches of 8 with all index loads, then all value loads, in flight together; the
+        // sum still runs in element order
+        const int64_t lo = dsc.c[0], hi = lo + n;
         for (int64_t q0 = lo; q0 < hi; q0 += 8) {
             int64_t cc[8];
 #pragma unroll

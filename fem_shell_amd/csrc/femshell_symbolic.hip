@@ -144,6 +144,18 @@ __global__ __launch_bounds__(256) void sym_desc_kernel(const int64_t *__restrict
             if (c < cnt) out.c[c] = contrib[lo + c];
     } else {
         out.c[0] = lo;
+        if (cnt <= 8) {          // FS_BLK_PACKED: the codes inline as uint32[8] when they all fit
+            int64_t code[8];
+            bool fits = true;
+            for (int c = 0; c < 8; c++) {
+                code[c] = (c < cnt) ? contrib[lo + c] : 0;
+                fits = fits && code[c] >= 0 && code[c] < (int64_t(1) << 32);
+            }
+            if (fits) {
+                for (int c = 0; c < 4; c++) out.c[c] = code[2 * c] | (code[2 * c + 1] << 32);
+                out.cnt = (int32_t)cnt | FS_BLK_PACKED;
+            }
+        }
     }
     desc[b] = out;
 }

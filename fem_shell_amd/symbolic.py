@@ -16,6 +16,7 @@ import numpy as np
 
 BLK_DESC_DTYPE = np.dtype([("dst", "i8"), ("stride", "i4"), ("cnt", "i4"), ("c", "i8", (4,))])
 assert BLK_DESC_DTYPE.itemsize == 48
+FS_BLK_PACKED = 0x40000000
 
 
 def pair_index(nn):
@@ -164,6 +165,17 @@ class BlockPlan:
             desc["c"][has, c] = self.contrib[start[has] + c]
         big = cnt > 4
         desc["c"][big, 0] = start[big]
+        # FS_BLK_PACKED: 5..8 contributions whose codes all fit 32 bits sit inline as uint32[8]
+        mid = np.flatnonzero(big & (cnt <= 8))
+        if mid.size:
+            codes = np.zeros((mid.size, 8), dtype=np.int64)
+            for c in range(8):
+                has = cnt[mid] > c
+                codes[has, c] = self.contrib[start[mid][has] + c]
+            fits = ((codes >= 0) & (codes < (1 << 32))).all(axis=1)
+            m2 = mid[fits]
+            desc["c"][m2] = codes[fits].astype(np.uint32).view(np.int64).reshape(-1, 4)
+            desc["cnt"][m2] = cnt[m2] | FS_BLK_PACKED
         return desc
 
     def row_nnz(self):

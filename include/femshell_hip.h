@@ -297,11 +297,15 @@ int fs_csr_numeric(const double *vals, const int64_t *src, const int64_t *seg_pt
  *   dst     index in `data` of entry (k=0,l=0) of the block: data is CSR with rows = d*I+k, row-major, sorted
  *           columns, so dst = d*d*nbr_ptr[I] + d*r with r = rank of J among I's neighbours
  *   stride  distance between consecutive rows k of the block in `data` (= d * m_I, m_I = neighbours of I)
- *   cnt     number of contributions; cnt <= 4: c[0..cnt) hold them inline
- *           ((index of the d*d source block in `vals` << 1) | transposed, element order); cnt > 4: c[0] is the
- *           offset of the cnt contributions in `contrib` (same encoding, sorted by element index)
- * The sum runs in element order (== the reference's ADD_VALUES insertion order); blocks with fewer than 4
- * contributions add +0.0 for the missing ones. */
+ *   cnt     number of contributions n; n <= 4: c[0..n) hold them inline
+ *           ((index of the d*d source block in `vals` << 1) | transposed, element order); n > 4: c[0] is the
+ *           offset of the n contributions in `contrib` (same encoding, sorted by element index) -- unless
+ *           FS_BLK_PACKED is set in cnt (cnt = n | FS_BLK_PACKED, 5 <= n <= 8, every code below 2^32): then the 32
+ *           bytes of c hold the n codes inline as uint32[8] (the diagonal block of a node shared by 6 triangles or 8
+ *           bricks then costs no second, dependent read of `contrib`)
+ * The sum runs in element order (== the reference's ADD_VALUES insertion order): n <= 4 as ((x0 + x1) + x2) + x3 with
+ * +0.0 for the missing ones, n > 4 as 0.0 + x0 + x1 + ... */
+#define FS_BLK_PACKED 0x40000000
 typedef struct fs_blk_desc {
     int64_t dst;
     int32_t stride;
