@@ -2803,12 +2803,17 @@ __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double
     };
     const double *sv0 = reinterpret_cast<const double *>(&s_val[0][bl * TPB]);
     constexpr int CS = BPW * TPB * 2;   // doubles between contribution slots
-    double2 x[4];
+    double2 x[4], y[4];
     const int n0 = n < 4 ? n : 4;
     if (staged) {
 #pragma unroll
         for (int c = 0; c < 4; c++)
             x[c] = (c < n0) ? reinterpret_cast<const double2 *>(vals + (code(c) >> 1) * DD)[r] : make_double2(0.0, 0.0);
+        if (packed) {       // contributions 4..7 are fetched now too: all value loads of a block in flight together
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                y[c] = (4 + c < n) ? reinterpret_cast<const double2 *>(vals + (code(4 + c) >> 1) * DD)[r] : make_double2(0.0, 0.0);
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) s_val[c][tid] = x[c];
     }
@@ -2836,10 +2841,7 @@ __global__ __launch_bounds__(256) void csr_numeric_desc6_lds_kernel(const double
         __syncthreads();        // every lane has read round one from s_val
         if (active && packed) {
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                x[c] = (4 + c < n) ? reinterpret_cast<const double2 *>(vals + (code(4 + c) >> 1) * DD)[r] : make_double2(0.0, 0.0);
-#pragma unroll
-            for (int c = 0; c < 4; c++) s_val[c][tid] = x[c];
+            for (int c = 0; c < 4; c++) { x[c] = y[c]; s_val[c][tid] = x[c]; }
         }
         __syncthreads();
         if (active && packed) {
