@@ -2468,8 +2468,11 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
     constexpr int NPAIR = NN * (NN + 1) / 2;
     constexpr int EPB = 256 / NPAIR;
     constexpr int GS = NN * 3;                     // doubles of one gradient set
-    __shared__ double s_g[EPB * NG * GS];          // dN/dx      (SOLID.py:245-248)
-    __shared__ double s_gt[EPB * NG * GS];         // inv_J.T form used by K_G (SOLID.py:352-354)
+    // gradients of phase 1; reused at the very end as the staging area of the stiffness blocks (EPB * NPAIR * 9 doubles)
+    constexpr int NGRAD = EPB * NG * GS, NOUT = EPB * NPAIR * 9;
+    __shared__ double s_gg[(2 * NGRAD > NOUT) ? 2 * NGRAD : NOUT];
+    double *s_g = s_gg;                            // dN/dx      (SOLID.py:245-248)
+    double *s_gt = s_gg + NGRAD;                   // inv_J.T form used by K_G (SOLID.py:352-354)
     __shared__ double s_wd[EPB * NG];              // w * detJ
     __shared__ double s_N[EPB * NG * NN];          // shape values (mass, body load)
     const int tid = threadIdx.x;
@@ -2526,8 +2529,10 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
     {
 #pragma clang fp contract(fast)
         const int el = tid / NPAIR, p = tid - el * NPAIR;
-        const int64_t e = e0 + el;
-        if (el >= EPB || e >= E) return;
+        const bool valid = el < EPB && e0 + el < E;
+        const int64_t e = valid ? e0 + el : e0;
+        double K[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (valid) {
         int ti = 0, rem = p;
         while (rem >= NN - ti) { rem -= NN - ti; ti++; }
         const int tj = ti + rem;
@@ -2539,7 +2544,6 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
             for (int a = 0; a < 6; a++)
 #pragma unroll
                 for (int b = 0; b < 6; b++) C[a][b] = 0.5 * (pr[a * 6 + b] + pr[b * 6 + a]);   // 0.5 (K + K^T) of SOLID.py:565
-            double K[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             for (int q = 0; q < ng; q++) {
                 const double *gi = s_g + (el * NG + q) * GS + 3 * ti, *gj = s_g + (el * NG + q) * GS + 3 * tj;
                 const double ax = gi[0], ay = gi[1], az = gi[2], bx_ = gj[0], by_ = gj[1], bz_ = gj[2];
@@ -2565,8 +2569,6 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
 #pragma unroll
                     for (int b = a + 1; b < 3; b++) { const double m = 0.5 * (K[a][b] + K[b][a]); K[a][b] = m; K[b][a] = m; }
             }
-#pragma unroll
-            for (int c = 0; c < 9; c++) Ke[ob + c] = (&K[0][0])[c];
         }
         if (Me || fe) {
             const double rho = pr[36];
@@ -2598,6 +2600,21 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
             }
 #pragma unroll
             for (int c = 0; c < 9; c++) KGe[ob + c] = (c == 0 || c == 4 || c == 8) ? gsum : 0.0;
+        }
+        }
+        // stiffness blocks: a thread storing its own 72 bytes issues 9 instructions of 8-byte pieces 72 bytes apart (every
+        // instruction touches every line of the wave's range); staged through LDS the workgroup's blocks -- contiguous in
+        // FS_LAYOUT_SYMBLK -- leave as whole 512-byte runs per wave instruction
+        if (Ke) {
+            __syncthreads();        // phase-1 data no longer needed: the staging area overlays it
+            if (valid)
+#pragma unroll
+                for (int c = 0; c < 9; c++) s_gg[tid * 9 + c] = (&K[0][0])[c];
+            __syncthreads();
+            const int64_t left = E - e0;
+            const int nout = (int)(left < EPB ? left : EPB) * NPAIR * 9;
+            double *dst = Ke + e0 * NPAIR * 9;
+            for (int i = tid; i < nout; i += 256) dst[i] = s_gg[i];
         }
     }
 }
