@@ -2507,18 +2507,22 @@ __global__ __launch_bounds__(256) void solid_kernel(const double *__restrict__ x
             const double det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
             if (det <= 1e-14 && status) atomicOr(status + e, FS_ST_BAD_JAC);   // ValueError in SOLID.py:211-212
             double inv[3][3];
-            inv[0][0] = c00 / det; inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
-            inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det; inv[1][0] = -c01 / det;
-            inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det; inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
-            inv[2][0] = c02 / det; inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
-            inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+            {   // nine IEEE quotients over one denominator: one shared reciprocal (divr, femshell_geom.h), the same bits
+                const double rdet = recip(det);
+                inv[0][0] = divr(c00, det, rdet); inv[0][1] = divr(J[0][2] * J[2][1] - J[0][1] * J[2][2], det, rdet);
+                inv[0][2] = divr(J[0][1] * J[1][2] - J[0][2] * J[1][1], det, rdet); inv[1][0] = divr(-c01, det, rdet);
+                inv[1][1] = divr(J[0][0] * J[2][2] - J[0][2] * J[2][0], det, rdet);
+                inv[1][2] = divr(J[0][2] * J[1][0] - J[0][0] * J[1][2], det, rdet);
+                inv[2][0] = divr(c02, det, rdet); inv[2][1] = divr(J[0][1] * J[2][0] - J[0][0] * J[2][1], det, rdet);
+                inv[2][2] = divr(J[0][0] * J[1][1] - J[0][1] * J[1][0], det, rdet);
+            }
             double *g = s_g + (el * NG + q) * GS, *gt = s_gt + (el * NG + q) * GS;
 #pragma unroll
             for (int i = 0; i < NN; i++) {
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
                     g[3 * i + a] = inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i];
-                    gt[3 * i + a] = inv[0][a] * dxi[i] + inv[1][a] * deta[i] + inv[2][a] * dzeta[i];
+                    if (KGe) gt[3 * i + a] = inv[0][a] * dxi[i] + inv[1][a] * deta[i] + inv[2][a] * dzeta[i];
                 }
                 s_N[(el * NG + q) * NN + i] = N[i];
             }
