@@ -13,10 +13,11 @@ asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL,
 asm.fused_plan()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 out = (ctypes.c_ulonglong * 24)()
-for _ in range(3): asm.assemble_stiffness_fused()
+fn = asm.assemble_mass_fused if 'mass' in sys.argv else asm.assemble_stiffness_fused
+for _ in range(3): fn()
 torch.cuda.synchronize()
 lib.fs_debug_fused_timing(None, 1)
-ms = bench.avg_ms(torch, asm.assemble_stiffness_fused, 5)
+ms = bench.avg_ms(torch, fn, 5)
 torch.cuda.synchronize()
 lib.fs_debug_fused_timing(out, 0)
 t = np.array(list(out)[:7], dtype=np.float64)
