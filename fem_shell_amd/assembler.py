@@ -436,7 +436,10 @@ class MeshAssembler:
         if recompute and fused and self.can_fuse:
             return self.assemble_stiffness_fused()
         if recompute or self._K_blk is None:
-            self.refresh_element_matrices(want_K=True, want_M=False)
+            # the geometry was checked when the assembler was built (the reference checks in its element constructors
+            # only); a re-evaluation does not sync with the host again -- the status words are still written
+            # (check_status() reads them)
+            self.refresh_element_matrices(want_K=True, want_M=False, check=self._K_blk is None)
         return self._assemble(self._K_blk)
 
     def assemble_mass_matrix(self, recompute=False, fused=None) -> CsrMatrix:
@@ -447,7 +450,7 @@ class MeshAssembler:
         if (recompute or self._M_blk is None) and fused and self.can_fuse:
             return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
-            self.refresh_element_matrices(want_K=False, want_M=True)
+            self.refresh_element_matrices(want_K=False, want_M=True, check=False)
         return self._assemble(self._M_blk)
 
     # --- new (SURVEY.md 8a "New"): Newton re-assembly of K_T(u) and f_int(u) -----------------
