@@ -62,3 +62,39 @@ def test_device_plan_errors_and_empty():
         symbolic.DeviceBlockPlan(conn, 4, 6, DEV)           # node 7 outside [0, 4)
     dp = symbolic.DeviceBlockPlan(np.zeros((0, 4), dtype=np.int64), 5, 6, DEV)
     assert dp.nblk == 0 and dp.nnz == 0 and not dp.nbr_ptr.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("kind", ["tris", "hexa"])
+def test_packed_and_listed_descriptors_give_the_same_sums(kind):
+    """Blocks with 5..8 contributions: codes inline (FS_BLK_PACKED, what fs_csr_symbolic_finish writes) against the
+    same blocks described through the `contrib` list (flag clear, c[0] = offset) -- the assembly must be bit-identical,
+    d = 6 (triangles: 6 elements around a node) and d = 3 (bricks: 8)."""
+    import torch
+    from fem_shell_amd import _lib
+    rng = np.random.default_rng(4)
+    if kind == "tris":
+        mesh = meshes.cylindrical_patch(25.0, 25.0, 40.0, 14, 11, triangular=True)
+        conn, n, d = mesh.conn, mesh.node_count, 6
+    else:
+        from tests.test_gpu_assembly import _hex_block
+        coords, conn = _hex_block(7, 5, 4)
+        n, d = coords.shape[0], 3
+    dp = symbolic.DeviceBlockPlan(conn, n, d, DEV)
+    desc = dp.descriptors().copy()
+    packed = (desc["cnt"] & symbolic.FS_BLK_PACKED) != 0
+    assert packed.any() and int((desc["cnt"][packed] & (symbolic.FS_BLK_PACKED - 1)).max()) == (6 if kind == "tris" else 8)
+    listed = desc.copy()
+    listed["cnt"][packed] &= symbolic.FS_BLK_PACKED - 1
+    listed["c"][packed] = 0
+    listed["c"][packed, 0] = dp.blk_ptr.cpu().numpy()[:-1][packed]
+    vals = torch.from_numpy(rng.standard_normal((dp.n_src_blocks, d * d))).to(DEV)
+    lib, out = _lib.load(), []
+    for dsc in (desc, listed):
+        dd = torch.from_numpy(dsc.view(np.uint8).reshape(-1).copy()).to(DEV)
+        data = torch.full((dp.nnz,), np.nan, dtype=torch.float64, device=DEV)
+        _lib.check(lib.fs_csr_numeric_desc(_lib.ptr(vals), _lib.ptr(dd), _lib.ptr(dp.contrib), dp.nblk, d, _lib.ptr(data),
+                                           _lib.stream_ptr()), "fs_csr_numeric_desc")
+        out.append(data)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out[0]).any()
+    assert bool((out[0].view(torch.int64) == out[1].view(torch.int64)).all())
