@@ -7,11 +7,11 @@ One "step" = one pass of the hot path over the rank's shard: ONE launch of the f
 HBM before the timed region; the symbolic phase (pattern + plans) is precomputed, as north_star specifies.
 
 Workload (BASELINE.json configs[4], the configuration the metric is quoted on): the synthetic 3200 x 3125 = 10 M element
-MITC4+ laminate plate (16 laminates striped by x-band, jittered nodes).
-  N = 1   the whole 10 M plate on one GPU (about 75 GB of device memory) is `value`; the 400 x 3125 strip one rank owns at
-          N = 8 is timed in the same run and reported as `weak_scaling_point`.
-  N > 1   each rank owns a 400 x 3125 strip (1.25 M elements; the full plate at N = 8), x-strip partition, interface rows
-          exchanged with the two neighbours over RCCL.
+MITC4+ laminate plate (16 laminates in x-bands of 25 columns cycling over the plate, jittered nodes).
+  N = 1   the whole 10 M plate on one GPU is `value`; the 400 x 3125 strip one rank owns at N = 8 is timed in the same
+          run and reported as `one_rank_share_at_n8`.
+  N > 1   the SAME plate cut into N x-strips of 3200/N x 3125 elements (STRONG scaling: total work fixed, N = 8 is
+          1.25 M elements per rank), interface rows exchanged with the two neighbours over RCCL.
 configs[0..3] and the HEXA8 block of configs[4] are timed in their own legs outside `value`; tests/ holds their parity.
 
 Contract: python bench.py --gpus N --steps K --warmup W  (N > 1: launched by torch.distributed.run,
@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 STRIP_NX, STRIP_NY = 400, 3125
 FULL_NX, FULL_NY = 3200, 3125
+BAND = 25                         # columns per laminate band of the plate (global column index; 16 laminates cycle)
 # bench/FLOPS.md (tools/count_flops.py: fp64 instruction count of the shipped device functions, FMA = 2):
 FLOP_PER_ELEM = 18779.0           # algorithmic, geometry once per element
 FLOP_PER_ELEM_COUPLED = 21783.0   # membrane-bending coupling active (asymmetric laminates)
@@ -520,34 +521,39 @@ def git_commit_of(path):
         return None
 
 
-def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed):
+def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, return_matrix=False):
     """Build the assembler for an nx x ny piece of the plate (x offset rank * nx), run warmup + `steps` timed steps of
-    assemble_stiffness_matrix(recompute=True) bracketed by barrier + synchronize, return the measurements."""
+    assemble_stiffness_matrix(recompute=True) bracketed by barrier + synchronize, return the measurements
+    (return_matrix=True: also the last step's matrix and the assembler, for tests/test_gpu_dist.py)."""
     from fem_shell_amd import meshes
     from fem_shell_amd.assembler import MeshAssembler
     from fem_shell_amd.elements import ElementFamily
     lams = c5_laminates()
     log(f"plate {nx}x{ny}: mesh")
     t0 = time.perf_counter()
-    # x-bands of 25 columns cycling through the 16 laminates: every rank's strip sees all 16
-    mesh = meshes.jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=rank * nx)
+    # x-bands of 25 columns of the GLOBAL plate cycling through the 16 laminates: every strip is its part of the plate
+    mesh = meshes.jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=rank * nx, band=BAND)
     names = mesh.set_names
     model = {"elements": {"element_family": ElementFamily.SHELL, "properties": {names[i]: lams[i] for i in range(16)}}}
     t1 = time.perf_counter()
     log(f"plate {nx}x{ny}: assembler (symbolic phase, first K)")
     if distributed:
         from fem_shell_amd.dist import DistributedAssembler
-        asm = DistributedAssembler(mesh, model, strip=(rank, world, nx, ny),
+        asm = DistributedAssembler(mesh, model, strip=(rank, world, nx, ny), cache_blocks=False,
                                    overlap=os.environ.get("FEMSHELL_DIST_OVERLAP", "1") != "0")
         local = asm.local
     else:
-        asm = local = MeshAssembler(mesh, model)
+        # cache_blocks=False: no element stiffness blocks in memory (the fused kernel never reads them)
+        asm = local = MeshAssembler(mesh, model, cache_blocks=False)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     if not local.can_fuse:
         raise SystemExit("bench: the plate must run through the fused kernel")
+    if local._K_blk is not None:
+        raise SystemExit("bench: cache_blocks=False must not leave element blocks in memory")
     log(f"plate {nx}x{ny}: fused patch plan")
-    local.fused_plan()
+    if not local.fused_ready():
+        raise SystemExit(f"bench: no fused plan for the plate: {local._fplan_error}")
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     E = mesh.element_count
@@ -580,7 +586,7 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed):
     stream_ms = e0.elapsed_time(e1) / steps            # launch stream only: the fused kernel, back to back
     # the kernel alone, HIP events on its stream, nothing else in flight (no exchange)
     k_ms = avg_ms(torch, lambda: local.assemble_stiffness_fused(), max(3, min(steps, 10)))
-    res = {"E": E, "dt": dt, "kernel_ms": k_ms, "launch_stream_ms_per_step": stream_ms, "nnz": int(K.nnz),
+    res = {"E": E, "dt": dt, "kernel_ms": k_ms, "nx": nx, "ny": ny, "launch_stream_ms_per_step": stream_ms, "nnz": int(K.nnz),
            "coupled_frac": float(np.mean((local._prop_table["flags"][local._prop_id] & 1) != 0)),
            "setup_s": {"mesh": t1 - t0, "assembler_symbolic_and_first_K": t2 - t1, "fused_plan": t3 - t2},
            "plan": local.fused_plan().stats(),
@@ -598,6 +604,9 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed):
         res["interface_exchange_MB"] = sum(b.numel() for b in list(asm._sbuf.values()) + list(asm._rbuf.values())) * 8 / 1e6
         res["overlap"] = asm.overlap
         res["setup_s"]["distributed_plan"] = asm.setup_s
+    local.check_status()      # the status words the timed steps wrote
+    if return_matrix:
+        return res, K, asm
     del K, asm, local
     torch.cuda.empty_cache()
     return res
@@ -686,15 +695,20 @@ def main():
 
     strip = None
     if world > 1:
-        r = plate_run(torch, dist, rank, world, STRIP_NX, STRIP_NY, args.steps, args.warmup, True)
+        if FULL_NX % world:
+            raise SystemExit(f"--gpus {world}: the plate's {FULL_NX} element columns do not divide into {world} strips")
+        snx = FULL_NX // world
+        r = plate_run(torch, dist, rank, world, snx, FULL_NY, args.steps, args.warmup, True)
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, {"rank": rank, "kernel_ms": r["kernel_ms"], "exchange_ms": r["exchange_ms"],
+        dist.all_gather_object(per_rank, {"rank": rank, "elements": r["E"], "kernel_ms": r["kernel_ms"],
+                                          "exchange_ms": r["exchange_ms"],
                                           "launch_stream_ms_per_step": r["launch_stream_ms_per_step"],
+                                          "coupled_frac": r["coupled_frac"],
                                           "setup_s": r["setup_s"], "interface_exchange_MB": r["interface_exchange_MB"]})
-        workload = (f"C5 synthetic jittered MITC4+ laminate plate, {STRIP_NX}x{STRIP_NY}={r['E']} elements per GPU "
-                    f"({r['E'] * world} total; the 10 M plate at 8 GPUs), 16 laminates striped by x-band, "
-                    f"{r['coupled_frac']:.0%} of this rank's elements coupled; step = fused evaluate-and-assemble kernel "
-                    "+ RCCL interface-row exchange")
+        workload = (f"C5 synthetic jittered MITC4+ laminate plate, {FULL_NX}x{FULL_NY}={r['E'] * world} elements cut into "
+                    f"{world} x-strips of {snx}x{FULL_NY}={r['E']} elements (one per GPU), 16 laminates in x-bands of {BAND} "
+                    f"columns, {r['coupled_frac']:.0%} of this rank's elements coupled; step = fused evaluate-and-assemble "
+                    "kernel (status words written) + RCCL interface-row exchange")
     else:
         free = torch.cuda.mem_get_info()[0]
         full = not args.strip_only and free >= 120e9
@@ -712,7 +726,7 @@ def main():
         workload = (f"C5 synthetic jittered MITC4+ laminate plate, {nx}x{ny}={r['E']} elements on one GPU"
                     + (" (configs[4]'s full shell plate)" if full else f" (one x-strip: {free / 1e9:.0f} GB free or --strip-only)")
                     + f", 16 laminates striped by x-band, {r['coupled_frac']:.0%} of the elements coupled; "
-                    "step = one launch of the fused evaluate-and-assemble kernel")
+                    "step = one launch of the fused evaluate-and-assemble kernel (status words written)")
         per_rank = None
 
     if rank == 0:
@@ -730,7 +744,7 @@ def main():
             "metric": "MITC4+ element stiffness matrices assembled into CSR per second (fp64)",
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "elements_per_gpu": E, "nnz_per_gpu": r["nnz"],
                        "partition": f"x-strips x{world}" if world > 1 else "none",
                        "setup_s_rank0": r["setup_s"], "device_memory_GB_rank0": r["device_memory_GB"],
@@ -743,10 +757,17 @@ def main():
         }
         if per_rank is not None:
             line["per_rank"] = per_rank
+            km = [q["kernel_ms"] for q in per_rank]
+            line["load_balance_kernel_ms_max_over_min"] = max(km) / min(km)
+            # step time not covered by this rank's kernel: exchange (and waiting for neighbours) that the overlap did
+            # not hide; 0 when the side-stream exchange disappears under the next step's kernel
+            line["exchange_exposed_ms"] = max(0.0, ms_per_step - max(km))
+            line["multi_gpu_note"] = ("RCCL transport unmeasured on hardware by the builder (one-GPU boxes only); this line "
+                                      "is its first multi-GPU run")
         if strip is not None and strip is not r:
             sms = strip["dt"] / args.steps * 1e3
             sroof, sstep = roofline_objects(strip, sms)
-            line["weak_scaling_point"] = {"workload": f"{STRIP_NX}x{STRIP_NY}={strip['E']} element x-strip (one rank's share at N = 8)",
+            line["one_rank_share_at_n8"] = {"workload": f"{STRIP_NX}x{STRIP_NY}={strip['E']} element x-strip (rank 0's share of the same plate at N = 8)",
                                           "value": strip["E"] * args.steps / strip["dt"], "unit": "elements/s",
                                           "ms_per_step": sms, "kernel_ms": strip["kernel_ms"], "nnz": strip["nnz"],
                                           "roofline_frac_hbm": sroof["frac"], "setup_s": strip["setup_s"]}

@@ -27,6 +27,8 @@ SIGNATURES = {
     "fs_shell_quad_fint_noalloc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
     "fs_fused_assemble_quad": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _u32,
                                               _vp, _vp, _vp]),
+    "fs_fused_plan_check": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp]),
+    "fs_shell_quad_geom_status": (ctypes.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "fs_fused_plan_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "fs_fused_plan_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_plan_free": (None, [_vp]),

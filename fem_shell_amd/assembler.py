@@ -95,8 +95,13 @@ class MeshAssembler:
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
-    def __init__(self, mesh, model: Dict, comm=None, device=None, plan=None):
+    def __init__(self, mesh, model: Dict, comm=None, device=None, plan=None, cache_blocks=True):
+        """cache_blocks=False (uniform MITC4+ meshes): the constructor does not evaluate and keep the element stiffness
+        blocks (2 880 B per element) -- the geometry check of the reference's constructor loop runs through the
+        status words of the fused kernel's mass pass (frame + Jacobians only), K and M come from the fused kernel, and
+        `_ke_array` / the Newton path evaluate the blocks on first use."""
         self._given_plan = plan   # precomputed BlockPlan (distributed runs add ghost columns)
+        self._cache_blocks = bool(cache_blocks)
         self.mesh = mesh
         self.model = model["elements"]
         self.comm = comm
@@ -108,6 +113,7 @@ class MeshAssembler:
         self._is_mixed_mesh = False
         self._K_blk = self._M_blk = None
         self._fplan = self._fplan_d = None
+        self._fplan_error = None
         self._precompute_elements()
         self._compute_sparsity_pattern()
 
@@ -267,7 +273,27 @@ class MeshAssembler:
         self._desc_d = self._plan_d["desc"]
         # K of every element now (this is also the geometry check of the reference's constructor loop); M on first use
         # (assemble_mass_matrix / _me_array): the reference evaluates both up front, here that would only cost memory
-        self.refresh_element_matrices(want_K=True, want_M=False)
+        if self._cache_blocks or not self.can_fuse:
+            self.refresh_element_matrices(want_K=True, want_M=False)
+        else:
+            self._status = [self._geometry_status()]
+            self.check_status()
+
+    def _geometry_status(self):
+        """Status words of every quad (degenerate frame, non-positive Jacobian, bad property id) without element
+        matrices: fs_shell_quad_geom_status, the geometry stage of the stiffness kernel alone."""
+        g = self._groups[0]
+        st = torch.zeros(g["E"], dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().fs_shell_quad_geom_status(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), len(self._prop_table),
+                                                         g["E"], _lib.ptr(st), _lib.stream_ptr()),
+                   "fs_shell_quad_geom_status")
+        return st
+
+    def _k_blocks(self):
+        """Element stiffness blocks, evaluated on first use when the constructor skipped them (cache_blocks=False)."""
+        if self._K_blk is None:
+            self.refresh_element_matrices(want_K=True, want_M=False)
+        return self._K_blk
 
     def _group_view(self, buf, g):
         dd = self.dofs_per_node ** 2
@@ -342,14 +368,14 @@ class MeshAssembler:
                 out[int(pos)] = arr[k]
         return out
 
-    _ke_array = property(lambda self: self._dense(self._K_blk, True))
+    _ke_array = property(lambda self: self._dense(self._k_blocks(), True))
     def _mass_blocks(self):
         if self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True)
         return self._M_blk
 
     _me_array = property(lambda self: self._dense(self._mass_blocks(), True))
-    _ke_list = property(lambda self: self._dense(self._K_blk, False))
+    _ke_list = property(lambda self: self._dense(self._k_blocks(), False))
     _me_list = property(lambda self: self._dense(self._mass_blocks(), False))
 
     @property
@@ -393,9 +419,10 @@ class MeshAssembler:
     # ------------------------------------------------------------------ fused evaluate-and-assemble
     @property
     def can_fuse(self):
-        """The fused kernel covers uniform MITC4+ meshes (one quad group, 6 dofs per node)."""
+        """The fused kernel covers uniform MITC4+ meshes (one quad group, 6 dofs per node) whose patch plan can be
+        built (see fused_ready)."""
         return (self._family == ElementFamily.SHELL and len(self._groups) == 1 and self._groups[0]["nn"] == 4
-                and self._groups[0]["pos"] is None)
+                and self._groups[0]["pos"] is None and self._fplan_error is None)
 
     def fused_plan(self):
         """Patch plan of fs_fused_assemble_quad (fem_shell_amd/fused.py), built on first use."""
@@ -407,13 +434,30 @@ class MeshAssembler:
             self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
         return self._fplan
 
+    def fused_ready(self):
+        """True when the fused route can run on this mesh.  The patch plan has limits the two-kernel route does not
+        have (a node pair shared by more than 32 elements, a node touching more than a patch holds, more than 255
+        blocks stored by one wave): a mesh beyond them is remembered as not fusable and the default entry points fall
+        through to element kernel + assembly kernel -- they never raise for it."""
+        if not self.can_fuse:
+            return False
+        if self._fplan_d is None:
+            try:
+                self.fused_plan()
+            except (ValueError, RuntimeError) as exc:     # FemShellHipError is a RuntimeError
+                self._fplan_error = exc
+                self._fplan = self._fplan_d = None
+                return False
+        return True
+
     def assemble_stiffness_fused(self, status=None, mass=False) -> CsrMatrix:
         """K straight from the coordinates in one launch: element evaluation (core/assembler.py:160-193 ->
         MITC4.K) and the ADD_VALUES loop (:287-303) fused, no element matrices in memory.  Bit-identical to
         refresh_element_matrices() + the descriptor assembly.  `status`: optional int32 [E] device tensor.
         mass=True: the consistent mass matrix the same way (FS_FUSED_MASS; MITC4.M, core/assembler.py:305-336)."""
         if not self.can_fuse:
-            raise NotImplementedError("the fused kernel covers uniform MITC4+ quad meshes")
+            raise NotImplementedError("the fused kernel covers uniform MITC4+ quad meshes"
+                                      + (f" (plan: {self._fplan_error})" if self._fplan_error is not None else ""))
         fp = self.fused_plan()
         d, g = self._fplan_d, self._groups[0]
         lib = _lib.load()
@@ -433,12 +477,16 @@ class MeshAssembler:
         """core/assembler.py:269-303.  recompute=True re-evaluates the element matrices: on uniform MITC4+ meshes
         through the fused kernel (fused=False forces element kernel + assembly kernel; same bits)."""
         fused = self.use_fused if fused is None else fused
-        if recompute and fused and self.can_fuse:
-            return self.assemble_stiffness_fused()
-        if recompute or self._K_blk is None:
+        if (recompute or self._K_blk is None) and fused and self.fused_ready():
             # the geometry was checked when the assembler was built (the reference checks in its element constructors
-            # only); a re-evaluation does not sync with the host again -- the status words are still written
-            # (check_status() reads them)
+            # only); a re-evaluation does not sync with the host again.  The status words of THIS evaluation are
+            # written (check_status() reads them); the cached element blocks (`_ke_array`, the linear blocks the
+            # Newton path reuses) are dropped, so that they are re-evaluated from the current inputs on next use.
+            st = self._status[0] if self._status and self._status[0].numel() == self._groups[0]["E"] else None
+            if recompute:
+                self._K_blk = None
+            return self.assemble_stiffness_fused(status=st)
+        if recompute or self._K_blk is None:
             self.refresh_element_matrices(want_K=True, want_M=False, check=self._K_blk is None)
         return self._assemble(self._K_blk)
 
@@ -447,7 +495,7 @@ class MeshAssembler:
         mass matrices in memory; `_me_array` still materialises them on demand); fused=False forces element kernel +
         assembly kernel (same bits)."""
         fused = self.use_fused if fused is None else fused
-        if (recompute or self._M_blk is None) and fused and self.can_fuse:
+        if (recompute or self._M_blk is None) and fused and self.fused_ready():
             return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True, check=False)
@@ -481,6 +529,8 @@ class MeshAssembler:
         # the linear blocks do not depend on u: the tiled quad path hands the ones of the last K evaluation back to the
         # kernel instead of recomputing them every iterate (the reference reads its cached MITC4.K the same way)
         tiled = self._layout == _lib.FS_LAYOUT_SYMBLK_T16
+        if self.reuse_linear_blocks:
+            self._k_blocks()
         can = self.reuse_linear_blocks and self._K_blk is not None
         group_cached = [can and (tiled or g["nn"] == 3) for g in self._groups]   # element-major quads recompute
         buf = None

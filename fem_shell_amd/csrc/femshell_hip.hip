@@ -2685,6 +2685,82 @@ __global__ void mitc4_geom_kernel(const double *xyz, int64_t E, double *frame, d
     for (int k = 0; k < 5; k++) acoef[e * 5 + k] = geo.a[k];
 }
 
+// status words of the stiffness kernels without the element matrices: frame / coefficient bits of quad_geometry and
+// FS_ST_BAD_JAC over the four Gauss points (what quad_stage1 reports), FS_ST_BAD_PROP for ids outside the table
+__global__ __launch_bounds__(256) void mitc4_geom_status_kernel(const double *__restrict__ xyz,
+                                                               const int32_t *__restrict__ prop_id, int32_t n_props,
+                                                               int64_t E, int32_t *__restrict__ status) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double x[4][3];
+    for (int c = 0; c < 12; c++) (&x[0][0])[c] = xyz[e * 12 + c];
+    QuadGeom geo;
+    quad_geometry(x, geo);
+    int st = geo.status;
+    for (int g = 0; g < 4; g++) {
+        const double xi = (g == 1 || g == 2) ? kGP : -kGP, eta = (g >= 2) ? kGP : -kGP;
+        double dxi[4], deta[4], ia, ib, ic, id;
+        dshape(xi, eta, dxi, deta);
+        st |= (jacobian(geo, dxi, deta, ia, ib, ic, id) > 0.0) ? 0 : FS_ST_BAD_JAC;
+    }
+    if (prop_id && (uint32_t)prop_id[e] >= (uint32_t)n_props) st |= FS_ST_BAD_PROP;
+    status[e] = st;
+}
+
+// Invariants fused_quad_k_kernel relies on when it indexes LDS and `data` with values read from the plan
+// (fs_fused_plan_check): one workgroup per patch (grid-stride), lanes over the patch's records.  err[0] = number of
+// violations, err[1] = first violated rule (1-based, see fs_fused_plan_check), err[2..3] = patch / record of it.
+__global__ __launch_bounds__(256) void fused_plan_check_kernel(int64_t n_pat, const int64_t *__restrict__ pat_eptr,
+                                                              const int32_t *__restrict__ pat_elems,
+                                                              const int64_t *__restrict__ pat_rptr,
+                                                              const fs_fused_rec *__restrict__ recs, int64_t E,
+                                                              int32_t max_patch_elems, int64_t nnz,
+                                                              unsigned long long *__restrict__ err) {
+    auto report = [&](int rule, int64_t p, int64_t r) {
+        if (atomicAdd(&err[0], 1ull) == 0) { err[1] = (unsigned long long)rule; err[2] = (unsigned long long)p; err[3] = (unsigned long long)r; }
+    };
+    for (int64_t p = blockIdx.x; p < n_pat; p += gridDim.x) {
+        const int64_t e0 = pat_eptr[p], e1 = pat_eptr[p + 1], r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
+        const int64_t ne = e1 - e0;
+        if (threadIdx.x == 0) {
+            if (ne < 1 || ne > max_patch_elems || e0 < 0) report(1, p, -1);
+            if (r1 <= r0 || (r0 & 63) || (r1 & 63) || r0 < 0) report(2, p, -1);
+            if (p == 0 && (e0 != 0 || r0 != 0)) report(2, p, -1);
+        }
+        if (ne < 1 || ne > max_patch_elems || r1 <= r0) continue;
+        for (int64_t q = threadIdx.x; q < ne; q += blockDim.x) {
+            const int64_t el = pat_elems[e0 + q];
+            if (el < 0 || el >= E) report(3, p, q);
+        }
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+            const fs_fused_rec rc = recs[r];
+            for (int k = 0; k < 2; k++) {
+                const uint32_t ev = rc.ev[k];
+                if (FS_EV_ACTIVE(ev) && (FS_EV_SLOT(ev) >= ne || FS_EV_TI(ev) > FS_EV_TJ(ev))) report(4, p, r);
+            }
+            const uint32_t fl = rc.flags;
+            const int maxc = (int)((fl >> 8) & 255u), pos = (int)((fl >> 16) & 15u);
+            if (maxc < 1 || maxc > 16 || pos >= maxc || ((fl & FS_FL_CHAIN) && (pos == 0 || (int)(r & 15) < pos))) report(5, p, r);
+            // chain length is wave-uniform (the kernel reads it with readfirstlane)
+            const uint32_t fl0 = recs[r & ~(int64_t)63].flags;
+            if (((fl0 >> 8) & 255u) != (uint32_t)maxc) report(5, p, r);
+            for (int k = 0; k < 2; k++) {
+                const bool out = (fl & (k == 0 ? FS_FL_OUT0 : FS_FL_OUT1)) != 0;
+                if (!out) continue;
+                const uint32_t sd = (rc.slots >> (16 * k)) & 255u, st = (rc.slots >> (16 * k + 8)) & 255u;
+                if (sd >= 128u) report(6, p, r);
+                const int64_t d0 = rc.dst[k], str = rc.stride[k];
+                if (d0 < 0 || (d0 & 1) || str < 6 || (str & 1) || d0 + 5 * str + 6 > nnz) report(7, p, r);
+                const int64_t dt = rc.dst_t[k], strt = rc.stride_t[k];
+                if (dt >= 0) {
+                    if (st >= 128u) report(6, p, r);
+                    if ((dt & 1) || strt < 6 || (strt & 1) || dt + 5 * strt + 6 > nnz) report(7, p, r);
+                }
+            }
+        }
+    }
+}
+
 // FS_LAYOUT_SYMBLK -> dense [E][nn*d][nn*d]
 __global__ void blk_expand_kernel(const double *__restrict__ packed, int64_t E, int nn, int d,
                                   double *__restrict__ dense, int tiled) {
@@ -2969,6 +3045,7 @@ inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
 }  // namespace
 
 int fs_fail_(int code, const char *what, int hip_error) { return fail(code, what, (hipError_t)hip_error); }
+int fs_noalloc_prepare_();
 
 extern "C" {
 
@@ -2981,6 +3058,11 @@ int fs_device_info(int device, char *name, int len, int *cu_count) {
     if (name && len > 0) snprintf(name, len, "%s", prop.gcnArchName);
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FS_ENOSYS, "device is not gfx950");
+    // set-up for fs_shell_quad_fint_noalloc: when `device` is the current device, the address of its static workspace
+    // is resolved here (hipGetSymbolAddress may load the code object), so that the entry point itself does nothing
+    // of the kind later -- e.g. under HIP graph capture
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return fs_noalloc_prepare_();
     return FS_OK;
 }
 
@@ -3411,6 +3493,25 @@ constexpr int kMaxDevices = 64;
 double *g_scratch_ptr[kMaxDevices] = {};
 std::mutex g_scratch_mu;
 
+// CU count of the CURRENT device, cached per device index (a process may drive several GPUs from several threads)
+int g_cu_count[kMaxDevices] = {};
+std::mutex g_cu_mu;
+int device_cu_count(int *out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(FS_EHIP, "hipGetDevice", e);
+    if (dev < 0 || dev >= kMaxDevices) return fail(FS_EINVAL, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_cu_mu);
+    if (!g_cu_count[dev]) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || n <= 0) return fail(FS_EHIP, "hipDeviceGetAttribute(MultiprocessorCount)", e);
+        g_cu_count[dev] = n;
+    }
+    *out = g_cu_count[dev];
+    return FS_OK;
+}
+
 // device address of `scratch` on the CURRENT device (each GPU holds its own copy at its own address)
 int scratch_ptr_current(double **out) {
     int dev = -1;
@@ -3428,6 +3529,11 @@ int scratch_ptr_current(double **out) {
     return FS_OK;
 }
 }  // namespace
+
+int fs_noalloc_prepare_() {
+    double *ws = nullptr;
+    return scratch_ptr_current(&ws);
+}
 
 extern "C" {
 
@@ -3466,14 +3572,8 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
         return fail(FS_EINVAL, "fs_fused_assemble_quad: a patch may hold at most FS_FUSED_MAX_PATCH_ELEMS elements");
     hipStream_t s = (hipStream_t)stream;
     // persistent workgroups: as many as are resident at once (one per CU with the 124 KB image), a multiple of 8
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(FS_EHIP, "fs_fused_assemble_quad: hipGetDeviceProperties");
-        cus = prop.multiProcessorCount;
-    }
+    int cus = 0;
+    if (int rc = device_cu_count(&cus)) return rc;
     int64_t wgs = ((int64_t)cus / 8) * 8;
     if (wgs < 8) wgs = 8;
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
@@ -3500,6 +3600,51 @@ int fs_debug_fused_timing(unsigned long long *out, int reset) {
     return FS_OK;
 }
 #endif
+
+int fs_shell_quad_geom_status(const double *xyz, const int32_t *prop_id, int32_t n_props, int64_t E, int32_t *status,
+                              void *stream) {
+    if (E < 0) return fail(FS_EINVAL, "fs_shell_quad_geom_status: bad sizes");
+    if (E == 0) return FS_OK;
+    if (!xyz || !status) return fail(FS_EINVAL, "fs_shell_quad_geom_status: null argument");
+    hipLaunchKernelGGL(mitc4_geom_status_kernel, dim3(grid_for(E, 256, INT32_MAX)), dim3(256), 0, (hipStream_t)stream, xyz,
+                       prop_id, n_props, E, status);
+    FS_LAUNCH_CHECK("mitc4_geom_status_kernel");
+    return FS_OK;
+}
+
+int fs_fused_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
+                        const fs_fused_rec *recs, int64_t E, int32_t max_patch_elems, int64_t nnz, void *stream) {
+    if (E < 0 || n_patches < 0 || nnz < 0) return fail(FS_EINVAL, "fs_fused_plan_check: bad sizes");
+    if (n_patches == 0) return FS_OK;
+    if (!pat_eptr || !pat_elems || !pat_rptr || !recs) return fail(FS_EINVAL, "fs_fused_plan_check: null argument");
+    if (max_patch_elems <= 0 || max_patch_elems > FS_FUSED_MAX_PATCH_ELEMS)
+        return fail(FS_EINVAL, "fs_fused_plan_check: a patch may hold at most FS_FUSED_MAX_PATCH_ELEMS elements");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *err = nullptr, host[4] = {0, 0, 0, 0};
+    hipError_t e = hipMalloc(&err, sizeof host);
+    if (e != hipSuccess) return fail(FS_EHIP, "fs_fused_plan_check: hipMalloc", e);
+    e = hipMemsetAsync(err, 0, sizeof host, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fused_plan_check_kernel, dim3(grid_for(n_patches, 1, 8192)), dim3(256), 0, s, n_patches, pat_eptr,
+                           pat_elems, pat_rptr, recs, E, max_patch_elems, nnz, err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, err, sizeof host, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(err);
+    if (e != hipSuccess) return fail(FS_EHIP, "fs_fused_plan_check", e);
+    if (host[0]) {
+        static const char *const rules[] = {"", "a patch holds no element or more than max_patch_elems",
+            "record range of a patch empty or not whole waves", "element index outside [0, E)",
+            "contribution names a slot beyond its patch or ti > tj", "chain flags inconsistent",
+            "staging slot / rank byte out of range", "destination outside the value array or misaligned"};
+        char msg[256];
+        snprintf(msg, sizeof msg, "fs_fused_plan_check: %llu violations; first: %s (patch %lld, record %lld)", host[0],
+                 rules[host[1] < 8 ? host[1] : 0], (long long)host[2], (long long)host[3]);
+        return fail(FS_EINVAL, msg);
+    }
+    return FS_OK;
+}
 
 int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e, void *stream) {
     if (n <= 0) return n == 0 ? FS_OK : fail(FS_EINVAL, "fs_gather_dofs: n < 0");

@@ -277,7 +277,7 @@ class DistributedAssembler:
     `mesh` is the rank's local ArrayMesh; `l2g` its global node ids.  For the bench's x-strip
     partition pass strip=(rank, world, nx, ny) and l2g is derived."""
 
-    def __init__(self, mesh, model, l2g=None, strip=None, overlap=False):
+    def __init__(self, mesh, model, l2g=None, strip=None, overlap=False, cache_blocks=True):
         """overlap=True runs pack -> send/recv -> add on a side stream: the caller's stream goes straight on
         (e.g. to the next element kernel, which does not touch the CSR values) and joins again at the next
         assemble_* call or at finish().  The returned matrix is complete only after finish()."""
@@ -304,7 +304,7 @@ class DistributedAssembler:
         sel = X[pos] == l2g                      # local nodes no element references are not part of the plan
         coords[pos[sel]] = mesh.coords[sel]
         ext = ArrayMesh(coords, self.dplan.conn_x, mesh.set_id, mesh.set_names)
-        self.local = MeshAssembler(ext, model, plan=self.dplan.plan)
+        self.local = MeshAssembler(ext, model, plan=self.dplan.plan, cache_blocks=cache_blocks)
         dev = self.local.device
         self._send = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.send_idx.items()}
         self._recv = {q: torch.from_numpy(i).to(dev) for q, i in self.dplan.recv_idx.items()}

@@ -164,10 +164,12 @@ def flat_patch(x0, x1, y0, y1, nx, ny, triangular=False, surface_z=None):
     return ArrayMesh(np.stack([X, Y, Z], -1).reshape(-1, 3), structured_conn(nx, ny, triangular))
 
 
-def jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=0):
+def jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=0, band=None):
     """Synthetic C5 laminate plate: nx x ny MITC4+ cells of size `cell`, nodes
     jittered +-5 % in-plane and +-1 % out-of-plane so every element is distinct and warped;
-    `n_sets` property sets striped by x-band. `x_offset_cells` shifts the strip (rank shards)."""
+    `n_sets` property sets striped by x-band. `x_offset_cells` shifts the strip (rank shards).
+    band=None: ceil(nx / n_sets) columns per band, counted from the piece's own first column; band=k: bands of k
+    columns of the GLOBAL plate cycling through the sets, so that an x-strip is exactly its part of the whole plate."""
     ix = np.arange(nx + 1, dtype=np.int64) + x_offset_cells
     iy = np.arange(ny + 1, dtype=np.int64)
     IX, IY = np.meshgrid(ix, iy)
@@ -180,8 +182,10 @@ def jittered_plate(nx, ny, cell=1e-3, seed=11, n_sets=16, x_offset_cells=0):
     coords[:, 1] += (hash_uniform(gid, seed + 1) - 0.5) * 0.1 * cell
     coords[:, 2] += (hash_uniform(gid, seed + 2) - 0.5) * 0.02 * cell
     conn = structured_conn(nx, ny)
-    band = max(1, -(-nx // n_sets))
-    set_id = np.tile((np.arange(nx) // band).astype(np.int32) % n_sets, ny)
+    if band is None:
+        set_id = np.tile((np.arange(nx) // max(1, -(-nx // n_sets))).astype(np.int32) % n_sets, ny)
+    else:
+        set_id = np.tile(((np.arange(nx) + x_offset_cells) // int(band)).astype(np.int32) % n_sets, ny)
     return ArrayMesh(coords, conn, set_id, [f"band_{i}" for i in range(n_sets)])
 
 

@@ -90,7 +90,8 @@ FS_STATIC_ASSERT(offsetof(fs_shell_prop, Cs) == 216 && offsetof(fs_shell_prop, h
                  offsetof(fs_shell_prop, flags) == 360, "fs_shell_prop field offsets");
 
 const char *fs_last_error(void);
-/* library / device probe: returns FS_OK when a gfx950 device is usable; fills name (<=len). */
+/* library / device probe: returns FS_OK when a gfx950 device is usable; fills name (<=len).  Also the library's set-up
+ * call for fs_shell_quad_fint_noalloc (see there) when `device` is the current device. */
 int fs_device_info(int device, char *name, int len, int *cu_count);
 
 /*
@@ -276,6 +277,13 @@ int fs_stress_invariants(const double *voigt, int64_t N, int32_t is_3d, int32_t 
 int fs_shell_quad_geom(const double *xyz, int64_t E, double *frame, double *xl, double *detJ,
                        double *acoef, void *stream);
 
+/* Status words alone: the FS_ST_* bits fs_shell_quad_batch(FS_WANT_K) would report (degenerate frame, failed
+ * coefficient solve, det J <= 0 at a Gauss point, prop_id outside [0, n_props) when prop_id != NULL) without evaluating
+ * element matrices -- the geometry checks of the reference's constructor loop (core/assembler.py:160-164 ->
+ * MITC4.__init__, elements/MITC4.py:52-99,436-476) for callers that assemble through fs_fused_assemble_quad only. */
+int fs_shell_quad_geom_status(const double *xyz, const int32_t *prop_id, int32_t n_props, int64_t E, int32_t *status,
+                              void *stream);
+
 /* FS_LAYOUT_SYMBLK / FS_LAYOUT_SYMBLK_T16 (`layout`) -> FS_LAYOUT_DENSE ([E][nn*d][nn*d]);
  * nn nodes/element, d dofs/node. */
 int fs_blk_expand(const double *packed, uint32_t layout, int64_t E, int32_t nn, int32_t d, double *dense,
@@ -380,6 +388,20 @@ int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_s
                            int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
                            const int64_t *pat_rptr, const fs_fused_rec *recs, int32_t max_patch_elems,
                            uint32_t flags, double *data, int32_t *status, void *stream);
+
+/*
+ * fs_fused_assemble_quad TRUSTS its plan: the kernel indexes LDS with the slots, ranks and chain positions of the
+ * records and `data` with their destinations.  Plans of fs_fused_plan_build satisfy every invariant by construction; a
+ * plan from anywhere else must pass fs_fused_plan_check ONCE before its first launch (device pointers; synchronises
+ * `stream`, allocates 32 bytes).  Checked: every patch holds 1..max_patch_elems elements with indices in [0, E) and a
+ * non-empty record range of whole waves; every active contribution names a slot of its patch with ti <= tj; chain
+ * length (1..16, uniform over a wave) and chain positions are consistent; staging slots and transposed ranks are below
+ * 128; every destination block (and transposed copy) lies inside [0, nnz) with even offsets and strides (the stores
+ * are 16 bytes wide).  Returns FS_EINVAL (fs_last_error names the first violated rule) instead of a GPU fault.
+ * No counterpart in the reference.
+ */
+int fs_fused_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
+                        const fs_fused_rec *recs, int64_t E, int32_t max_patch_elems, int64_t nnz, void *stream);
 
 /*
  * The plan of fs_fused_assemble_quad, built on the HOST in native code (OpenMP over patches; all pointers of these
@@ -509,6 +531,10 @@ int fs_inertial_forces(const double *coords, const double *vel, const double *ma
  * elements' linear blocks, 2 880 B per element) lives in a static device array of the library, 47 185 920 B on every
  * GPU the entry point is used on, held until the process ends.  The call allocates nothing (no hipMalloc / hipFree).
  *   E > FS_FINT_NOALLOC_MAX_E  ->  FS_EINVAL (use fs_shell_quad_batch with your own workspace)
+ * Set-up: the array's device address is resolved once per GPU -- by fs_device_info(dev, ...) when `dev` is the
+ * current device (call it once per GPU, with that GPU current, BEFORE a graph capture that contains this entry point),
+ * else by the first call on that GPU (which must then happen outside a capture).  `stream` must belong to the current
+ * device.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race;
  * serialise them.  Nothing has to be cleared between calls (every workspace block that is read is rewritten first).
  */

@@ -133,6 +133,41 @@ int main(int argc, char **argv) {
             to_dev(&d_elems, h_elems, (size_t)nslots * 4) || to_dev(&d_recs, h_recs, (size_t)nrecs * sizeof(fs_fused_rec)) ||
             to_dev(&d_Kf, NULL, (size_t)nnz * 8) || to_dev(&d_stf, NULL, (size_t)E * 4))
             return 2;
+        /* a plan from anywhere else than fs_fused_plan_build must pass fs_fused_plan_check before its first launch: the
+         * built plan passes; a corrupted copy (slot beyond the patch, destination past the value array, empty patch)
+         * comes back as FS_EINVAL -- it is never launched */
+        FSCHK(fs_fused_plan_check(npat, d_eptr, d_elems, d_rptr, d_recs, E, FS_FUSED_MAX_PATCH_ELEMS, nnz, s));
+        {
+            fs_fused_rec *bad = malloc((size_t)nrecs * sizeof(fs_fused_rec) + 1);
+            void *d_bad;
+            int64_t first_out = -1, first_act = -1;
+            for (int64_t i = 0; i < nrecs; i++) {
+                if (first_out < 0 && (h_recs[i].flags & FS_FL_OUT0)) first_out = i;
+                if (first_act < 0 && (h_recs[i].ev[0] & (1u << 13))) first_act = i;
+            }
+            if (first_out < 0 || first_act < 0) return 10;
+            memcpy(bad, h_recs, (size_t)nrecs * sizeof(fs_fused_rec));
+            bad[first_act].ev[0] |= 255u;
+            if (to_dev(&d_bad, bad, (size_t)nrecs * sizeof(fs_fused_rec))) return 2;
+            if (fs_fused_plan_check(npat, d_eptr, d_elems, d_rptr, d_bad, E, FS_FUSED_MAX_PATCH_ELEMS, nnz, s) != FS_EINVAL ||
+                !strstr(fs_last_error(), "slot"))
+                return 10;
+            memcpy(bad, h_recs, (size_t)nrecs * sizeof(fs_fused_rec));
+            bad[first_out].dst[0] = nnz - 4;
+            HIPCHK(hipMemcpy(d_bad, bad, (size_t)nrecs * sizeof(fs_fused_rec), hipMemcpyHostToDevice));
+            if (fs_fused_plan_check(npat, d_eptr, d_elems, d_rptr, d_bad, E, FS_FUSED_MAX_PATCH_ELEMS, nnz, s) != FS_EINVAL ||
+                !strstr(fs_last_error(), "destination"))
+                return 10;
+            if (npat >= 2) {
+                int64_t *be = malloc((size_t)(npat + 1) * 8);
+                void *d_be;
+                memcpy(be, h_eptr, (size_t)(npat + 1) * 8);
+                be[1] = be[0];                                   /* patch 0 without elements */
+                if (to_dev(&d_be, be, (size_t)(npat + 1) * 8)) return 2;
+                if (fs_fused_plan_check(npat, d_be, d_elems, d_rptr, d_recs, E, FS_FUSED_MAX_PATCH_ELEMS, nnz, s) != FS_EINVAL)
+                    return 10;
+            }
+        }
         uint32_t fl = 0;
         for (int64_t i = 0; i < P; i++)
             if (props[i].flags & FS_PROP_COUPLED) fl = FS_FUSED_HAS_COUPLED;

@@ -92,6 +92,14 @@ def test_c2_hemisphere_256(oracle, tri):
     err, sym, rb = _common_checks(asm, mesh, K, oracle, nodes, rng)
     print("C2", "MITC3+" if tri else "MITC4+", "rows vs oracle", err, "symmetry", sym, "rigid translation", rb)
     assert err < 1e-12 and sym < 1e-12 and rb < 1e-9
+    if not tri:
+        # the headline kernel itself (fs_fused_assemble_quad) on this configuration, against the oracle directly
+        Kf = asm.assemble_stiffness_matrix(recompute=True)
+        assert asm._fplan is not None
+        errf = _sample_rows(asm, mesh, Kf, oracle, "K", nodes)
+        print("C2 MITC4+ fused rows vs oracle", errf, "vs two-kernel route", float((Kf.data - K.data).abs().max() / K.data.abs().max()))
+        assert errf < 1e-12 and float((Kf.data - K.data).abs().max()) <= 1e-13 * float(K.data.abs().max())
+        asm.check_status()
     M = asm.assemble_mass_matrix()
     assert _sample_rows(asm, mesh, M, oracle, "M", nodes[:16]) < 1e-12
     # total mass: sum of the u-u entries = rho h area of the patch (R^2 (cos 18 - cos 90) pi/2), faceted
@@ -165,6 +173,13 @@ def test_c3_blade_like_tube(oracle):
     err, sym, rb = _common_checks(asm, mesh, K, oracle, nodes, rng)
     print("C3 rows vs oracle", err, "symmetry", sym, "rigid translation", rb)
     assert err < 1e-12 and sym < 1e-12 and rb < 1e-9
+    # the headline kernel itself (fs_fused_assemble_quad, coupled variant) on this configuration, against the oracle
+    Kf = asm.assemble_stiffness_matrix(recompute=True)
+    assert asm._fplan is not None
+    errf = _sample_rows(asm, mesh, Kf, oracle, "K", nodes)
+    print("C3 fused rows vs oracle", errf, "vs two-kernel route", float((Kf.data - K.data).abs().max() / K.data.abs().max()))
+    assert errf < 1e-12 and float((Kf.data - K.data).abs().max()) <= 1e-13 * float(K.data.abs().max())
+    asm.check_status()
     M = asm.assemble_mass_matrix()
     lumped = M.lump_rows()
     # mass check: lumped translational mass == sum over elements of m_t * area (oracle element masses)

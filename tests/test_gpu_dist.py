@@ -305,3 +305,64 @@ def test_nccl_backend_world_1():
     p.join(30)
     assert err is None, err
     assert E == 48 * 40 and nnz == 36 * (3 * 49 - 2) * (3 * 41 - 2) and overlap is True and rank == 0
+
+
+def _worker_bench(rank, world, port, nx, ny, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from fem_shell_amd import meshes
+        from fem_shell_amd.assembler import MeshAssembler
+        from fem_shell_amd.elements import ElementFamily
+        res, A, da = bench.plate_run(torch, dist, rank, world, nx, ny, 2, 1, True, return_matrix=True)
+        da.finish()
+        torch.cuda.synchronize()
+        assert res["E"] == nx * ny and res["exchange_ms"] > 0 and da.local._K_blk is None
+        # the serial plate of the same bench workload (global laminate bands), through the same fused kernel
+        lams = bench.c5_laminates()
+        g = meshes.jittered_plate(nx * world, ny, cell=1e-3, seed=11, n_sets=16, band=bench.BAND)
+        ser = MeshAssembler(g, {"elements": {"element_family": ElementFamily.SHELL,
+                                             "properties": {g.set_names[i]: lams[i] for i in range(16)}}}, cache_blocks=False)
+        ref = ser.assemble_stiffness_matrix(recompute=True).to_scipy()
+        assert ser._K_blk is None
+        ip, ix, data = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy()
+        X = da.dplan.nodes_g
+        worst = 0.0
+        for r in np.flatnonzero(da.owned_rows):
+            gr = 6 * X[r // 6] + r % 6
+            cols = 6 * X[ix[ip[r]:ip[r + 1]] // 6] + ix[ip[r]:ip[r + 1]] % 6
+            assert np.array_equal(cols, ref.indices[ref.indptr[gr]:ref.indptr[gr + 1]])
+            worst = max(worst, np.abs(data[ip[r]:ip[r + 1]] - ref.data[ref.indptr[gr]:ref.indptr[gr + 1]]).max())
+        assert worst <= 1e-13 * np.abs(ref.data).max(), worst
+        q.put((rank, int(da.owned_rows.sum()), None))
+    except BaseException:  # noqa: BLE001  (SystemExit of the bench included)
+        import traceback
+        q.put((rank, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_strong_scaling_strips_two_ranks():
+    """bench.py --gpus N cuts ONE plate into N x-strips (strong scaling).  The bench's own plate_run(distributed=True)
+    with 2 ranks on this GPU (gloo): owned rows of both strips equal the serial plate of the same workload (global
+    laminate bands: a band boundary falls inside each strip), no element blocks in memory (cache_blocks=False)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, nx, ny = 2, 40, 21
+    procs = [ctx.Process(target=_worker_bench, args=(r, world, port, nx, ny, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, n, err in res:
+        assert err is None, err
+    assert sum(n for _, n, _ in res) == 6 * (nx * world + 1) * (ny + 1)

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import fem_shell_amd as fsa
-from fem_shell_amd import meshes
+from fem_shell_amd import _lib, meshes
 from fem_shell_amd.elements import ElementFamily
 from tests import util
 
@@ -149,3 +149,96 @@ def test_fused_small_and_ragged_meshes():
         torch.cuda.synchronize()
         assert bool((_bits(Kf.data) == _bits(K2.data)).all()), (nx, ny, "K")
         assert bool((_bits(Mf.data) == _bits(M2.data)).all()), (nx, ny, "M")
+
+
+def test_mesh_beyond_the_plan_limits_falls_back_to_two_kernels():
+    """A pole node of valence 40: its diagonal block has 40 contributions (fs_fused_plan_build allows 32) -- the default
+    entry points must not raise, they remember the mesh as not fusable and take element kernel + assembly kernel."""
+    from fem_shell_amd.assembler import MeshAssembler
+    coords, conn = fan_mesh(40, seed=2)
+    mesh = meshes.ArrayMesh(coords, conn)
+    iso = {"element_family": ElementFamily.SHELL, "material": fsa.IsotropicMaterial("m", 6.825e7, 0.3, 1.0), "thickness": 0.04}
+    ref = MeshAssembler(mesh, {"elements": iso})
+    K2 = ref.assemble_stiffness_matrix(recompute=True, fused=False)
+    M2 = ref.assemble_mass_matrix(recompute=True, fused=False)
+    for cache in (True, False):
+        asm = MeshAssembler(mesh, {"elements": iso}, cache_blocks=cache)
+        M = asm.assemble_mass_matrix()                     # default route: tries the fused plan first
+        K = asm.assemble_stiffness_matrix(recompute=True)
+        assert not asm.can_fuse and asm._fplan_error is not None and "32" in str(asm._fplan_error)
+        assert bool((_bits(K.data) == _bits(K2.data)).all()) and bool((_bits(M.data) == _bits(M2.data)).all())
+        with pytest.raises(NotImplementedError):
+            asm.assemble_stiffness_fused()
+
+
+def test_cache_blocks_false_keeps_no_element_matrices(oracle):
+    """MeshAssembler(cache_blocks=False): the constructor checks the geometry through fs_shell_quad_geom_status, K and M
+    come from the fused kernel, the element blocks appear only when `_ke_array` or the Newton path ask for them."""
+    from fem_shell_amd.assembler import MeshAssembler
+    p8 = util.standard_props()
+    mesh = meshes.jittered_plate(23, 17, n_sets=8)
+    model = {"element_family": ElementFamily.SHELL, "nonlinear": True,
+             "properties": {nm: p8[i % 8] for i, nm in enumerate(mesh.set_names)}}
+    full = MeshAssembler(mesh, {"elements": model})
+    lazy = MeshAssembler(mesh, {"elements": model}, cache_blocks=False)
+    assert lazy._K_blk is None and torch.equal(lazy._status[0], full._status[0])
+    K, Kl = full.assemble_stiffness_matrix(recompute=True), lazy.assemble_stiffness_matrix()
+    assert lazy._K_blk is None and bool((_bits(K.data) == _bits(Kl.data)).all())
+    assert bool((_bits(full.assemble_mass_matrix().data) == _bits(lazy.assemble_mass_matrix().data)).all())
+    lazy.check_status()
+    u = 1e-3 * torch.from_numpy(np.random.default_rng(0).standard_normal(lazy.dofs_count)).to(lazy.device)
+    (KT, f), (KTl, fl) = full.assemble_tangent_and_forces(u), lazy.assemble_tangent_and_forces(u)
+    assert lazy._K_blk is not None                         # evaluated on first use
+    assert bool((_bits(KT.data) == _bits(KTl.data)).all()) and torch.equal(f, fl)
+    assert np.array_equal(full._ke_array[:5], lazy._ke_array[:5])
+    # a degenerate element is still caught by the constructor
+    bad = meshes.jittered_plate(6, 5, n_sets=8)
+    bad.coords[bad.conn[7]] = bad.coords[bad.conn[7, 0]]
+    with pytest.raises(ValueError, match="degenerate"):
+        MeshAssembler(bad, {"elements": model}, cache_blocks=False)
+    # the status words of a fused re-evaluation replace the constructor's (inputs mutated in place)
+    pid = lazy._groups[0]["pid_d"]
+    pid[3] = 999
+    lazy.assemble_stiffness_matrix(recompute=True)
+    with pytest.raises(ValueError, match="element 3"):
+        lazy.check_status()
+
+
+def test_plan_check_rejects_malformed_plans():
+    """fs_fused_plan_check: a plan of fs_fused_plan_build passes; corrupted ones (empty patch, slot beyond the patch,
+    destination outside the value array, rank byte out of range, odd destination) return FS_EINVAL -- no launch."""
+    from fem_shell_amd.assembler import MeshAssembler
+    from fem_shell_amd.fused import REC_DTYPE
+    mesh = meshes.jittered_plate(30, 20, n_sets=1)
+    iso = {"element_family": ElementFamily.SHELL, "material": fsa.IsotropicMaterial("m", 6.825e7, 0.3, 1.0), "thickness": 0.04}
+    asm = MeshAssembler(mesh, {"elements": iso})
+    fp = asm.fused_plan()
+    lib, dev, nnz = _lib.load(), asm.device, asm._plan.nnz
+
+    def check(eptr=None, elems=None, rptr=None, recs=None):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        a = [t(fp.pat_eptr if eptr is None else eptr), t(fp.pat_elems if elems is None else elems),
+             t(fp.pat_rptr if rptr is None else rptr), t((fp.recs if recs is None else recs).view(np.uint8).reshape(-1))]
+        rc = lib.fs_fused_plan_check(fp.n_patches, *[_lib.ptr(x) for x in a], mesh.conn.shape[0], fp.max_patch_elems, nnz,
+                                     _lib.stream_ptr())
+        return rc, lib.fs_last_error().decode()
+
+    assert check()[0] == 0
+    e = fp.pat_eptr.copy(); e[2] = e[1]                                    # patch 1 holds no element
+    assert check(eptr=e)[0] == -22
+    el = fp.pat_elems.copy(); el[5] = mesh.conn.shape[0]                   # element index == E
+    rc, msg = check(elems=el); assert rc == -22 and "element index" in msg
+    r = fp.pat_rptr.copy(); r[3] += 1                                      # not whole waves
+    assert check(rptr=r)[0] == -22
+    act = np.flatnonzero(fp.recs["ev"][:, 0] & (1 << 13))
+    rc_ = fp.recs.copy(); rc_["ev"][act[10], 0] |= 255                     # slot 255 of a patch of <= 64
+    rc, msg = check(recs=rc_); assert rc == -22 and "slot" in msg
+    out = np.flatnonzero(fp.recs["flags"] & 2)
+    rc_ = fp.recs.copy(); rc_["dst"][out[7], 0] = nnz - 8                  # block would run past the end
+    rc, msg = check(recs=rc_); assert rc == -22 and "destination" in msg
+    rc_ = fp.recs.copy(); rc_["dst"][out[7], 0] += 1                       # misaligned 16-byte stores
+    assert check(recs=rc_)[0] == -22
+    rc_ = fp.recs.copy(); rc_["slots"][out[9]] = (rc_["slots"][out[9]] & ~np.uint32(0xFF)) | np.uint32(200)
+    rc, msg = check(recs=rc_); assert rc == -22 and "slot" in msg
+    rc_ = fp.recs.copy(); rc_["flags"][out[3]] |= np.uint32(15 << 16)      # chain position beyond the chain
+    assert check(recs=rc_)[0] == -22

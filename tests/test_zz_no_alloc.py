@@ -88,3 +88,36 @@ def test_noalloc_fint_limits():
     got, _ = _noalloc(lib, xyz_d, pid_d, props_d, props.shape[0], u_d, E)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+def test_noalloc_fint_under_graph_capture():
+    """The use case the entry point exists for: after the set-up call (fs_device_info on the current device resolves
+    the workspace address) it is captured in a HIP graph -- nothing in it allocates or resolves symbols -- and the
+    replays reproduce the eager result bit for bit, also with new inputs written into the captured buffers."""
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    name = ctypes.create_string_buffer(64)
+    cus = ctypes.c_int()
+    assert lib.fs_device_info(torch.cuda.current_device(), name, 64, ctypes.byref(cus)) == 0
+    E = 2000
+    props, xyz, pid, u = _inputs(E, 9)
+    props_d = to_device_props(props)
+    xyz_d, pid_d, u_d = (torch.from_numpy(a).to(dev) for a in (xyz, pid, u))
+    fe = torch.zeros((E, 24), dtype=torch.float64, device=dev)
+    st = torch.zeros(E, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        _lib.check(lib.fs_shell_quad_fint_noalloc(_lib.ptr(xyz_d), _lib.ptr(pid_d), _lib.ptr(props_d), props.shape[0],
+                                                  _lib.ptr(u_d), E, _lib.ptr(fe), _lib.ptr(st), _lib.stream_ptr()),
+                   "fs_shell_quad_fint_noalloc (capture)")
+    for seed in (9, 10):
+        _, _, _, u2 = _inputs(E, seed)
+        u_d.copy_(torch.from_numpy(u2).to(dev))
+        fe.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref, _ = _existing(lib, xyz_d, pid_d, props_d, props.shape[0], u_d, E)
+        torch.cuda.synchronize()
+        assert torch.equal(fe, ref)
