@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         r0n = pat_rptr[p + wpx]; r1n = pat_rptr[p + wpx + 1];
     }
 #ifdef FS_FUSED_TIMING
-    unsigned long long acc_[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc_[19] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -832,9 +832,13 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             for (int t = 0; t < 8; t++) el.tacc[t] = 0;
             el.tick = __builtin_readcyclecounter();
 #endif
+#ifdef FS_FUSED_TIMING
+            acc_[18] += el.tick - tick_;       // loop top .. call of quad_stage1 (prefetch issue, waits for the inputs)
+#endif
             quad_stage1(x, pr, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
 #ifdef FS_FUSED_TIMING
             for (int t = 0; t < 7; t++) acc_[7 + t] += el.tacc[t];
+            acc_[17] += el.tacc[7];
 #endif
             double *ex = img + Q;
             if (COUPLED && !wave_coupled)
@@ -1023,7 +1027,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
         FS_TICK(5);
 #ifdef FS_FUSED_TIMING
         if (!more && lane == 0)
-            for (int ph = 0; ph < 17; ph++) atomicAdd(&g_fused_t[ph], acc_[ph]);
+            for (int ph = 0; ph < 19; ph++) atomicAdd(&g_fused_t[ph], acc_[ph]);
 #endif
         if (!more) break;
         __syncthreads();        // every wave is done with the image: stage 1 of the next patch may overwrite it
@@ -3631,7 +3635,7 @@ int fs_fused_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_
     }
     if (e == hipSuccess) e = hipMemcpyAsync(host, err, sizeof host, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(err);
+    (void)hipFree(err);
     if (e != hipSuccess) return fail(FS_EHIP, "fs_fused_plan_check", e);
     if (host[0]) {
         static const char *const rules[] = {"", "a patch holds no element or more than max_patch_elems",

@@ -33,6 +33,8 @@ names1 = ["geometry", "tying tangents", "Jacobian store, blend, W, S partial", "
 print("inside stage 1:")
 for n, v in zip(names1, t1):
     print(f"  {n:46s} {100 * v / t.sum():5.1f} %   {ms * v / t.sum():.3f} ms")
+print(f"  {'property-row loads issued (phase 7)':46s} {100 * out[17] / t.sum():5.1f} %")
+print(f"  {'loop top .. quad_stage1 (prefetch issue, waits)':46s} {100 * out[18] / t.sum():5.1f} %")
 print("inside staging + stores:")
 for n, v in zip(["slot bookkeeping before the passes", "staging writes (+ wave sync)", "read-back + global stores (+ wave sync)"], t2):
     print(f"  {n:46s} {100 * v / t.sum():5.1f} %   {ms * v / t.sum():.3f} ms")
