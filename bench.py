@@ -232,13 +232,34 @@ def hex8_leg(torch, steps=5):
     torch.cuda.synchronize()
     setup = time.perf_counter() - t0
     k_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=True, want_M=False, check=False), steps)
-    a_ms = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=False), steps)
+    a_ms = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=False, fused=False), steps)
     E = conn.shape[0]
+    # the fused evaluate-and-assemble kernel (fs_fused_assemble_hex8): the default of assemble_stiffness_matrix(recompute=True)
+    fused = None
+    if asm.fused_ready():
+        t1 = time.perf_counter()
+        f_ms = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=True), steps)
+        Kf = asm.assemble_stiffness_matrix(recompute=True)
+        K2 = asm.assemble_stiffness_matrix(recompute=True, fused=False)
+        dev_rel = float((Kf.data - K2.data).abs().max() / K2.data.abs().max())
+        fb = 192.0 + 8.0 * K.nnz / E          # SURVEY.md 8(d) form: coordinates in, CSR values out
+        gbs = E * fb / (f_ms * 1e-3) / 1e9
+        fused = {"ms_per_step": f_ms, "elements_per_s": E / (f_ms * 1e-3), "max_rel_dev_from_two_kernel_route": dev_rel,
+                 "plan": asm.fused_plan().stats(),
+                 "roofline": {"kernel": "fused_hex8_kernel", "kernel_ms": f_ms, "bound": "hbm", "achieved": gbs,
+                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "bytes_per_element": fb,
+                              "note": "algorithmic bytes: 192 B coordinates + 8 nnz / E CSR values; the kernel contracts over the "
+                                      "Gauss points first (K = C : sum_q g g^T): about 15 kflop per element executed incl. the "
+                                      "halo, against 47 kflop of the B^T C B form (SURVEY.md 8d)"}}
+        del Kf, K2
     flop = 47000.0                    # SURVEY.md 8(d) estimate for the 2x2x2 HEXA8 stiffness (not re-derived)
     # element kernel: 192 B coordinates in, 36 upper 3x3 node-pair blocks out; assembly: those blocks in, CSR values out
     a_bytes = 36 * 72 + 8.0 * K.nnz / E
-    return {"workload": f"{nx}x{ny}x{nz}={E} jittered HEXA8, orthotropic C, SOLID-family assembler (two kernels per step)",
-            "value": E / ((k_ms + a_ms) * 1e-3), "unit": "elements/s", "nnz": int(K.nnz), "setup_s": setup,
+    return {"workload": f"{nx}x{ny}x{nz}={E} jittered HEXA8, orthotropic C, SOLID-family assembler; value = fused "
+                        "evaluate-and-assemble kernel (one launch per step), two_kernel_* = element kernel + assembly kernel",
+            "value": (E / (fused["ms_per_step"] * 1e-3)) if fused else E / ((k_ms + a_ms) * 1e-3), "unit": "elements/s",
+            "fused": fused, "two_kernel_ms_per_step": k_ms + a_ms, "two_kernel_elements_per_s": E / ((k_ms + a_ms) * 1e-3),
+            "nnz": int(K.nnz), "setup_s": setup,
             "kernels": {
                 "solid_kernel<8>": {"kernel_ms": k_ms, "bound": "valu_fp64", "achieved": E * flop / (k_ms * 1e-3) / 1e12,
                                     "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",

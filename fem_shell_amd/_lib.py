@@ -15,6 +15,7 @@ FS_INERTIAL_CENTRIFUGAL, FS_INERTIAL_CORIOLIS, FS_INERTIAL_EULER = 1, 2, 4
 FS_FUSED_HAS_COUPLED = 1
 FS_FUSED_MASS = 2
 FS_FUSED_MAX_PATCH_ELEMS = 64
+FS_HEX_MAX_PATCH_ELEMS, FS_HEX_MAX_PATCH_NODES, FS_HEX_MAX_PATCH_LANES = 100, 64, 512
 
 _vp, _i64, _i32, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
 
@@ -29,6 +30,11 @@ SIGNATURES = {
                                               _vp, _vp, _vp]),
     "fs_fused_plan_check": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp]),
     "fs_shell_quad_geom_status": (ctypes.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "fs_fused_assemble_hex8": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                              _vp, _vp, _vp]),
+    "fs_fused_hex_plan_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_fused_hex_plan_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_fused_hex_plan_free": (None, [_vp]),
     "fs_fused_plan_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "fs_fused_plan_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_plan_free": (None, [_vp]),

@@ -273,7 +273,7 @@ class MeshAssembler:
         self._desc_d = self._plan_d["desc"]
         # K of every element now (this is also the geometry check of the reference's constructor loop); M on first use
         # (assemble_mass_matrix / _me_array): the reference evaluates both up front, here that would only cost memory
-        if self._cache_blocks or not self.can_fuse:
+        if self._cache_blocks or not (self.can_fuse and fam == ElementFamily.SHELL):
             self.refresh_element_matrices(want_K=True, want_M=False)
         else:
             self._status = [self._geometry_status()]
@@ -419,19 +419,26 @@ class MeshAssembler:
     # ------------------------------------------------------------------ fused evaluate-and-assemble
     @property
     def can_fuse(self):
-        """The fused kernel covers uniform MITC4+ meshes (one quad group, 6 dofs per node) whose patch plan can be
-        built (see fused_ready)."""
-        return (self._family == ElementFamily.SHELL and len(self._groups) == 1 and self._groups[0]["nn"] == 4
-                and self._groups[0]["pos"] is None and self._fplan_error is None)
+        """The fused kernels cover uniform MITC4+ meshes (one quad group, 6 dofs per node) and uniform HEXA8 meshes with
+        the full 2 x 2 x 2 rule (3 dofs per node) whose patch plan can be built (see fused_ready)."""
+        if self._fplan_error is not None or len(self._groups) != 1 or self._groups[0]["pos"] is not None:
+            return False
+        if self._family == ElementFamily.SHELL:
+            return self._groups[0]["nn"] == 4
+        return self._groups[0]["nn"] == 8 and not self._reduced      # HEXA8, full rule: fs_fused_assemble_hex8
 
     def fused_plan(self):
         """Patch plan of fs_fused_assemble_quad (fem_shell_amd/fused.py), built on first use."""
         if self._fplan_d is None:
-            from .fused import FusedQuadPlan
+            from .fused import FusedHexPlan, FusedQuadPlan
             host = self._plan.host() if hasattr(self._plan, "host") else self._plan
-            self._fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems)
+            if self._family == ElementFamily.SOLID:
+                self._fplan = FusedHexPlan(host, self._conn, self._coords)
+                self._fused_flags = 0
+            else:
+                self._fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems)
+                self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
             self._fplan_d = self._fplan.to_device(self.device)
-            self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
         return self._fplan
 
     def fused_ready(self):
@@ -456,12 +463,25 @@ class MeshAssembler:
         refresh_element_matrices() + the descriptor assembly.  `status`: optional int32 [E] device tensor.
         mass=True: the consistent mass matrix the same way (FS_FUSED_MASS; MITC4.M, core/assembler.py:305-336)."""
         if not self.can_fuse:
-            raise NotImplementedError("the fused kernel covers uniform MITC4+ quad meshes"
+            raise NotImplementedError("the fused kernels cover uniform MITC4+ quad meshes and HEXA8 meshes (full rule)"
                                       + (f" (plan: {self._fplan_error})" if self._fplan_error is not None else ""))
         fp = self.fused_plan()
         d, g = self._fplan_d, self._groups[0]
         lib = _lib.load()
         data = torch.empty(self._plan.nnz, dtype=torch.float64, device=self.device)
+        if self._family == ElementFamily.SOLID:
+            # HEXA8.K of every element (elements/SOLID.py:543-567) and the ADD_VALUES loop (core/assembler.py:287-303)
+            if mass:
+                raise NotImplementedError("the fused HEXA8 kernel forms K (the mass matrix keeps the two-kernel route)")
+            if status is not None:
+                status.zero_()                     # the kernel ORs FS_ST_BAD_JAC in
+            _lib.check(lib.fs_fused_assemble_hex8(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+                                                  len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
+                                                  _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_nptr"]), _lib.ptr(d["nodes"]),
+                                                  _lib.ptr(d["pat_rptr"]), _lib.ptr(d["runs"]), _lib.ptr(d["pat_lptr"]),
+                                                  _lib.ptr(d["steps"]), _lib.ptr(data), _lib.ptr(status), _lib.stream_ptr()),
+                       "fs_fused_assemble_hex8")
+            return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
         _lib.check(lib.fs_fused_assemble_quad(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
                                               len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
                                               _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]),
@@ -495,7 +515,7 @@ class MeshAssembler:
         mass matrices in memory; `_me_array` still materialises them on demand); fused=False forces element kernel +
         assembly kernel (same bits)."""
         fused = self.use_fused if fused is None else fused
-        if (recompute or self._M_blk is None) and fused and self.fused_ready():
+        if (recompute or self._M_blk is None) and fused and self._family == ElementFamily.SHELL and self.fused_ready():
             return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True, check=False)

@@ -1,0 +1,261 @@
+// femshell_fused_hex.hip -- fused evaluate-and-assemble for HEXA8 (fs_fused_assemble_hex8, include/femshell_hip.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (csrc/Makefile).  Citations: /root/reference/src/fem_shell/.
+//
+// One launch replaces HEXA8.K of every element (elements/SOLID.py:543-567) and the ADD_VALUES loop over the element
+// matrices (core/assembler.py:287-303).  Gather form, one workgroup (512 lanes, persistent, XCD-contiguous patch ranges)
+// per PATCH of nodes:
+//   phase 1  lane = (element slot, Gauss point): Jacobian, inverse, w detJ and the physical gradients of the 8 shape
+//            functions (SOLID.py:164-266, rule :1745-1766, N :1768-1818) with the expressions of solid_kernel, scaled by
+//            sqrt(w detJ), into LDS: [slot][q][node][3], 193 doubles per slot (odd stride: lanes of different slots hit
+//            different banks).  Elements of the one-element halo are evaluated by every patch that touches them.
+//   phase 2  lane = up to 8 contributions (element slot, local node pair) in a row.  C is constant over the element, so
+//            a contribution contracts over the Gauss points first: G = sum_q g_i g_j^T (72 FMA), K = C : G (81 FMA with
+//            C in scalar registers when the model has one material, as every SOLID-family model of the reference has).
+//            It is formed for the ordered pair (min, max) and transposed where the block wants (max, min); diagonal
+//            ones are symmetrised (SOLID.py:565) -- the assembled matrix is exactly symmetric.  The contributions of a
+//            CSR block follow each other on one lane and are added in element order, 0 + x0 + x1 + ...; a finished
+//            block stays in registers until the phase ends.
+//   stores   the blocks go to an LDS image of the patch's CSR slabs (overlaying the gradients) and leave as contiguous
+//            runs: the 3 rows of a node are adjacent in CSR, and so are the slabs of consecutively numbered nodes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+
+#include "femshell_hip.h"
+#include "femshell_internal.h"
+#include "femshell_geom.h"
+
+namespace {
+
+constexpr int HX_GS = 193;                       // doubles per element slot (8 x 8 x 3 + 1)
+constexpr int HX_NT = FS_HEX_MAX_PATCH_LANES;    // 512
+static_assert(FS_HEX_STAGE_DOUBLES == FS_HEX_MAX_PATCH_ELEMS * HX_GS, "staging overlays the gradient image");
+
+#define HX_SLOT(r) ((int)((r) & 127u))
+#define HX_LI(r) ((int)(((r) >> 7) & 7u))
+#define HX_LJ(r) ((int)(((r) >> 10) & 7u))
+#define HX_ACTIVE(r) ((((r) >> 13) & 1u) != 0)
+#define HX_FLUSH(r) ((((r) >> 14) & 1u) != 0)
+#define HX_NODE(r) ((int)(((r) >> 15) & 63u))
+#define HX_RANK(r) ((int)(((r) >> 21) & 127u))
+
+// Voigt row of the strain component (alpha, gamma): [xx, yy, zz, xy, yz, zx] (SOLID.py:218-266)
+__device__ __forceinline__ constexpr int voigt(int a, int g) {
+    return a == g ? a : (a + g == 1 ? 3 : (a + g == 3 ? 4 : 5));
+}
+
+template <bool UNI>
+__global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restrict__ xyz, const int32_t *__restrict__ prop_id,
+                                                          const double *__restrict__ props, int32_t n_props, int64_t n_pat,
+                                                          const int64_t *__restrict__ pat_eptr, const int32_t *__restrict__ pat_elems,
+                                                          const int64_t *__restrict__ pat_nptr, const fs_hex_node *__restrict__ nodes,
+                                                          const int64_t *__restrict__ pat_rptr, const fs_hex_run *__restrict__ runs,
+                                                          const int64_t *__restrict__ pat_lptr, const uint32_t *__restrict__ steps,
+                                                          double *__restrict__ data, int32_t *__restrict__ status) {
+    __shared__ double s_g[FS_HEX_STAGE_DOUBLES];          // gradients, later the staging image of the patch's CSR slabs
+    __shared__ int s_pid[UNI ? 1 : FS_HEX_MAX_PATCH_ELEMS];
+    __shared__ fs_hex_node s_node[FS_HEX_MAX_PATCH_NODES];
+    const int tid = threadIdx.x;
+    // persistent workgroups, XCD k (workgroup index & 7 under round-robin dispatch) walks a contiguous eighth of the patches
+    const int xcd = blockIdx.x & 7, wpx = (int)(gridDim.x >> 3);
+    const int64_t per_xcd = (n_pat + 7) / 8;
+    const int64_t pend = ((xcd + 1) * per_xcd < n_pat) ? (xcd + 1) * per_xcd : n_pat;
+
+    // material: one row for the whole model -> uniform (scalar) loads; C symmetrised like K (SOLID.py:565)
+    double Cu[6][6];
+    if (UNI) {
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) { const double v = 0.5 * (props[a * 6 + b] + props[b * 6 + a]); Cu[a][b] = v; Cu[b][a] = v; }
+    }
+    const double gp = kGP;                                // 1 / sqrt(3)   (SOLID.py:1745-1766: order k-j-i, weights 1)
+
+    for (int64_t p = xcd * per_xcd + (blockIdx.x >> 3); p < pend; p += wpx) {
+        const int64_t e0 = pat_eptr[p], n0 = pat_nptr[p], r0 = pat_rptr[p], l0 = pat_lptr[p];
+        const int ne = (int)(pat_eptr[p + 1] - e0), nn = (int)(pat_nptr[p + 1] - n0), nr = (int)(pat_rptr[p + 1] - r0);
+        const int nl = (int)(pat_lptr[p + 1] - l0);
+        // this lane's eight steps (used after phase 1: the loads travel under it)
+        uint4 sa = make_uint4(0, 0, 0, 0), sb = sa;
+        if (tid < nl) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(steps + (l0 + tid) * 8);
+            sa = sp[0]; sb = sp[1];
+        }
+        if (tid < nn) s_node[tid] = nodes[n0 + tid];
+        // ---------------- phase 1: gradients of (slot, Gauss point) ----------------
+        for (int t = tid; t < ne * 8; t += HX_NT) {
+#pragma clang fp contract(fast)
+            const int slot = t >> 3, q = t & 7;
+            const int64_t e = pat_elems[e0 + slot];
+            const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp, zeta = (q & 4) ? gp : -gp;
+            double N[8], dxi[8], deta[8], dzeta[8];
+            solid_shape<8>(xi, eta, zeta, N, dxi, deta, dzeta);
+            double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            const double *x = xyz + e * 24;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double xc = x[3 * i + c];
+                    J[0][c] += dxi[i] * xc; J[1][c] += deta[i] * xc; J[2][c] += dzeta[i] * xc;
+                }
+            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0],
+                         c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+            const double det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+            if (det <= 1e-14 && status) atomicOr(status + e, FS_ST_BAD_JAC);      // ValueError in SOLID.py:211-212
+            double inv[3][3];
+            {
+                const double rdet = recip(det);
+                inv[0][0] = divr(c00, det, rdet); inv[0][1] = divr(J[0][2] * J[2][1] - J[0][1] * J[2][2], det, rdet);
+                inv[0][2] = divr(J[0][1] * J[1][2] - J[0][2] * J[1][1], det, rdet); inv[1][0] = divr(-c01, det, rdet);
+                inv[1][1] = divr(J[0][0] * J[2][2] - J[0][2] * J[2][0], det, rdet);
+                inv[1][2] = divr(J[0][2] * J[1][0] - J[0][0] * J[1][2], det, rdet);
+                inv[2][0] = divr(c02, det, rdet); inv[2][1] = divr(J[0][1] * J[2][0] - J[0][0] * J[2][1], det, rdet);
+                inv[2][2] = divr(J[0][0] * J[1][1] - J[0][1] * J[1][0], det, rdet);
+            }
+            const double sw = __builtin_sqrt(det);          // weights are 1: w detJ = detJ
+            double *g = s_g + slot * HX_GS + q * 24;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+                    g[3 * i + a] = sw * (inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i]);
+            if (!UNI && q == 0) s_pid[slot] = safe_pid(prop_id[e], n_props);
+        }
+        __syncthreads();
+
+        // ---------------- phase 2: eight steps per lane ----------------
+        double Kout[4][9];       // finished blocks: the plan lets blocks end at odd steps only
+        {
+#pragma clang fp contract(fast)
+            const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const uint32_t r = rec[s];
+                if (HX_ACTIVE(r)) {
+                    const int li = HX_LI(r), lj = HX_LJ(r);
+                    const int ci = li < lj ? li : lj, cj = li < lj ? lj : li;
+                    const double *ga = s_g + HX_SLOT(r) * HX_GS + 3 * ci, *gb = s_g + HX_SLOT(r) * HX_GS + 3 * cj;
+                    double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double a0 = ga[q * 24], a1 = ga[q * 24 + 1], a2 = ga[q * 24 + 2];
+                        const double b0 = gb[q * 24], b1 = gb[q * 24 + 1], b2 = gb[q * 24 + 2];
+                        G[0][0] = FMA(a0, b0, G[0][0]); G[0][1] = FMA(a0, b1, G[0][1]); G[0][2] = FMA(a0, b2, G[0][2]);
+                        G[1][0] = FMA(a1, b0, G[1][0]); G[1][1] = FMA(a1, b1, G[1][1]); G[1][2] = FMA(a1, b2, G[1][2]);
+                        G[2][0] = FMA(a2, b0, G[2][0]); G[2][1] = FMA(a2, b1, G[2][1]); G[2][2] = FMA(a2, b2, G[2][2]);
+                    }
+                    double C[6][6];
+                    if (UNI) {
+                        for (int a = 0; a < 36; a++) (&C[0][0])[a] = (&Cu[0][0])[a];
+                    } else {
+                        const double *pr = props + 37 * (int64_t)s_pid[HX_SLOT(r)];
+                        for (int a = 0; a < 6; a++)
+                            for (int b = a; b < 6; b++) { const double v = 0.5 * (pr[a * 6 + b] + pr[b * 6 + a]); C[a][b] = v; C[b][a] = v; }
+                    }
+                    // K[al][be] = sum over (ga, de) of C[voigt(al, ga)][voigt(be, de)] G[ga][de]
+                    double K[3][3];
+#pragma unroll
+                    for (int al = 0; al < 3; al++)
+#pragma unroll
+                        for (int be = 0; be < 3; be++) {
+                            double v = C[voigt(al, 0)][voigt(be, 0)] * G[0][0];
+#pragma unroll
+                            for (int t = 1; t < 9; t++) v = FMA(C[voigt(al, t / 3)][voigt(be, t % 3)], G[t / 3][t % 3], v);
+                            K[al][be] = v;
+                        }
+                    const bool tr = li > lj, dg = li == lj;
+#pragma unroll
+                    for (int al = 0; al < 3; al++)
+#pragma unroll
+                        for (int be = al + 1; be < 3; be++) {
+                            const double u = K[al][be], l = K[be][al], mean = 0.5 * (u + l);
+                            K[al][be] = dg ? mean : (tr ? l : u);
+                            K[be][al] = dg ? mean : (tr ? u : l);
+                        }
+#pragma unroll
+                    for (int c = 0; c < 9; c++) acc[c] = acc[c] + (&K[0][0])[c];
+                }
+                if ((s & 1) && HX_FLUSH(r)) {
+#pragma unroll
+                    for (int c = 0; c < 9; c++) { Kout[s >> 1][c] = acc[c]; acc[c] = 0.0; }
+                }
+            }
+        }
+        __syncthreads();        // every wave is done with the gradients: the staging image overlays them
+        {
+            const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+            for (int s = 1; s < 8; s += 2) {
+                const uint32_t r = rec[s];
+                if (HX_FLUSH(r)) {
+                    const fs_hex_node nd = s_node[HX_NODE(r)];
+                    double *o = s_g + nd.sbase + 3 * HX_RANK(r);
+                    const int stride = 3 * nd.m;
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int l = 0; l < 3; l++) o[k * stride + l] = Kout[s >> 1][3 * k + l];
+                }
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < nr; rr++) {
+            const fs_hex_run run = runs[r0 + rr];
+            double *dst = data + run.gdst;
+            const double *src = s_g + run.sbase;
+            for (int c = tid; c < run.len; c += HX_NT) dst[c] = src[c];
+        }
+        __syncthreads();        // the next patch's phase 1 overwrites the image
+    }
+}
+
+constexpr int kMaxDev = 64;
+int g_cus[kMaxDev] = {};
+std::mutex g_mu;
+
+int cu_count(int *out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "hipGetDevice", (int)e);
+    if (dev < 0 || dev >= kMaxDev) return fs_fail_(FS_EINVAL, "device index out of range", 0);
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_cus[dev]) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || n <= 0) return fs_fail_(FS_EHIP, "hipDeviceGetAttribute(MultiprocessorCount)", (int)e);
+        g_cus[dev] = n;
+    }
+    *out = g_cus[dev];
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props,
+                                      int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
+                                      const int64_t *pat_nptr, const fs_hex_node *nodes, const int64_t *pat_rptr,
+                                      const fs_hex_run *runs, const int64_t *pat_lptr, const uint32_t *steps, double *data,
+                                      int32_t *status, void *stream) {
+    if (E < 0 || n_props <= 0 || n_patches < 0) return fs_fail_(FS_EINVAL, "fs_fused_assemble_hex8: bad sizes", 0);
+    if (E == 0 || n_patches == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !pat_eptr || !pat_elems || !pat_nptr || !nodes || !pat_rptr || !runs || !pat_lptr ||
+        !steps || !data)
+        return fs_fail_(FS_EINVAL, "fs_fused_assemble_hex8: null argument", 0);
+    int cus = 0;
+    if (int rc = cu_count(&cus)) return rc;
+    int64_t wgs = ((int64_t)cus / 8) * 8;
+    if (wgs < 8) wgs = 8;
+    if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_props == 1)
+        hipLaunchKernelGGL(fused_hex8_kernel<true>, dim3((unsigned)wgs), dim3(HX_NT), 0, s, xyz, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_rptr, runs, pat_lptr, steps, data, status);
+    else
+        hipLaunchKernelGGL(fused_hex8_kernel<false>, dim3((unsigned)wgs), dim3(HX_NT), 0, s, xyz, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_rptr, runs, pat_lptr, steps, data, status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_hex8_kernel", (int)e);
+    return FS_OK;
+}

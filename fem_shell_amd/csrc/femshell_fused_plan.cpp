@@ -336,3 +336,242 @@ int fs_fused_plan_export(const fs_fused_plan *plan, int64_t *pat_eptr, int32_t *
 void fs_fused_plan_free(fs_fused_plan *plan) { delete plan; }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Plan of fs_fused_assemble_hex8 (include/femshell_hip.h, "Fused evaluate-and-assemble, HEXA8"): patches of nodes; a
+// patch forms the COMPLETE 3-row CSR slabs of its nodes (all 27 node-pair blocks of an interior node, not only J >= I),
+// so that its output leaves as long contiguous runs.  A lane works through up to 8 STEPS, one contribution (element, local
+// node pair) each, accumulating a block's contributions in ELEMENT ORDER (0 + x0 + x1 + ..., the reference's ADD_VALUES
+// insertion order, core/assembler.py:295-300) and flushing the finished block; the blocks of a node are packed into
+// lanes first-fit by decreasing contribution count (interior node of a structured mesh: 8 | 4+4 x 3 | 2+2+2+2 x 3 |
+// 8 x 1, each padded to 2 steps = 9 lanes of 8 steps).
+// ------------------------------------------------------------------------------------------------------------------
+struct fs_fused_hex_plan {
+    std::vector<int64_t> pat_eptr, pat_nptr, pat_rptr, pat_lptr;
+    std::vector<int32_t> pat_elems;
+    std::vector<fs_hex_node> nodes;
+    std::vector<fs_hex_run> runs;
+    std::vector<uint32_t> steps;      // [lanes][8]
+    int64_t n_evals = 0;
+};
+
+namespace {
+
+struct HexBlock { int rank; int n; uint32_t ev[8]; };    // one CSR block of a node: contributions slot | li << 7 | lj << 10
+
+// returns 0 or a negative code (-1: a node pair shared by more than 8 elements, -2: element missing from the patch,
+// -6: limits of the step record exceeded)
+int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, int nn, const int32_t *elems, int ne,
+                     std::vector<fs_hex_node> *out_nodes, std::vector<fs_hex_run> *out_runs, std::vector<uint32_t> *out_steps,
+                     int64_t *n_lanes, int64_t *n_evals, int64_t *stage_len) {
+    if (nn > FS_HEX_MAX_PATCH_NODES || ne > 128) return -6;
+    int64_t lanes = 0, evals = 0, sbase = 0;
+    std::vector<HexBlock> blocks;
+    std::vector<int> ord;
+    for (int q = 0; q < nn; q++) {
+        const int64_t I = nodes[q];
+        const int64_t r0 = m.nbr_ptr[I], r1 = m.nbr_ptr[I + 1];
+        const int mI = (int)(r1 - r0);
+        if (mI > 128) return -6;
+        const int32_t *eI = m.n2e.data() + m.n2e_ptr[I], *eIe = m.n2e.data() + m.n2e_ptr[I + 1];
+        blocks.clear();
+        for (int64_t b = r0; b < r1; b++) {
+            const int64_t J = m.nbr[b];
+            HexBlock hb;
+            hb.rank = (int)(b - r0);
+            hb.n = 0;
+            const int32_t *eJ = m.n2e.data() + m.n2e_ptr[J], *eJe = m.n2e.data() + m.n2e_ptr[J + 1];
+            const int32_t *a = eI, *c = eJ;
+            while (a != eIe && c != eJe) {
+                if (*a < *c) a++;
+                else if (*c < *a) c++;
+                else {
+                    const int32_t e = *a;
+                    const int64_t *cn = conn + (int64_t)e * 8;
+                    int li = -1, lj = -1;
+                    for (int k = 0; k < 8; k++) { if (cn[k] == I && li < 0) li = k; if (cn[k] == J && lj < 0) lj = k; }
+                    const int64_t slot = find_sorted(elems, elems + ne, e);
+                    if (slot < 0) return -2;
+                    if (hb.n >= 8) return -1;
+                    hb.ev[hb.n++] = (uint32_t)slot | ((uint32_t)li << 7) | ((uint32_t)lj << 10);
+                    a++; c++;
+                }
+            }
+            evals += hb.n;
+            blocks.push_back(hb);
+        }
+        // first fit, decreasing: a block takes max(n, 1) steps rounded up to an EVEN number (a pattern-only block still
+        // flushes its zeros), so that blocks start at even steps and flush at odd ones: the kernel keeps a finished block
+        // in one of FOUR register sets (index = step / 2) until the phase ends
+        ord.resize(blocks.size());
+        for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return blocks[x].n > blocks[y].n; });
+        std::vector<int> fill;                                 // steps used per lane of this node
+        const int64_t lane0 = lanes;
+        for (int bi : ord) {
+            const HexBlock &hb = blocks[bi];
+            const int need = ((hb.n > 0 ? hb.n : 1) + 1) & ~1;
+            size_t l = 0;
+            while (l < fill.size() && fill[l] + need > 8) l++;
+            if (l == fill.size()) {
+                fill.push_back(0);
+                if (out_steps) out_steps->resize((size_t)(lane0 + (int64_t)fill.size()) * 8, 0u);
+            }
+            if (out_steps) {
+                uint32_t *st = out_steps->data() + (size_t)(lane0 + (int64_t)l) * 8 + fill[l];
+                for (int c = 0; c < need; c++) {
+                    uint32_t r = c < hb.n ? (hb.ev[c] | (1u << 13)) : 0u;
+                    if (c == need - 1) r |= (1u << 14) | ((uint32_t)q << 15) | ((uint32_t)hb.rank << 21);
+                    st[c] = r;
+                }
+            }
+            fill[l] += need;
+        }
+        lanes += (int64_t)fill.size();
+        if (out_nodes) out_nodes->push_back(fs_hex_node{(int32_t)sbase, (int32_t)mI});
+        if (out_runs) {
+            const int64_t gdst = 9 * r0;
+            if (!out_runs->empty() && out_runs->back().gdst + out_runs->back().len == gdst &&
+                (int64_t)out_runs->back().sbase + out_runs->back().len == sbase)
+                out_runs->back().len += 9 * mI;
+            else
+                out_runs->push_back(fs_hex_run{gdst, (int32_t)sbase, (int32_t)(9 * mI)});
+        }
+        sbase += 9 * (int64_t)mI;
+    }
+    *n_lanes = (lanes + 63) / 64 * 64;
+    if (out_steps) out_steps->resize((size_t)*n_lanes * 8, 0u);
+    *n_evals = evals;
+    *stage_len = sbase;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_fused_hex_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                            const int64_t *node_patch, fs_fused_hex_plan **plan, int64_t *n_patches, int64_t *n_elem_slots,
+                            int64_t *n_pat_nodes, int64_t *n_runs, int64_t *n_lanes) {
+    if (!conn || !nbr_ptr || !nbr || !node_patch || !plan || !n_patches || !n_elem_slots || !n_pat_nodes || !n_runs || !n_lanes)
+        return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: null argument", 0);
+    if (E < 0 || n_nodes <= 0 || E > INT32_MAX) return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: bad sizes", 0);
+    for (int64_t i = 0; i < E * 8; i++)
+        if (conn[i] < 0 || conn[i] >= n_nodes) return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: connectivity out of range", 0);
+    fs_fused_hex_plan *P = new (std::nothrow) fs_fused_hex_plan;
+    if (!P) return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: out of memory", 0);
+    try {
+        Mesh m{conn, E, n_nodes, nbr_ptr, nbr, {}, {}};
+        m.n2e_ptr.assign(n_nodes + 1, 0);
+        for (int64_t i = 0; i < E * 8; i++) m.n2e_ptr[conn[i] + 1]++;
+        for (int64_t i = 0; i < n_nodes; i++) m.n2e_ptr[i + 1] += m.n2e_ptr[i];
+        m.n2e.resize(E * 8);
+        {
+            std::vector<int64_t> fill(m.n2e_ptr.begin(), m.n2e_ptr.end() - 1);
+            for (int64_t e = 0; e < E; e++)
+                for (int k = 0; k < 8; k++) {
+                    const int64_t nd = conn[e * 8 + k];
+                    if (fill[nd] > m.n2e_ptr[nd] && m.n2e[fill[nd] - 1] == (int32_t)e) {     // a node listed twice
+                        delete P;
+                        return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: an element lists a node twice", 0);
+                    }
+                    m.n2e[fill[nd]++] = (int32_t)e;
+                }
+        }
+        std::vector<int64_t> order;
+        for (int64_t i = 0; i < n_nodes; i++)
+            if (nbr_ptr[i + 1] > nbr_ptr[i]) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return node_patch[a] < node_patch[b]; });
+        std::vector<int64_t> pstart;
+        for (int64_t i = 0; i < (int64_t)order.size(); i++)
+            if (i == 0 || node_patch[order[i]] != node_patch[order[i - 1]]) pstart.push_back(i);
+        pstart.push_back((int64_t)order.size());
+        const int64_t np = (int64_t)pstart.size() - 1;
+        std::vector<int64_t> ne(np, 0), nl(np, 0), nev(np, 0), nr(np, 0);
+        std::vector<std::vector<int32_t>> els(np);
+        std::vector<std::vector<fs_hex_run>> runs(np);
+        std::vector<std::vector<fs_hex_node>> pnodes(np);
+        std::vector<std::vector<uint32_t>> steps(np);
+        int err = 0;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t p = 0; p < np; p++) {
+            const int64_t *nodes = order.data() + pstart[p];
+            const int nn = (int)(pstart[p + 1] - pstart[p]);
+            std::vector<int32_t> &el = els[p];
+            for (int q = 0; q < nn; q++)
+                el.insert(el.end(), m.n2e.begin() + m.n2e_ptr[nodes[q]], m.n2e.begin() + m.n2e_ptr[nodes[q] + 1]);
+            std::sort(el.begin(), el.end());
+            el.erase(std::unique(el.begin(), el.end()), el.end());
+            ne[p] = (int64_t)el.size();
+            int rc = 0;
+            int64_t stage = 0;
+            if ((int64_t)el.size() > FS_HEX_MAX_PATCH_ELEMS) rc = -4;
+            else rc = hex_patch_layout(m, conn, nodes, nn, el.data(), (int)el.size(), &pnodes[p], &runs[p], &steps[p], &nl[p], &nev[p], &stage);
+            if (!rc && (nl[p] > FS_HEX_MAX_PATCH_LANES || stage > FS_HEX_STAGE_DOUBLES)) rc = -7;
+            if (rc) {
+#pragma omp atomic write
+                err = rc;
+            }
+        }
+        if (err) {
+            delete P;
+            const char *msg = err == -4 ? "fs_fused_hex_plan_build: a patch touches more than FS_HEX_MAX_PATCH_ELEMS elements"
+                            : err == -1 ? "fs_fused_hex_plan_build: a node pair is shared by more than 8 elements"
+                            : err == -7 ? "fs_fused_hex_plan_build: a patch needs more than FS_HEX_MAX_PATCH_LANES lanes or staging doubles"
+                            : err == -6 ? "fs_fused_hex_plan_build: more than 64 nodes in a patch or more than 128 neighbours of a node"
+                                        : "fs_fused_hex_plan_build: inconsistent connectivity";
+            return fs_fail_(FS_EINVAL, msg, 0);
+        }
+        P->pat_eptr.assign(np + 1, 0); P->pat_nptr.assign(np + 1, 0); P->pat_rptr.assign(np + 1, 0); P->pat_lptr.assign(np + 1, 0);
+        for (int64_t p = 0; p < np; p++) {
+            P->pat_eptr[p + 1] = P->pat_eptr[p] + ne[p];
+            P->pat_nptr[p + 1] = P->pat_nptr[p] + (int64_t)pnodes[p].size();
+            P->pat_rptr[p + 1] = P->pat_rptr[p] + (int64_t)runs[p].size();
+            P->pat_lptr[p + 1] = P->pat_lptr[p] + nl[p];
+            P->n_evals += nev[p];
+        }
+        P->pat_elems.resize(P->pat_eptr[np]);
+        P->nodes.resize(P->pat_nptr[np]);
+        P->runs.resize(P->pat_rptr[np]);
+        P->steps.resize((size_t)P->pat_lptr[np] * 8);
+#pragma omp parallel for schedule(static)
+        for (int64_t p = 0; p < np; p++) {
+            std::copy(els[p].begin(), els[p].end(), P->pat_elems.begin() + P->pat_eptr[p]);
+            std::copy(pnodes[p].begin(), pnodes[p].end(), P->nodes.begin() + P->pat_nptr[p]);
+            std::copy(runs[p].begin(), runs[p].end(), P->runs.begin() + P->pat_rptr[p]);
+            std::copy(steps[p].begin(), steps[p].end(), P->steps.begin() + (size_t)P->pat_lptr[p] * 8);
+        }
+        *plan = P;
+        *n_patches = np;
+        *n_elem_slots = P->pat_eptr[np];
+        *n_pat_nodes = P->pat_nptr[np];
+        *n_runs = P->pat_rptr[np];
+        *n_lanes = P->pat_lptr[np];
+        return FS_OK;
+    } catch (const std::bad_alloc &) {
+        delete P;
+        return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: out of memory", 0);
+    }
+}
+
+int fs_fused_hex_plan_export(const fs_fused_hex_plan *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_nptr,
+                             fs_hex_node *nodes, int64_t *pat_rptr, fs_hex_run *runs, int64_t *pat_lptr, uint32_t *steps,
+                             int64_t *n_evals) {
+    if (!plan || !pat_eptr || !pat_elems || !pat_nptr || !nodes || !pat_rptr || !runs || !pat_lptr || !steps)
+        return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_export: null argument", 0);
+    std::copy(plan->pat_eptr.begin(), plan->pat_eptr.end(), pat_eptr);
+    std::copy(plan->pat_nptr.begin(), plan->pat_nptr.end(), pat_nptr);
+    std::copy(plan->pat_rptr.begin(), plan->pat_rptr.end(), pat_rptr);
+    std::copy(plan->pat_lptr.begin(), plan->pat_lptr.end(), pat_lptr);
+    std::copy(plan->pat_elems.begin(), plan->pat_elems.end(), pat_elems);
+    std::copy(plan->nodes.begin(), plan->nodes.end(), nodes);
+    std::copy(plan->runs.begin(), plan->runs.end(), runs);
+    std::copy(plan->steps.begin(), plan->steps.end(), steps);
+    if (n_evals) *n_evals = plan->n_evals;
+    return FS_OK;
+}
+
+void fs_fused_hex_plan_free(fs_fused_hex_plan *plan) { delete plan; }
+
+}  // extern "C"

@@ -220,3 +220,146 @@ class FusedQuadPlan:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         return {"pat_eptr": t(self.pat_eptr), "pat_elems": t(self.pat_elems), "pat_rptr": t(self.pat_rptr),
                 "recs": t(self.recs.view(np.uint8).reshape(-1))}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HEXA8 (fs_fused_assemble_hex8)
+# ---------------------------------------------------------------------------------------------------------------------
+HEX_NODE_DTYPE = np.dtype([("sbase", "i4"), ("m", "i4")])
+HEX_RUN_DTYPE = np.dtype([("gdst", "i8"), ("sbase", "i4"), ("len", "i4")])
+HEX_CELL = (4, 4, 3)       # nodes per patch along the numbering direction, the next one, the slowest one: 48 nodes touch
+                           # 5 x 5 x 4 = 100 elements (FS_HEX_MAX_PATCH_ELEMS: the LDS image of one workgroup)
+
+
+def partition_nodes_hex(coords, conn, max_elems=100, max_nodes=48, max_lanes=512):
+    """node -> patch id for the fused HEXA8 kernel: bins of HEX_CELL nodes on the coordinates (spacing = mean element
+    extent per axis; the axis along which consecutive node indices run is the fastest one, so the CSR slabs of a patch
+    form long runs and consecutive patches are neighbours), then median bisection of the patches that touch more than
+    `max_elems` elements, hold more than `max_nodes` nodes or would need more than `max_lanes` lanes (9 lanes per
+    interior node of a structured block: 72 two-step slots for its 64 contributions)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    conn = np.asarray(conn, dtype=np.int64)
+    N, E = coords.shape[0], conn.shape[0]
+    if E == 0:
+        return np.zeros(N, dtype=np.int64)
+    used = np.zeros(N, dtype=bool)
+    used[conn.reshape(-1)] = True
+    x = coords[conn]
+    hk = np.maximum((x.max(axis=1) - x.min(axis=1)).mean(axis=0), 1e-300)
+    hk = np.maximum(hk, 1e-3 * float(hk.max()))
+    # order of the axes in the node numbering: along which global axis does the node index grow by the smallest step?
+    # (structured blocks: 1 along the fastest axis, one row of nodes along the next, one layer along the slowest)
+    ea = np.array([0, 3, 4, 7, 0, 1, 4, 5, 0, 1, 2, 3])
+    eb = np.array([1, 2, 5, 6, 3, 2, 7, 6, 4, 5, 6, 7])
+    sub = conn[:: max(1, E // 4096)]
+    dx = np.abs(coords[sub[:, eb]] - coords[sub[:, ea]]) / hk               # [e, 12 edges, 3]
+    ax_of = np.argmax(dx, axis=2)
+    di = np.abs(sub[:, eb] - sub[:, ea]).astype(np.float64)
+    med = [np.median(di[ax_of == k]) if (ax_of == k).any() else np.inf for k in range(3)]
+    order_axes = [int(k) for k in np.argsort(med, kind="stable")]
+    # node spacing per axis = median edge length along it (the element extents above are inflated by distortion: bins of
+    # "4 spacings" would then catch a fifth node now and then and be bisected)
+    raw = np.abs(coords[sub[:, eb]] - coords[sub[:, ea]])
+    hk = np.array([np.median(raw[:, :, k][ax_of == k]) if (ax_of == k).any() else hk[k] for k in range(3)])
+    hk = np.maximum(hk, 1e-3 * float(hk.max()))
+    cell = np.empty(3)
+    for k, ax in enumerate(order_axes):
+        cell[ax] = HEX_CELL[k]
+    side = cell * hk
+    lo = coords[used].min(axis=0) - 0.5 * hk
+    cc = np.where(used[:, None], coords, lo)
+    b = np.clip(np.floor((cc - lo) / side).astype(np.int64), 0, None)
+    nb = b[used].max(axis=0) + 1
+    b = np.minimum(b, nb - 1)
+    key = np.zeros(N, dtype=np.int64)
+    for ax in reversed(order_axes):
+        key = key * nb[ax] + b[:, ax]
+    _, patch = np.unique(key, return_inverse=True)
+    patch = patch.astype(np.int64)
+    earange = np.repeat(np.arange(E, dtype=np.int64), conn.shape[1])
+    valence = np.bincount(conn.reshape(-1), minlength=N)
+    for _ in range(64):
+        npat = int(patch.max()) + 1
+        pe = np.unique(patch[conn].reshape(-1) * E + earange)
+        cnt = np.bincount(pe // E, minlength=npat)
+        nn = np.bincount(patch[used], minlength=npat)
+        lanes = np.bincount(patch[used], weights=np.ceil(np.maximum(valence[used], 1) * 1.125), minlength=npat)
+        bad = (cnt > max_elems) | (nn > max_nodes) | (lanes > max_lanes)
+        if not bad.any():
+            return patch
+        nodes = np.flatnonzero(bad[patch] & used)
+        pb = patch[nodes]
+        o = np.argsort(pb, kind="stable")
+        nodes, pb = nodes[o], pb[o]
+        starts = np.flatnonzero(np.r_[True, pb[1:] != pb[:-1]])
+        seg = np.cumsum(np.r_[False, pb[1:] != pb[:-1]])
+        size = np.diff(np.r_[starts, pb.shape[0]])
+        c = coords[nodes]
+        ext = (np.maximum.reduceat(c, starts, axis=0) - np.minimum.reduceat(c, starts, axis=0)) / hk
+        axis = np.argmax(ext, axis=1)
+        val = c[np.arange(c.shape[0]), axis[seg]]
+        o2 = np.lexsort((val, seg))
+        rank = np.empty(o2.shape[0], dtype=np.int64)
+        rank[o2] = np.arange(o2.shape[0]) - starts[seg[o2]]
+        upper = rank >= (size[seg] + 1) // 2
+        if (size < 2).any():
+            raise ValueError("a single node touches more elements than one patch may hold")
+        patch[nodes[upper]] = npat + seg[upper]
+    raise RuntimeError("partition_nodes_hex did not converge")
+
+
+class FusedHexPlan:
+    """Host arrays of fs_fused_assemble_hex8's plan (layout: include/femshell_hip.h), built by the native
+    fs_fused_hex_plan_build (csrc/femshell_fused_plan.cpp)."""
+
+    def __init__(self, plan, conn, coords, node_patch=None):
+        import ctypes
+        from . import _lib
+        conn = np.ascontiguousarray(conn, dtype=np.int64)
+        if plan.d != 3 or conn.ndim != 2 or conn.shape[1] != 8:
+            raise ValueError("the fused HEXA8 kernel is built for uniform 8-node brick meshes (3 dofs per node)")
+        self.E = int(conn.shape[0])
+        if node_patch is None:
+            node_patch = partition_nodes_hex(coords, conn)
+        node_patch = np.ascontiguousarray(node_patch, dtype=np.int64)
+        nbr_ptr = np.ascontiguousarray(plan.nbr_ptr, dtype=np.int64)
+        nbr = np.ascontiguousarray(plan.nbr, dtype=np.int32)
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        c = [ctypes.c_int64() for _ in range(5)]
+        _lib.check(lib.fs_fused_hex_plan_build(conn.ctypes.data, self.E, int(plan.n_nodes), nbr_ptr.ctypes.data, nbr.ctypes.data,
+                                               node_patch.ctypes.data, ctypes.byref(h), *[ctypes.byref(v) for v in c]),
+                   "fs_fused_hex_plan_build")
+        try:
+            npat, nslots, nnodes, nruns, nlanes = (int(v.value) for v in c)
+            self.n_patches, self.n_elem_slots, self.n_lanes = npat, nslots, nlanes
+            self.pat_eptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_nptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_rptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_lptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_elems = np.empty(nslots, dtype=np.int32)
+            self.nodes = np.empty(nnodes, dtype=HEX_NODE_DTYPE)
+            self.runs = np.empty(nruns, dtype=HEX_RUN_DTYPE)
+            self.steps = np.empty((nlanes, 8), dtype=np.uint32)
+            nev = ctypes.c_int64()
+            _lib.check(lib.fs_fused_hex_plan_export(h, self.pat_eptr.ctypes.data, self.pat_elems.ctypes.data,
+                                                    self.pat_nptr.ctypes.data, self.nodes.ctypes.data, self.pat_rptr.ctypes.data,
+                                                    self.runs.ctypes.data, self.pat_lptr.ctypes.data, self.steps.ctypes.data,
+                                                    ctypes.byref(nev)), "fs_fused_hex_plan_export")
+            self.n_evals = int(nev.value)
+        finally:
+            lib.fs_fused_hex_plan_free(h)
+
+    def stats(self):
+        return {"patches": self.n_patches, "elements_per_patch": self.n_elem_slots / max(self.n_patches, 1),
+                "stage1_recompute": self.n_elem_slots / max(self.E, 1),
+                "nodes_per_patch": self.nodes.shape[0] / max(self.n_patches, 1),
+                "runs_per_patch": self.runs.shape[0] / max(self.n_patches, 1),
+                "step_fill": self.n_evals / max(self.steps.size, 1),
+                "record_bytes_per_element": (self.steps.nbytes + self.runs.nbytes + self.nodes.nbytes) / max(self.E, 1)}
+
+    def to_device(self, device):
+        import torch
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(device)
+        return {k: t(getattr(self, k)) for k in ("pat_eptr", "pat_elems", "pat_nptr", "nodes", "pat_rptr", "runs",
+                                                 "pat_lptr", "steps")}

@@ -423,6 +423,59 @@ int fs_fused_plan_export(const fs_fused_plan *plan, int64_t *pat_eptr, int32_t *
                          fs_fused_rec *recs, int64_t *n_evals);
 void fs_fused_plan_free(fs_fused_plan *plan);
 
+/*
+ * Fused evaluate-and-assemble, HEXA8 (3 dofs per node, full 2 x 2 x 2 rule): the CSR values of K straight from the
+ * coordinates, no element matrices in memory.  Replaces the element evaluations HEXA8.K (elements/SOLID.py:543-567 with
+ * _compute_jacobian / compute_B_matrix :164-266 and the rule / shape functions :1744-1818) TOGETHER with the
+ * setValuesLocal(ADD_VALUES) loop over them (core/assembler.py:287-303).
+ *
+ * Gather form over PATCHES of nodes (plan built once per mesh by fs_fused_hex_plan_build from a map node -> patch).  A
+ * workgroup (512 lanes) evaluates, for every element touching its patch, the physical shape-function gradients at the 8
+ * Gauss points (scaled by sqrt(w detJ)) into LDS, then forms the COMPLETE 3-row CSR slabs of the patch's nodes -- every
+ * node-pair block (I, J) with I in the patch, 27 of them for an interior node of a structured mesh -- stages them in LDS
+ * and stores them as contiguous runs (the three rows of consecutively numbered nodes are adjacent in CSR).
+ * C is constant over an element, so a contribution is contracted over the Gauss points FIRST:
+ *     K_e[i][j] = sum_q w detJ B_i^T C B_j = C : G,   G = sum_q (w detJ) grad N_i grad N_j^T   (3 x 3),
+ * 8 x 9 + 81 multiply-adds instead of 8 x 90 (the same sum of products re-associated: eps-level differences).  Every
+ * contribution is formed for the ordered local pair (min, max) and transposed where the block wants (max, min), the
+ * diagonal ones are symmetrised (SOLID.py:565), so the assembled matrix is EXACTLY symmetric; a block's contributions are
+ * added in element order, 0 + x0 + x1 + ... (the reference's insertion order).
+ *   pat_eptr / pat_elems   elements of each patch (ascending; position = LDS slot), <= FS_HEX_MAX_PATCH_ELEMS per patch
+ *   pat_nptr / nodes       per patch node (ascending node index): offset of its slab in the patch's staging image
+ *                          (doubles) and its number of neighbours m (slab = 3 rows x 3 m values)
+ *   pat_rptr / runs        copy-out runs of the staging image: `len` doubles from staging offset `sbase` to data[gdst...]
+ *   pat_lptr / steps       lanes of each patch (multiples of 64, <= FS_HEX_MAX_PATCH_LANES), 8 step words per lane:
+ *                          slot | li << 7 | lj << 10 | active << 13 | flush << 14 | node_local << 15 | rank << 21 --
+ *                          contribution (element in `slot`, local nodes li of I and lj of J); `flush`: the block
+ *                          (node_local, rank-th neighbour) is complete after this step.  Blocks start at EVEN steps and
+ *                          flush at ODD ones (a block with an odd number of contributions ends in an idle step; a
+ *                          pattern-only block is two idle steps, the second flushing zeros)
+ *   props [n_props][37] as for fs_solid_batch; status [E] (FS_ST_BAD_JAC where det J <= 1e-14, OR-ed in: zero it) or NULL
+ * The kernel trusts its plan (fs_fused_hex_plan_build's output).  No counterpart in the reference beyond the lines above.
+ */
+typedef struct fs_hex_node { int32_t sbase; int32_t m; } fs_hex_node;                    /* 8 bytes */
+typedef struct fs_hex_run { int64_t gdst; int32_t sbase; int32_t len; } fs_hex_run;      /* 16 bytes */
+FS_STATIC_ASSERT(sizeof(fs_hex_node) == 8 && sizeof(fs_hex_run) == 16, "fused HEXA8 plan records");
+#define FS_HEX_MAX_PATCH_ELEMS 100
+#define FS_HEX_MAX_PATCH_NODES 64
+#define FS_HEX_MAX_PATCH_LANES 512
+#define FS_HEX_STAGE_DOUBLES 19300      /* FS_HEX_MAX_PATCH_ELEMS x 193: the gradient image the staging overlays */
+int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props, int64_t E,
+                           int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
+                           const fs_hex_node *nodes, const int64_t *pat_rptr, const fs_hex_run *runs,
+                           const int64_t *pat_lptr, const uint32_t *steps, double *data, int32_t *status, void *stream);
+/* Host-side plan builder (all pointers host memory; OpenMP over patches).  conn [E][8]; nbr_ptr / nbr: node graph of the
+ * CSR pattern (neighbours ascending); node_patch [n_nodes].  FS_EINVAL when a patch exceeds a limit above, when a node
+ * pair is shared by more than 8 elements or when an element lists a node twice -- callers then keep the two-kernel route. */
+typedef struct fs_fused_hex_plan fs_fused_hex_plan;
+int fs_fused_hex_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                            const int64_t *node_patch, fs_fused_hex_plan **plan, int64_t *n_patches, int64_t *n_elem_slots,
+                            int64_t *n_pat_nodes, int64_t *n_runs, int64_t *n_lanes);
+int fs_fused_hex_plan_export(const fs_fused_hex_plan *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_nptr,
+                             fs_hex_node *nodes, int64_t *pat_rptr, fs_hex_run *runs, int64_t *pat_lptr, uint32_t *steps,
+                             int64_t *n_evals);
+void fs_fused_hex_plan_free(fs_fused_hex_plan *plan);
+
 /* Symbolic companion of fs_csr_numeric_desc (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph:
  *   nbr_ptr [N+1] row pointer of the node graph (block rows), blk_row [nblk] node I and nbr [nblk] node J of

@@ -374,8 +374,21 @@ def test_c5_hexa8_block_full_size(oracle):
             assert np.abs(got[:, 3 * c:3 * c + 3] - blk2[:, 3 * cj:3 * cj + 3].T).max() <= 1e-12 * np.abs(ref).max()
     print("C5 HEXA8 block: sampled rows vs oracle", worst / scale, "nnz", K.nnz)
     assert worst <= 1e-12 * scale
+    # the fused evaluate-and-assemble kernel (fs_fused_assemble_hex8: the default of a re-evaluation) on the full block:
+    # the same sampled rows against the oracle, agreement with the two-kernel route, bitwise repeatability
+    Kf = asm.assemble_stiffness_matrix(recompute=True)
+    assert asm._fplan is not None
+    worst_f = 0.0
+    for I in nodes:
+        lo, hi = int(ip[3 * I]), int(ip[3 * I + 3])
+        worst_f = max(worst_f, float((Kf.data[lo:hi] - K.data[lo:hi]).abs().max()))
+    dmax = float((Kf.data - K.data).abs().max())
+    print("C5 HEXA8 block fused: vs two-kernel route", dmax / scale, "plan", asm.fused_plan().stats())
+    assert dmax <= 1e-13 * scale and worst + worst_f <= 1e-12 * scale
     again = asm.assemble_stiffness_matrix(recompute=True)
-    assert bool((again.data == K.data).all())
+    assert bool((again.data == Kf.data).all())
+    asm.check_status()
+    del Kf, again
     M = asm.assemble_mass_matrix()
     vol = nx * ny * nz * 1e-9
     total = float(M.data.sum()) / 3.0                        # each direction carries the whole mass

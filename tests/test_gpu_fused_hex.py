@@ -1,0 +1,112 @@
+"""GPU: the fused evaluate-and-assemble kernel for HEXA8 (fs_fused_assemble_hex8) against the two-kernel route it replaces
+(fs_solid_batch + fs_csr_numeric_desc, itself pinned to the reference's goldens) and against the oracle directly.
+The fused kernel contracts over the Gauss points first (K = C : sum_q g g^T), i.e. it re-associates the same sum of
+products: the bar is 1e-12 relative to max|K| against the oracle (the reference's own tolerance class), 1e-13 against the
+two-kernel route, EXACT symmetry of the assembled matrix, bitwise repeatability."""
+import numpy as np
+import pytest
+import torch
+
+import fem_shell_amd as fsa
+from fem_shell_amd import _lib, batch, meshes
+from fem_shell_amd.elements import ElementFamily
+from fem_shell_amd.properties import solid_row
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def brick_block(nx, ny, nz, jitter=0.1, seed=5, shear=0.0):
+    ids = np.arange((nx + 1) * (ny + 1) * (nz + 1), dtype=np.int64).reshape(nz + 1, ny + 1, nx + 1)
+    Z, Y, X = np.meshgrid(np.arange(nz + 1.0), np.arange(ny + 1.0), np.arange(nx + 1.0), indexing="ij")
+    coords = np.stack([X + shear * Y, Y + 0.5 * shear * Z, Z], -1).reshape(-1, 3) * 1e-3
+    coords += (meshes.hash_uniform(np.arange(coords.size), seed).reshape(-1, 3) - 0.5) * jitter * 1e-3
+    n = lambda dz, dy, dx: ids[dz:nz + dz, dy:ny + dy, dx:nx + dx]
+    conn = np.stack([n(0, 0, 0), n(0, 0, 1), n(0, 1, 1), n(0, 1, 0), n(1, 0, 0), n(1, 0, 1), n(1, 1, 1), n(1, 1, 0)],
+                    -1).reshape(-1, 8)
+    return coords, conn
+
+
+def _asm(coords, conn, mat=None, **kw):
+    from fem_shell_amd.assembler import MeshAssembler
+    model = {"element_family": ElementFamily.SOLID, "material": mat or util.t300()}
+    model.update(kw)
+    return MeshAssembler(meshes.ArrayMesh(coords, conn), {"elements": model})
+
+
+def _oracle_csr(oracle, coords, conn, props, pid=None):
+    pid = np.zeros(conn.shape[0], np.int32) if pid is None else pid
+    Ke = oracle.solid_batch(8, coords[conn], pid, props)["K"]
+    dofs = (conn[:, :, None] * 3 + np.arange(3)).reshape(conn.shape[0], -1)
+    return oracle.csr_assemble(dofs, coords.shape[0] * 3, Ke)
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 1), (2, 1, 1), (3, 2, 2), (5, 4, 3), (9, 7, 5), (13, 4, 11), (17, 9, 8)])
+def test_fused_hex8_vs_two_kernels_and_oracle(oracle, dims):
+    coords, conn = brick_block(*dims, shear=0.2)
+    asm = _asm(coords, conn)
+    assert asm.can_fuse
+    K2 = asm.assemble_stiffness_matrix(recompute=True, fused=False)
+    st = torch.full((conn.shape[0],), -1, dtype=torch.int32, device=asm.device)
+    Kf = asm.assemble_stiffness_fused(status=st)
+    torch.cuda.synchronize()
+    assert int(st.abs().max()) == 0 and not torch.isnan(Kf.data).any()
+    scale = float(K2.data.abs().max())
+    assert float((Kf.data - K2.data).abs().max()) <= 1e-13 * scale
+    ip, ix, kd = _oracle_csr(oracle, coords, conn, solid_row(util.t300(), None)[None])
+    assert np.array_equal(ip, Kf.indptr.cpu().numpy()) and np.array_equal(ix, Kf.indices.cpu().numpy())
+    err = np.abs(Kf.data.cpu().numpy() - kd).max() / np.abs(kd).max()
+    print(dims, "fused HEXA8 vs oracle", err, "vs two-kernel route", float((Kf.data - K2.data).abs().max()) / scale,
+          asm.fused_plan().stats())
+    assert err <= 1e-12
+    A = Kf.to_scipy()
+    assert (A != A.T).nnz == 0                                           # exactly symmetric
+    again = asm.assemble_stiffness_matrix(recompute=True)               # default route == fused; repeatable
+    assert asm._fplan is not None and bool((again.data.view(torch.int64) == Kf.data.view(torch.int64)).all())
+
+
+def test_fused_hex8_renumbered_nodes_and_two_materials(oracle):
+    """Random node numbering and element order (the patches come from the coordinates; the CSR slabs of a patch are no
+    longer adjacent: many short copy-out runs), and a property table with two rows (the kernel's per-element C path)."""
+    coords, conn = brick_block(7, 6, 5, jitter=0.15, seed=9)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(coords.shape[0])
+    inv = np.empty_like(perm); inv[perm] = np.arange(perm.shape[0])
+    coords, conn = coords[perm], inv[conn][rng.permutation(conn.shape[0])]
+    asm = _asm(coords, conn)
+    iso = fsa.IsotropicMaterial("steel", 2.1e11, 0.3, 7850.0)
+    rows = np.stack([solid_row(util.t300(), None), solid_row(iso, None)])
+    pid = (np.arange(conn.shape[0]) % 2).astype(np.int32)
+    asm._prop_table, asm._prop_id = rows, pid
+    asm._props_d = batch.to_device_solid_props(rows)
+    asm._groups[0]["pid_d"] = torch.from_numpy(pid).to(asm.device)
+    K2 = asm.assemble_stiffness_matrix(recompute=True, fused=False)
+    Kf = asm.assemble_stiffness_matrix(recompute=True)
+    assert asm._fplan is not None
+    assert float((Kf.data - K2.data).abs().max()) <= 1e-13 * float(K2.data.abs().max())
+    ip, ix, kd = _oracle_csr(oracle, coords, conn, rows, pid)
+    assert np.array_equal(ix, Kf.indices.cpu().numpy())
+    assert np.abs(Kf.data.cpu().numpy() - kd).max() <= 1e-12 * np.abs(kd).max()
+    A = Kf.to_scipy()
+    assert (A != A.T).nnz == 0
+    print("renumbered:", asm.fused_plan().stats())
+
+
+def test_fused_hex8_status_and_fallbacks():
+    coords, conn = brick_block(4, 3, 3)
+    bad = coords.copy()
+    bad[conn[5]] = bad[conn[5]][[1, 0, 3, 2, 5, 4, 7, 6]]                 # mirrored brick: det J < 0
+    asm = _asm(coords, conn)
+    asm._groups[0]["xyz_d"] = torch.from_numpy(bad[conn]).to(asm.device)
+    asm.assemble_stiffness_matrix(recompute=True)
+    with pytest.raises(ValueError, match="degenerate"):
+        asm.check_status()
+    # the 1-point rule is not fused: the default entry point keeps the two-kernel route
+    red = _asm(coords, conn, reduced_integration=True)
+    assert not red.can_fuse
+    K = red.assemble_stiffness_matrix(recompute=True)
+    assert red._fplan is None and torch.isfinite(K.data).all()
+    # a null argument comes back as a code, not as a fault
+    lib = _lib.load()
+    assert lib.fs_fused_assemble_hex8(None, None, None, 1, 5, 1, None, None, None, None, None, None, None, None, None, None,
+                                      _lib.stream_ptr()) == -22
