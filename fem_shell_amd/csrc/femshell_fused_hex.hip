@@ -57,6 +57,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
     __shared__ double s_g[FS_HEX_STAGE_DOUBLES];          // gradients, later the staging image of the patch's CSR slabs
     __shared__ int s_pid[UNI ? 1 : FS_HEX_MAX_PATCH_ELEMS];
     __shared__ fs_hex_node s_node[FS_HEX_MAX_PATCH_NODES];
+    __shared__ fs_hex_run s_run[FS_HEX_MAX_PATCH_NODES];  // copy-out runs of the patch (at most one per node)
     const int tid = threadIdx.x;
     // persistent workgroups, XCD k (workgroup index & 7 under round-robin dispatch) walks a contiguous eighth of the patches
     const int xcd = blockIdx.x & 7, wpx = (int)(gridDim.x >> 3);
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
             sa = sp[0]; sb = sp[1];
         }
         if (tid < nn) s_node[tid] = nodes[n0 + tid];
+        if (tid >= 64 && tid - 64 < nr) s_run[tid - 64] = runs[r0 + tid - 64];     // (read after three barriers)
         // ---------------- phase 1: gradients of (slot, Gauss point) ----------------
         for (int t = tid; t < ne * 8; t += HX_NT) {
 #pragma clang fp contract(fast)
@@ -202,10 +204,15 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
         }
         __syncthreads();
         for (int rr = 0; rr < nr; rr++) {
-            const fs_hex_run run = runs[r0 + rr];
-            double *dst = data + run.gdst;
-            const double *src = s_g + run.sbase;
-            for (int c = tid; c < run.len; c += HX_NT) dst[c] = src[c];
+            // 16-byte stores on 16-byte aligned addresses: an odd first index goes out alone, and so does an odd tail
+            const fs_hex_run run = s_run[rr];
+            const int head = (int)(run.gdst & 1), np2 = (run.len - head) >> 1;
+            double *dst = data + run.gdst + head;
+            const double *src = s_g + run.sbase + head;
+            for (int c = tid; c < np2; c += HX_NT)
+                *reinterpret_cast<double2 *>(dst + 2 * c) = make_double2(src[2 * c], src[2 * c + 1]);
+            if (tid == 0 && head) dst[-1] = src[-1];
+            if (tid == 64 && ((run.len - head) & 1)) dst[2 * np2] = src[2 * np2];
         }
         __syncthreads();        // the next patch's phase 1 overwrites the image
     }
