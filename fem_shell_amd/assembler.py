@@ -436,7 +436,13 @@ class MeshAssembler:
                 self._fplan = FusedHexPlan(host, self._conn, self._coords)
                 self._fused_flags = 0
             else:
-                self._fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems)
+                from .fused import partition_nodes_device
+                g = self._groups[0]
+                # structured numbering: the node -> patch map is integer arithmetic on the device (None otherwise: the
+                # NumPy partition with its bisection pass runs inside FusedQuadPlan)
+                node_patch = partition_nodes_device(int(self.mesh.node_count), g["conn_d"], self.fused_max_patch_elems)
+                self._fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems,
+                                            node_patch=node_patch)
                 self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
             self._fplan_d = self._fplan.to_device(self.device)
         return self._fplan

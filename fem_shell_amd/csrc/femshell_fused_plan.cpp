@@ -5,6 +5,7 @@
 // is evaluated.  Host arrays in, host arrays out; the caller uploads them.  OpenMP over patches.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -15,8 +16,10 @@
 struct fs_fused_plan {
     std::vector<int64_t> pat_eptr, pat_rptr;
     std::vector<int32_t> pat_elems;
-    std::vector<fs_fused_rec> recs;
+    fs_fused_rec *recs = nullptr;      // n_recs records, NOT value-initialised (gigabytes at 10 M elements: every
+    int64_t n_recs = 0;                // record is written by the parallel copy below)
     int64_t n_evals = 0;
+    ~fs_fused_plan() { std::free(recs); }
 };
 
 namespace {
@@ -236,13 +239,19 @@ int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const i
         pstart.push_back((int64_t)order.size());
         const int64_t np = (int64_t)pstart.size() - 1;
         std::vector<int64_t> ne(np, 0), nl(np, 0), nev(np, 0);
+        std::vector<std::vector<int32_t>> els(np);
+        std::vector<std::vector<fs_fused_rec>> prec(np);
+        fs_fused_rec blank;
+        std::memset(&blank, 0, sizeof blank);
+        blank.dst[0] = blank.dst[1] = blank.dst_t[0] = blank.dst_t[1] = -1;
+        blank.slots = 0xFFFFFFFFu;
         int err = 0;
-        // pass 1: sizes
+        // one pass over the patches: element list, tasks, lane layout and records into per-patch buffers ...
 #pragma omp parallel for schedule(dynamic, 64)
         for (int64_t p = 0; p < np; p++) {
             const int64_t *nodes = order.data() + pstart[p];
             const int64_t nn = pstart[p + 1] - pstart[p];
-            std::vector<int32_t> el;
+            std::vector<int32_t> &el = els[p];
             for (int64_t q = 0; q < nn; q++)
                 el.insert(el.end(), m.n2e.begin() + m.n2e_ptr[nodes[q]], m.n2e.begin() + m.n2e_ptr[nodes[q] + 1]);
             std::sort(el.begin(), el.end());
@@ -264,12 +273,18 @@ int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const i
             }
             nl[p] = layout_patch(tasks, nullptr, scratch);
             nev[p] = evs;
+            prec[p].assign((size_t)nl[p], blank);
+            if (layout_patch(tasks, prec[p].data(), scratch) < 0) {
+#pragma omp atomic write
+                err = -5;
+            }
         }
         if (err) {
             delete P;
             const char *msg = err == -4 ? "fs_fused_plan_build: a patch touches more than max_patch_elems elements"
                             : err == -1 ? "fs_fused_plan_build: a node pair is shared by more than 32 elements"
                             : err == -3 ? "fs_fused_plan_build: block with contributions but no transposed partner (pattern not symmetric)"
+                            : err == -5 ? "fs_fused_plan_build: more than 255 blocks stored by one wave"
                                         : "fs_fused_plan_build: inconsistent connectivity";
             return fs_fail_(FS_EINVAL, msg, 0);
         }
@@ -281,34 +296,15 @@ int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const i
             P->n_evals += nev[p];
         }
         P->pat_elems.resize(P->pat_eptr[np]);
-        fs_fused_rec blank;
-        std::memset(&blank, 0, sizeof blank);
-        blank.dst[0] = blank.dst[1] = blank.dst_t[0] = blank.dst_t[1] = -1;
-        blank.slots = 0xFFFFFFFFu;
-        P->recs.assign(P->pat_rptr[np], blank);
-        // pass 2: fill
-#pragma omp parallel for schedule(dynamic, 64)
+        P->n_recs = P->pat_rptr[np];
+        P->recs = static_cast<fs_fused_rec *>(std::malloc((size_t)(P->n_recs > 0 ? P->n_recs : 1) * sizeof(fs_fused_rec)));
+        if (!P->recs) throw std::bad_alloc();
+        // ... then into place
+#pragma omp parallel for schedule(static)
         for (int64_t p = 0; p < np; p++) {
-            const int64_t *nodes = order.data() + pstart[p];
-            const int64_t nn = pstart[p + 1] - pstart[p];
-            std::vector<int32_t> el;
-            for (int64_t q = 0; q < nn; q++)
-                el.insert(el.end(), m.n2e.begin() + m.n2e_ptr[nodes[q]], m.n2e.begin() + m.n2e_ptr[nodes[q] + 1]);
-            std::sort(el.begin(), el.end());
-            el.erase(std::unique(el.begin(), el.end()), el.end());
-            std::copy(el.begin(), el.end(), P->pat_elems.begin() + P->pat_eptr[p]);
-            fs_fused_rec *rec = P->recs.data() + P->pat_rptr[p];
-            std::vector<TaskRec> tasks;
-            std::vector<int> scratch;
-            patch_tasks(m, nodes, nn, el.data(), (int)el.size(), [&](const Task &t) { tasks.push_back(t); });
-            if (layout_patch(tasks, rec, scratch) < 0) {
-#pragma omp atomic write
-                err = -5;
-            }
-        }
-        if (err) {
-            delete P;
-            return fs_fail_(FS_EINVAL, "fs_fused_plan_build: more than 255 blocks stored by one wave", 0);
+            std::copy(els[p].begin(), els[p].end(), P->pat_elems.begin() + P->pat_eptr[p]);
+            if (!prec[p].empty()) std::memcpy(P->recs + P->pat_rptr[p], prec[p].data(), prec[p].size() * sizeof(fs_fused_rec));
+            std::vector<fs_fused_rec>().swap(prec[p]);
         }
         *plan = P;
         *n_patches = np;
@@ -328,7 +324,14 @@ int fs_fused_plan_export(const fs_fused_plan *plan, int64_t *pat_eptr, int32_t *
     std::copy(plan->pat_eptr.begin(), plan->pat_eptr.end(), pat_eptr);
     std::copy(plan->pat_rptr.begin(), plan->pat_rptr.end(), pat_rptr);
     std::copy(plan->pat_elems.begin(), plan->pat_elems.end(), pat_elems);
-    if (!plan->recs.empty()) std::memcpy(recs, plan->recs.data(), plan->recs.size() * sizeof(fs_fused_rec));
+    {   // gigabytes: copied by all threads
+        const int64_t n = plan->n_recs, chunk = 1 << 16;
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < (n + chunk - 1) / chunk; c++) {
+            const int64_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            std::memcpy(recs + lo, plan->recs + lo, (size_t)(hi - lo) * sizeof(fs_fused_rec));
+        }
+    }
     if (n_evals) *n_evals = plan->n_evals;
     return FS_OK;
 }

@@ -82,6 +82,15 @@ def _lattice(conn, N):
     return np.stack([idx % L, idx // L], axis=1).astype(np.float64)
 
 
+def _elements_per_patch(patch, conn, npat):
+    """Number of elements touching each patch: distinct (patch, element) pairs, counted in O(E) -- the patches of an
+    element's nodes are sorted within the element's row and a patch counts where it first appears."""
+    pc = np.sort(patch[conn], axis=1)
+    first = np.ones(pc.shape, dtype=bool)
+    first[:, 1:] = pc[:, 1:] != pc[:, :-1]
+    return np.bincount(pc[first], minlength=npat)
+
+
 def partition_nodes(coords, conn, max_elems=64):
     """node -> patch id (int64 [N]); the elements touching any patch number <= max_elems.
 
@@ -128,11 +137,9 @@ def partition_nodes(coords, conn, max_elems=64):
         key = key * nb[k] + b[:, k]
     _, patch = np.unique(key, return_inverse=True)
     patch = patch.astype(np.int64)
-    earange = np.repeat(np.arange(E, dtype=np.int64), conn.shape[1])
     for _ in range(64):
         npat = int(patch.max()) + 1
-        pe = np.unique(patch[conn].reshape(-1) * E + earange)
-        cnt = np.bincount(pe // E, minlength=npat)
+        cnt = _elements_per_patch(patch, conn, npat)
         bad = cnt > max_elems
         if not bad.any():
             return patch
@@ -155,6 +162,52 @@ def partition_nodes(coords, conn, max_elems=64):
             raise ValueError("a single node touches more elements than one patch may hold")
         patch[nodes[upper]] = npat + seg[upper]
     raise RuntimeError("partition_nodes did not converge")
+
+
+def partition_nodes_device(n_nodes, conn_d, max_elems=64):
+    """partition_nodes for meshes numbered like a structured grid, on the device (torch integer plumbing, the same
+    arithmetic: lattice test, grid binning with patch ids in grid order).  Returns the int64 [N] map as a HOST array, or
+    None when the mesh is not lattice-numbered or some patch would touch more than max_elems elements (the NumPy
+    version with its bisection pass then takes over).  On lattice meshes the two agree exactly (tests/test_gpu_fused.py)."""
+    import torch
+    conn = conn_d.to(torch.int64)
+    E, N = int(conn.shape[0]), int(n_nodes)
+    if E < 4:
+        return None
+    d01, d32 = (conn[:, 1] - conn[:, 0]).abs(), (conn[:, 2] - conn[:, 3]).abs()
+    d03, d12 = (conn[:, 3] - conn[:, 0]).abs(), (conn[:, 2] - conn[:, 1]).abs()
+    lo, hi = torch.minimum(d01, d03), torch.maximum(d01, d03)
+    vals, cnts = torch.unique(hi, return_counts=True)
+    L = int(vals[int(torch.argmax(cnts))])
+    if L < 2:
+        return None
+    ok = (lo == 1) & (hi == L) & (d32 == d01) & (d12 == d03)
+    if float(ok.double().mean()) < 0.9:
+        return None
+    best = (1, 1)
+    for a in range(1, GRID_NODES + 1):
+        for bb in range(1, 40):
+            if (a + 1) * (bb + 1) <= max_elems and a * bb > best[0] * best[1]:
+                best = (a, bb)
+    used = torch.zeros(N, dtype=torch.bool, device=conn.device)
+    used[conn.reshape(-1)] = True
+    idx = torch.arange(N, dtype=torch.int64, device=conn.device)
+    li, lj = idx % L, idx // L
+    # lattice coordinates are integers: floor((c - (min - 0.5)) / side) == (c - min) // side for integer c, side
+    umin_i, umin_j = int(li[used].min()), int(lj[used].min())
+    bi = torch.where(used, (li - umin_i) // best[0], torch.zeros_like(li))
+    bj = torch.where(used, (lj - umin_j) // best[1], torch.zeros_like(lj))
+    nbi, nbj = int(bi[used].max()) + 1, int(bj[used].max()) + 1
+    key = torch.minimum(bj, torch.tensor(nbj - 1, device=conn.device)) * nbi + torch.minimum(bi, torch.tensor(nbi - 1, device=conn.device))
+    _, patch = torch.unique(key, return_inverse=True)
+    npat = int(patch.max()) + 1
+    pc, _ = torch.sort(patch[conn], dim=1)
+    first = torch.ones_like(pc, dtype=torch.bool)
+    first[:, 1:] = pc[:, 1:] != pc[:, :-1]
+    cnt = torch.bincount(pc[first], minlength=npat)
+    if int(cnt.max()) > max_elems:
+        return None
+    return patch.cpu().numpy()
 
 
 class FusedQuadPlan:
@@ -276,12 +329,10 @@ def partition_nodes_hex(coords, conn, max_elems=100, max_nodes=48, max_lanes=512
         key = key * nb[ax] + b[:, ax]
     _, patch = np.unique(key, return_inverse=True)
     patch = patch.astype(np.int64)
-    earange = np.repeat(np.arange(E, dtype=np.int64), conn.shape[1])
     valence = np.bincount(conn.reshape(-1), minlength=N)
     for _ in range(64):
         npat = int(patch.max()) + 1
-        pe = np.unique(patch[conn].reshape(-1) * E + earange)
-        cnt = np.bincount(pe // E, minlength=npat)
+        cnt = _elements_per_patch(patch, conn, npat)
         nn = np.bincount(patch[used], minlength=npat)
         lanes = np.bincount(patch[used], weights=np.ceil(np.maximum(valence[used], 1) * 1.125), minlength=npat)
         bad = (cnt > max_elems) | (nn > max_nodes) | (lanes > max_lanes)
