@@ -590,12 +590,14 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
 
     K = None
     for _ in range(warmup):
+        K = None                       # (the previous step's values go back to the allocator before the next 26 GB are taken)
         K = asm.assemble_stiffness_matrix(recompute=True)
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0s = time.perf_counter()
     e0.record()
     for _ in range(steps):
+        K = None
         K = asm.assemble_stiffness_matrix(recompute=True)
     e1.record()
     barrier()
