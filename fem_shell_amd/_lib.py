@@ -32,6 +32,7 @@ SIGNATURES = {
     "fs_shell_quad_geom_status": (ctypes.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "fs_fused_assemble_hex8": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                               _vp, _vp, _vp]),
+    "fs_fused_hex_plan_check": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "fs_fused_hex_plan_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_hex_plan_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_hex_plan_free": (None, [_vp]),

@@ -20,6 +20,7 @@
 //            runs: the 3 rows of a node are adjacent in CSR, and so are the slabs of consecutively numbered nodes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <mutex>
 
@@ -218,6 +219,46 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
     }
 }
 
+// Invariants fused_hex8_kernel relies on when it indexes LDS and `data` with values read from the plan
+// (fs_fused_hex_plan_check): workgroup per patch (grid-stride).  err[0] = violations, err[1] = first rule, err[2] = patch.
+__global__ __launch_bounds__(256) void hex_plan_check_kernel(int64_t n_pat, const int64_t *__restrict__ pat_eptr,
+                                                            const int32_t *__restrict__ pat_elems, const int64_t *__restrict__ pat_nptr,
+                                                            const fs_hex_node *__restrict__ nodes, const int64_t *__restrict__ pat_rptr,
+                                                            const fs_hex_run *__restrict__ runs, const int64_t *__restrict__ pat_lptr,
+                                                            const uint32_t *__restrict__ steps, int64_t E, int64_t nnz,
+                                                            unsigned long long *__restrict__ err) {
+    auto report = [&](int rule, int64_t p) {
+        if (atomicAdd(&err[0], 1ull) == 0) { err[1] = (unsigned long long)rule; err[2] = (unsigned long long)p; }
+    };
+    for (int64_t p = blockIdx.x; p < n_pat; p += gridDim.x) {
+        const int64_t e0 = pat_eptr[p], n0 = pat_nptr[p], r0 = pat_rptr[p], l0 = pat_lptr[p];
+        const int64_t ne = pat_eptr[p + 1] - e0, nn = pat_nptr[p + 1] - n0, nr = pat_rptr[p + 1] - r0, nl = pat_lptr[p + 1] - l0;
+        const bool hdr = ne >= 1 && ne <= FS_HEX_MAX_PATCH_ELEMS && nn >= 1 && nn <= FS_HEX_MAX_PATCH_NODES && nr >= 0 &&
+                         nr <= FS_HEX_MAX_PATCH_NODES && nl >= 0 && nl <= FS_HEX_MAX_PATCH_LANES && (nl & 63) == 0 &&
+                         e0 >= 0 && n0 >= 0 && r0 >= 0 && l0 >= 0;
+        if (!hdr) { if (threadIdx.x == 0) report(1, p); continue; }
+        for (int64_t q = threadIdx.x; q < ne; q += blockDim.x)
+            if (pat_elems[e0 + q] < 0 || pat_elems[e0 + q] >= E) report(2, p);
+        for (int64_t q = threadIdx.x; q < nn; q += blockDim.x) {
+            const fs_hex_node nd = nodes[n0 + q];
+            if (nd.sbase < 0 || nd.m < 1 || (int64_t)nd.sbase + 9 * (int64_t)nd.m > FS_HEX_STAGE_DOUBLES) report(3, p);
+        }
+        for (int64_t q = threadIdx.x; q < nr; q += blockDim.x) {
+            const fs_hex_run rn = runs[r0 + q];
+            if (rn.sbase < 0 || rn.len < 0 || (int64_t)rn.sbase + rn.len > FS_HEX_STAGE_DOUBLES || rn.gdst < 0 || rn.gdst + rn.len > nnz)
+                report(4, p);
+        }
+        for (int64_t q = threadIdx.x; q < nl * 8; q += blockDim.x) {
+            const uint32_t r = steps[l0 * 8 + q];
+            if (HX_ACTIVE(r) && HX_SLOT(r) >= ne) report(5, p);
+            if (HX_FLUSH(r)) {
+                if (!(q & 1) || HX_NODE(r) >= nn) report(6, p);
+                else if (HX_RANK(r) >= nodes[n0 + HX_NODE(r)].m) report(6, p);
+            }
+        }
+    }
+}
+
 constexpr int kMaxDev = 64;
 int g_cus[kMaxDev] = {};
 std::mutex g_mu;
@@ -264,5 +305,40 @@ extern "C" int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id,
                            n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_rptr, runs, pat_lptr, steps, data, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_hex8_kernel", (int)e);
+    return FS_OK;
+}
+
+extern "C" int fs_fused_hex_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
+                                       const int64_t *pat_nptr, const fs_hex_node *nodes, const int64_t *pat_rptr,
+                                       const fs_hex_run *runs, const int64_t *pat_lptr, const uint32_t *steps, int64_t E,
+                                       int64_t nnz, void *stream) {
+    if (E < 0 || n_patches < 0 || nnz < 0) return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_check: bad sizes", 0);
+    if (n_patches == 0) return FS_OK;
+    if (!pat_eptr || !pat_elems || !pat_nptr || !nodes || !pat_rptr || !runs || !pat_lptr || !steps)
+        return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_check: null argument", 0);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *err = nullptr, host[3] = {0, 0, 0};
+    hipError_t e = hipMalloc(&err, sizeof host);
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "fs_fused_hex_plan_check: hipMalloc", (int)e);
+    e = hipMemsetAsync(err, 0, sizeof host, s);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)(n_patches < 8192 ? n_patches : 8192);
+        hipLaunchKernelGGL(hex_plan_check_kernel, dim3(grid), dim3(256), 0, s, n_patches, pat_eptr, pat_elems, pat_nptr, nodes,
+                           pat_rptr, runs, pat_lptr, steps, E, nnz, err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, err, sizeof host, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(err);
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "fs_fused_hex_plan_check", (int)e);
+    if (host[0]) {
+        static const char *const rules[] = {"", "patch header out of range (elements, nodes, runs, lanes)", "element index outside [0, E)",
+            "node slab outside the staging image", "copy-out run outside the staging image or the value array",
+            "step names a slot beyond its patch", "flush on an even step, or node / neighbour rank out of range"};
+        char msg[200];
+        snprintf(msg, sizeof msg, "fs_fused_hex_plan_check: %llu violations; first: %s (patch %lld)", host[0],
+                 rules[host[1] < 7 ? host[1] : 0], (long long)host[2]);
+        return fs_fail_(FS_EINVAL, msg, 0);
+    }
     return FS_OK;
 }

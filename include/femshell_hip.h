@@ -451,7 +451,7 @@ void fs_fused_plan_free(fs_fused_plan *plan);
  *                          flush at ODD ones (a block with an odd number of contributions ends in an idle step; a
  *                          pattern-only block is two idle steps, the second flushing zeros)
  *   props [n_props][37] as for fs_solid_batch; status [E] (FS_ST_BAD_JAC where det J <= 1e-14, OR-ed in: zero it) or NULL
- * The kernel trusts its plan (fs_fused_hex_plan_build's output).  No counterpart in the reference beyond the lines above.
+ * No counterpart in the reference beyond the lines above.
  */
 typedef struct fs_hex_node { int32_t sbase; int32_t m; } fs_hex_node;                    /* 8 bytes */
 typedef struct fs_hex_run { int64_t gdst; int32_t sbase; int32_t len; } fs_hex_run;      /* 16 bytes */
@@ -464,6 +464,14 @@ int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id, const doub
                            int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
                            const fs_hex_node *nodes, const int64_t *pat_rptr, const fs_hex_run *runs,
                            const int64_t *pat_lptr, const uint32_t *steps, double *data, int32_t *status, void *stream);
+/* The kernel trusts its plan.  A plan that does not come from fs_fused_hex_plan_build must pass this check once before
+ * its first launch (device pointers; synchronises `stream`, allocates 24 bytes): patch sizes within the limits above,
+ * element indices in [0, E), node slabs and copy-out runs inside the staging image and inside [0, nnz), active steps
+ * naming a slot of their patch, flushes on odd steps with node and neighbour rank in range.  FS_EINVAL otherwise
+ * (fs_last_error names the first violated rule) -- never a GPU fault. */
+int fs_fused_hex_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
+                            const fs_hex_node *nodes, const int64_t *pat_rptr, const fs_hex_run *runs,
+                            const int64_t *pat_lptr, const uint32_t *steps, int64_t E, int64_t nnz, void *stream);
 /* Host-side plan builder (all pointers host memory; OpenMP over patches).  conn [E][8]; nbr_ptr / nbr: node graph of the
  * CSR pattern (neighbours ascending); node_patch [n_nodes].  FS_EINVAL when a patch exceeds a limit above, when a node
  * pair is shared by more than 8 elements or when an element lists a node twice -- callers then keep the two-kernel route. */

@@ -110,3 +110,32 @@ def test_fused_hex8_status_and_fallbacks():
     lib = _lib.load()
     assert lib.fs_fused_assemble_hex8(None, None, None, 1, 5, 1, None, None, None, None, None, None, None, None, None, None,
                                       _lib.stream_ptr()) == -22
+
+
+def test_hex_plan_check_rejects_malformed_plans():
+    """fs_fused_hex_plan_check: the built plan passes, corrupted copies come back as FS_EINVAL (never launched)."""
+    coords, conn = brick_block(9, 8, 7)
+    asm = _asm(coords, conn)
+    fp = asm.fused_plan()
+    lib, dev, nnz, E = _lib.load(), asm.device, asm._plan.nnz, conn.shape[0]
+    names = ("pat_eptr", "pat_elems", "pat_nptr", "nodes", "pat_rptr", "runs", "pat_lptr", "steps")
+
+    def check(**repl):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+        a = [t(repl.get(k, getattr(fp, k))) for k in names]
+        rc = lib.fs_fused_hex_plan_check(fp.n_patches, *[_lib.ptr(x) for x in a], E, nnz, _lib.stream_ptr())
+        return rc, lib.fs_last_error().decode()
+
+    assert check()[0] == 0
+    el = fp.pat_elems.copy(); el[3] = E
+    rc, msg = check(pat_elems=el); assert rc == -22 and "element index" in msg
+    nd = fp.nodes.copy(); nd["sbase"][1] = 19300
+    rc, msg = check(nodes=nd); assert rc == -22 and "slab" in msg
+    rn = fp.runs.copy(); rn["gdst"][0] = nnz - 3
+    rc, msg = check(runs=rn); assert rc == -22 and "run" in msg
+    st = fp.steps.copy(); act = np.argwhere((st >> 13) & 1); st[act[5][0], act[5][1]] |= 127
+    rc, msg = check(steps=st); assert rc == -22 and "slot" in msg
+    st = fp.steps.copy(); fl = np.argwhere((st >> 14) & 1); st[fl[2][0], fl[2][1]] |= np.uint32(127 << 21)
+    rc, msg = check(steps=st); assert rc == -22 and "rank" in msg
+    lp = fp.pat_lptr.copy(); lp[1:] += 1
+    assert check(pat_lptr=lp)[0] == -22
