@@ -550,6 +550,7 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
     from fem_shell_amd.assembler import MeshAssembler
     from fem_shell_amd.elements import ElementFamily
     lams = c5_laminates()
+    torch.cuda.reset_peak_memory_stats()
     log(f"plate {nx}x{ny}: mesh")
     t0 = time.perf_counter()
     # x-bands of 25 columns of the GLOBAL plate cycling through the 16 laminates: every strip is its part of the plate
@@ -607,9 +608,12 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stream_ms = e0.elapsed_time(e1) / steps            # launch stream only: the fused kernel, back to back
+    nnz = int(K.nnz)
+    if not distributed:
+        K = None                                       # (not kept beside the next measurement's value arrays)
     # the kernel alone, HIP events on its stream, nothing else in flight (no exchange)
     k_ms = avg_ms(torch, lambda: local.assemble_stiffness_fused(), max(3, min(steps, 10)))
-    res = {"E": E, "dt": dt, "kernel_ms": k_ms, "nx": nx, "ny": ny, "launch_stream_ms_per_step": stream_ms, "nnz": int(K.nnz),
+    res = {"E": E, "dt": dt, "kernel_ms": k_ms, "nx": nx, "ny": ny, "launch_stream_ms_per_step": stream_ms, "nnz": nnz,
            "coupled_frac": float(np.mean((local._prop_table["flags"][local._prop_id] & 1) != 0)),
            "setup_s": {"mesh": t1 - t0, "assembler_symbolic_and_first_K": t2 - t1, "fused_plan": t3 - t2},
            "plan": local.fused_plan().stats(),
@@ -629,8 +633,8 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
         res["setup_s"]["distributed_plan"] = asm.setup_s
     local.check_status()      # the status words the timed steps wrote
     if return_matrix:
-        if distributed:       # the exchange timing above added the interface rows to K five more times
-            K = asm.assemble_stiffness_matrix(recompute=True)
+        K = asm.assemble_stiffness_matrix(recompute=True)   # (the exchange timing above added the interface rows to K again)
+        if distributed:
             asm.finish()
         return res, K, asm
     del K, asm, local

@@ -431,7 +431,11 @@ class MeshAssembler:
         """Patch plan of fs_fused_assemble_quad (fem_shell_amd/fused.py), built on first use."""
         if self._fplan_d is None:
             from .fused import FusedHexPlan, FusedQuadPlan
-            host = self._plan.host() if hasattr(self._plan, "host") else self._plan
+            # the plan builders read the node graph only (not the contribution lists: gigabytes at 10 M elements)
+            from types import SimpleNamespace
+            p = self._plan
+            host = p if isinstance(p.nbr_ptr, np.ndarray) else SimpleNamespace(
+                d=p.d, n_nodes=p.n_nodes, nbr_ptr=p.nbr_ptr.cpu().numpy(), nbr=p.nbr.cpu().numpy())
             if self._family == ElementFamily.SOLID:
                 self._fplan = FusedHexPlan(host, self._conn, self._coords)
                 self._fused_flags = 0

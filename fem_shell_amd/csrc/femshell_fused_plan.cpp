@@ -4,6 +4,7 @@
 // ORDER (the reference's ADD_VALUES insertion order, core/assembler.py:295-300), and on which lane each contribution
 // is evaluated.  Host arrays in, host arrays out; the caller uploads them.  OpenMP over patches.
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,40 @@ struct Task {          // one CSR block (I, J) produced by a patch
     int n;             // contributions
     uint32_t ev[32];   // slot | ti << 8 | tj << 10 | transposed << 12
 };
+
+// Nodes that lead a block row, sorted by (patch id, node index), and the range of every patch in that order.  Patch ids
+// are any integers: dense small ones (the usual case: 0 .. n_patches - 1) go through a counting sort, O(N); anything
+// else through a stable comparison sort.
+inline void nodes_by_patch(int64_t n_nodes, const int64_t *nbr_ptr, const int64_t *node_patch, std::vector<int64_t> &order,
+                           std::vector<int64_t> &pstart) {
+    int64_t lo = INT64_MAX, hi = INT64_MIN, n_lead = 0;
+    for (int64_t i = 0; i < n_nodes; i++)
+        if (nbr_ptr[i + 1] > nbr_ptr[i]) { lo = std::min(lo, node_patch[i]); hi = std::max(hi, node_patch[i]); n_lead++; }
+    order.clear();
+    pstart.clear();
+    if (n_lead == 0) { pstart.push_back(0); return; }
+    if (lo >= 0 && hi < 4 * n_nodes + 1024) {
+        std::vector<int64_t> cnt((size_t)hi + 2, 0);
+        for (int64_t i = 0; i < n_nodes; i++)
+            if (nbr_ptr[i + 1] > nbr_ptr[i]) cnt[node_patch[i] + 1]++;
+        for (int64_t q = 0; q <= hi; q++) {
+            if (cnt[q + 1] > 0) pstart.push_back(cnt[q]);
+            cnt[q + 1] += cnt[q];
+        }
+        pstart.push_back(n_lead);
+        order.resize(n_lead);
+        for (int64_t i = 0; i < n_nodes; i++)             // ascending node index inside a patch
+            if (nbr_ptr[i + 1] > nbr_ptr[i]) order[cnt[node_patch[i]]++] = i;
+        return;
+    }
+    order.reserve(n_lead);
+    for (int64_t i = 0; i < n_nodes; i++)
+        if (nbr_ptr[i + 1] > nbr_ptr[i]) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return node_patch[a] < node_patch[b]; });
+    for (int64_t i = 0; i < (int64_t)order.size(); i++)
+        if (i == 0 || node_patch[order[i]] != node_patch[order[i - 1]]) pstart.push_back(i);
+    pstart.push_back((int64_t)order.size());
+}
 
 // position of `key` in the sorted range [b, e) or -1
 inline int64_t find_sorted(const int32_t *b, const int32_t *e, int32_t key) {
@@ -228,15 +263,8 @@ int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const i
             }
         }
         // nodes that lead a block row, sorted by (patch, node)
-        std::vector<int64_t> order;
-        order.reserve(n_nodes);
-        for (int64_t i = 0; i < n_nodes; i++)
-            if (nbr_ptr[i + 1] > nbr_ptr[i]) order.push_back(i);
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return node_patch[a] < node_patch[b]; });
-        std::vector<int64_t> pstart;        // ranges of `order`, one per patch
-        for (int64_t i = 0; i < (int64_t)order.size(); i++)
-            if (i == 0 || node_patch[order[i]] != node_patch[order[i - 1]]) pstart.push_back(i);
-        pstart.push_back((int64_t)order.size());
+        std::vector<int64_t> order, pstart;        // pstart: ranges of `order`, one per patch
+        nodes_by_patch(n_nodes, nbr_ptr, node_patch, order, pstart);
         const int64_t np = (int64_t)pstart.size() - 1;
         std::vector<int64_t> ne(np, 0), nl(np, 0), nev(np, 0);
         std::vector<std::vector<int32_t>> els(np);
@@ -482,14 +510,8 @@ int fs_fused_hex_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, con
                     m.n2e[fill[nd]++] = (int32_t)e;
                 }
         }
-        std::vector<int64_t> order;
-        for (int64_t i = 0; i < n_nodes; i++)
-            if (nbr_ptr[i + 1] > nbr_ptr[i]) order.push_back(i);
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return node_patch[a] < node_patch[b]; });
-        std::vector<int64_t> pstart;
-        for (int64_t i = 0; i < (int64_t)order.size(); i++)
-            if (i == 0 || node_patch[order[i]] != node_patch[order[i - 1]]) pstart.push_back(i);
-        pstart.push_back((int64_t)order.size());
+        std::vector<int64_t> order, pstart;
+        nodes_by_patch(n_nodes, nbr_ptr, node_patch, order, pstart);
         const int64_t np = (int64_t)pstart.size() - 1;
         std::vector<int64_t> ne(np, 0), nl(np, 0), nev(np, 0), nr(np, 0);
         std::vector<std::vector<int32_t>> els(np);
