@@ -42,6 +42,43 @@ struct Task {          // one CSR block (I, J) produced by a patch
     uint32_t ev[32];   // slot | ti << 8 | tj << 10 | transposed << 12
 };
 
+// node -> elements touching it, ascending element index, every element at most once per node.  All threads: counts with
+// atomic increments, fill with atomic cursors (any order), then every node's short list is sorted and deduplicated.
+inline void build_node_to_elements(const int64_t *conn, int64_t E, int nn, int64_t n_nodes, std::vector<int64_t> &ptr,
+                                   std::vector<int32_t> &n2e) {
+    std::vector<int64_t> cnt(n_nodes + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < E * nn; i++) {
+#pragma omp atomic
+        cnt[conn[i] + 1]++;
+    }
+    for (int64_t i = 0; i < n_nodes; i++) cnt[i + 1] += cnt[i];
+    std::vector<int32_t> raw((size_t)E * nn);
+    std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < E; e++)
+        for (int k = 0; k < nn; k++) {
+            int64_t pos;
+#pragma omp atomic capture
+            pos = cur[conn[e * nn + k]]++;
+            raw[pos] = (int32_t)e;
+        }
+    std::vector<int64_t> len(n_nodes + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_nodes; i++) {
+        int32_t *b = raw.data() + cnt[i], *e = raw.data() + cnt[i + 1];
+        std::sort(b, e);
+        len[i + 1] = std::unique(b, e) - b;
+    }
+    for (int64_t i = 0; i < n_nodes; i++) len[i + 1] += len[i];
+    ptr.swap(len);
+    if (ptr[n_nodes] == E * nn) { n2e.swap(raw); return; }
+    n2e.resize(ptr[n_nodes]);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_nodes; i++)
+        std::copy(raw.begin() + cnt[i], raw.begin() + cnt[i] + (ptr[i + 1] - ptr[i]), n2e.begin() + ptr[i]);
+}
+
 // Nodes that lead a block row, sorted by (patch id, node index), and the range of every patch in that order.  Patch ids
 // are any integers: dense small ones (the usual case: 0 .. n_patches - 1) go through a counting sort, O(N); anything
 // else through a stable comparison sort.
@@ -231,37 +268,18 @@ int fs_fused_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const i
     if (E < 0 || n_nodes <= 0 || E > INT32_MAX) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: bad sizes", 0);
     if (max_patch_elems < 16 || max_patch_elems > FS_FUSED_MAX_PATCH_ELEMS)
         return fs_fail_(FS_EINVAL, "fs_fused_plan_build: max_patch_elems must lie in [16, FS_FUSED_MAX_PATCH_ELEMS]", 0);
-    for (int64_t i = 0; i < E * 4; i++)
-        if (conn[i] < 0 || conn[i] >= n_nodes) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: connectivity out of range", 0);
+    {
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+        for (int64_t i = 0; i < E * 4; i++) bad |= (conn[i] < 0 || conn[i] >= n_nodes) ? 1 : 0;
+        if (bad) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: connectivity out of range", 0);
+    }
     fs_fused_plan *P = new (std::nothrow) fs_fused_plan;
     if (!P) return fs_fail_(FS_EINVAL, "fs_fused_plan_build: out of memory", 0);
     try {
         Mesh m{conn, E, n_nodes, nbr_ptr, nbr, {}, {}};
-        // node -> elements (element order)
-        m.n2e_ptr.assign(n_nodes + 1, 0);
-        for (int64_t i = 0; i < E * 4; i++) m.n2e_ptr[conn[i] + 1]++;
-        for (int64_t i = 0; i < n_nodes; i++) m.n2e_ptr[i + 1] += m.n2e_ptr[i];
-        m.n2e.resize(E * 4);
-        {
-            std::vector<int64_t> fill(m.n2e_ptr.begin(), m.n2e_ptr.end() - 1);
-            for (int64_t e = 0; e < E; e++)
-                for (int k = 0; k < 4; k++) {
-                    const int64_t nd = conn[e * 4 + k];
-                    // a node listed twice by one element counts once
-                    if (fill[nd] > m.n2e_ptr[nd] && m.n2e[fill[nd] - 1] == (int32_t)e) continue;
-                    m.n2e[fill[nd]++] = (int32_t)e;
-                }
-            // compact (duplicates skipped above leave holes at the row ends)
-            std::vector<int64_t> np(n_nodes + 1, 0);
-            for (int64_t i = 0; i < n_nodes; i++) np[i + 1] = np[i] + (fill[i] - m.n2e_ptr[i]);
-            if (np[n_nodes] != E * 4) {
-                std::vector<int32_t> c(np[n_nodes]);
-                for (int64_t i = 0; i < n_nodes; i++)
-                    std::copy(m.n2e.begin() + m.n2e_ptr[i], m.n2e.begin() + fill[i], c.begin() + np[i]);
-                m.n2e.swap(c);
-                m.n2e_ptr.swap(np);
-            }
-        }
+        // node -> elements (ascending; a node listed twice by one element counts once)
+        build_node_to_elements(conn, E, 4, n_nodes, m.n2e_ptr, m.n2e);
         // nodes that lead a block row, sorted by (patch, node)
         std::vector<int64_t> order, pstart;        // pstart: ranges of `order`, one per patch
         nodes_by_patch(n_nodes, nbr_ptr, node_patch, order, pstart);
@@ -494,21 +512,10 @@ int fs_fused_hex_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, con
     if (!P) return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: out of memory", 0);
     try {
         Mesh m{conn, E, n_nodes, nbr_ptr, nbr, {}, {}};
-        m.n2e_ptr.assign(n_nodes + 1, 0);
-        for (int64_t i = 0; i < E * 8; i++) m.n2e_ptr[conn[i] + 1]++;
-        for (int64_t i = 0; i < n_nodes; i++) m.n2e_ptr[i + 1] += m.n2e_ptr[i];
-        m.n2e.resize(E * 8);
-        {
-            std::vector<int64_t> fill(m.n2e_ptr.begin(), m.n2e_ptr.end() - 1);
-            for (int64_t e = 0; e < E; e++)
-                for (int k = 0; k < 8; k++) {
-                    const int64_t nd = conn[e * 8 + k];
-                    if (fill[nd] > m.n2e_ptr[nd] && m.n2e[fill[nd] - 1] == (int32_t)e) {     // a node listed twice
-                        delete P;
-                        return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: an element lists a node twice", 0);
-                    }
-                    m.n2e[fill[nd]++] = (int32_t)e;
-                }
+        build_node_to_elements(conn, E, 8, n_nodes, m.n2e_ptr, m.n2e);
+        if (m.n2e_ptr[n_nodes] != E * 8) {
+            delete P;
+            return fs_fail_(FS_EINVAL, "fs_fused_hex_plan_build: an element lists a node twice", 0);
         }
         std::vector<int64_t> order, pstart;
         nodes_by_patch(n_nodes, nbr_ptr, node_patch, order, pstart);
