@@ -242,3 +242,20 @@ def test_plan_check_rejects_malformed_plans():
     rc, msg = check(recs=rc_); assert rc == -22 and "slot" in msg
     rc_ = fp.recs.copy(); rc_["flags"][out[3]] |= np.uint32(15 << 16)      # chain position beyond the chain
     assert check(recs=rc_)[0] == -22
+
+
+def test_device_partition_equals_the_numpy_partition_on_lattice_meshes():
+    """fused.partition_nodes_device (torch, on the device) against fused.partition_nodes (NumPy): the same node -> patch
+    map on lattice-numbered meshes -- flat, curved, closed tube --, None on meshes that are not numbered like a grid."""
+    from fem_shell_amd import fused
+    dev = torch.device("cuda", 0)
+    cases = [meshes.jittered_plate(37, 23, 1.0, 0.7, seed=3), meshes.cylindrical_patch(25.0, 25.0, 40.0, 19, 31),
+             meshes.jittered_plate(200, 9, 5.0, 1.0, seed=4)]
+    for mesh in cases:
+        for max_elems in (64, 48):
+            want = fused.partition_nodes(mesh.coords, mesh.conn, max_elems)
+            got = fused.partition_nodes_device(mesh.node_count, torch.from_numpy(np.asarray(mesh.conn)).to(dev), max_elems)
+            assert got is not None and got.dtype == np.int64
+            assert np.array_equal(got, want)
+    coords, conn = fan_mesh(12, seed=1)          # not numbered like a grid: the NumPy version takes over
+    assert fused.partition_nodes_device(coords.shape[0], torch.from_numpy(conn).to(dev), 64) is None
