@@ -39,6 +39,9 @@ SIGNATURES = {
     "fs_fused_plan_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "fs_fused_plan_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_plan_free": (None, [_vp]),
+    "fs_fused_plan_device_begin": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_fused_plan_device_finish": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_fused_plan_device_free": (None, [_vp]),
     "fs_shell_tri_batch": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _vp, _vp,
                                           _vp, _vp, _vp, _vp]),
     "fs_solid_batch": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _i32, _i64, _u32, _u32, _vp, _vp, _vp,

@@ -430,23 +430,37 @@ class MeshAssembler:
     def fused_plan(self):
         """Patch plan of fs_fused_assemble_quad (fem_shell_amd/fused.py), built on first use."""
         if self._fplan_d is None:
-            from .fused import FusedHexPlan, FusedQuadPlan
-            # the plan builders read the node graph only (not the contribution lists: gigabytes at 10 M elements)
+            from .fused import FusedHexPlan, FusedQuadPlan, FusedQuadPlanDevice, partition_nodes, partition_nodes_device
+            # the host plan builders read the node graph only (not the contribution lists: gigabytes at 10 M elements)
             from types import SimpleNamespace
             p = self._plan
-            host = p if isinstance(p.nbr_ptr, np.ndarray) else SimpleNamespace(
+            on_device = not isinstance(p.nbr_ptr, np.ndarray)
+            host_view = lambda: p if not on_device else SimpleNamespace(
                 d=p.d, n_nodes=p.n_nodes, nbr_ptr=p.nbr_ptr.cpu().numpy(), nbr=p.nbr.cpu().numpy())
             if self._family == ElementFamily.SOLID:
-                self._fplan = FusedHexPlan(host, self._conn, self._coords)
+                self._fplan = FusedHexPlan(host_view(), self._conn, self._coords)
                 self._fused_flags = 0
             else:
-                from .fused import partition_nodes_device
                 g = self._groups[0]
                 # structured numbering: the node -> patch map is integer arithmetic on the device (None otherwise: the
-                # NumPy partition with its bisection pass runs inside FusedQuadPlan)
-                node_patch = partition_nodes_device(int(self.mesh.node_count), g["conn_d"], self.fused_max_patch_elems)
-                self._fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems,
-                                            node_patch=node_patch)
+                # NumPy partition with its bisection pass takes over)
+                node_patch = partition_nodes_device(int(self.mesh.node_count), g["conn_d"], self.fused_max_patch_elems,
+                                                    as_host=not on_device)
+                self._fplan = None
+                if on_device:
+                    # the whole plan on the device (fs_fused_plan_device_begin / _finish); a mesh beyond its LDS capacities
+                    # goes through the host builder, every other failure is the mesh's (fused_ready() handles it)
+                    if node_patch is None:
+                        node_patch = torch.from_numpy(partition_nodes(self._coords, self._conn, self.fused_max_patch_elems))
+                    try:
+                        self._fplan = FusedQuadPlanDevice(p, g["conn_d"], node_patch, self.fused_max_patch_elems)
+                    except _lib.FemShellHipError as exc:
+                        if "capacity" not in str(exc):
+                            raise
+                        node_patch = node_patch.cpu().numpy()
+                if self._fplan is None:
+                    self._fplan = FusedQuadPlan(host_view(), self._conn, self._coords,
+                                                max_patch_elems=self.fused_max_patch_elems, node_patch=node_patch)
                 self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
             self._fplan_d = self._fplan.to_device(self.device)
         return self._fplan

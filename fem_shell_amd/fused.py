@@ -164,9 +164,10 @@ def partition_nodes(coords, conn, max_elems=64):
     raise RuntimeError("partition_nodes did not converge")
 
 
-def partition_nodes_device(n_nodes, conn_d, max_elems=64):
+def partition_nodes_device(n_nodes, conn_d, max_elems=64, as_host=True):
     """partition_nodes for meshes numbered like a structured grid, on the device (torch integer plumbing, the same
-    arithmetic: lattice test, grid binning with patch ids in grid order).  Returns the int64 [N] map as a HOST array, or
+    arithmetic: lattice test, grid binning with patch ids in grid order).  Returns the int64 [N] map as a HOST array (as a
+    device tensor with as_host=False), or
     None when the mesh is not lattice-numbered or some patch would touch more than max_elems elements (the NumPy
     version with its bisection pass then takes over).  On lattice meshes the two agree exactly (tests/test_gpu_fused.py)."""
     import torch
@@ -207,7 +208,7 @@ def partition_nodes_device(n_nodes, conn_d, max_elems=64):
     cnt = torch.bincount(pc[first], minlength=npat)
     if int(cnt.max()) > max_elems:
         return None
-    return patch.cpu().numpy()
+    return patch.cpu().numpy() if as_host else patch
 
 
 class FusedQuadPlan:
@@ -273,6 +274,76 @@ class FusedQuadPlan:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         return {"pat_eptr": t(self.pat_eptr), "pat_elems": t(self.pat_elems), "pat_rptr": t(self.pat_rptr),
                 "recs": t(self.recs.view(np.uint8).reshape(-1))}
+
+
+class FusedQuadPlanDevice:
+    """The same plan built on the device (fs_fused_plan_device_begin / _finish, csrc/femshell_fused_plan_dev.hip): the
+    four arrays never exist on the host.  plan: symbolic.DeviceBlockPlan (device nbr_ptr / nbr), conn_d: device int64
+    [E][4], node_patch_d: device int64 [N] (partition_nodes_device(..., as_host=False), or an uploaded
+    partition_nodes).  Raises FemShellHipError like FusedQuadPlan; "device plan capacity exceeded" means: use the host
+    builder for this mesh."""
+
+    def __init__(self, plan, conn_d, node_patch_d, max_patch_elems=64):
+        import ctypes
+        import torch
+        from . import _lib
+        if plan.d != 6 or conn_d.ndim != 2 or conn_d.shape[1] != 4 or conn_d.dtype != torch.int64:
+            raise ValueError("the fused kernel is built for uniform MITC4+ meshes (4 nodes, 6 dofs per node)")
+        if not 16 <= max_patch_elems <= 64:
+            raise ValueError("max_patch_elems must lie in [16, 64]")
+        dev = conn_d.device
+        conn_d = conn_d.contiguous()
+        node_patch_d = node_patch_d.to(device=dev, dtype=torch.int64).contiguous()
+        nbr_ptr, nbr = plan.nbr_ptr.contiguous(), plan.nbr.contiguous()
+        assert nbr_ptr.dtype == torch.int64 and nbr.dtype == torch.int32
+        self.E, self.max_patch_elems = int(conn_d.shape[0]), int(max_patch_elems)
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        npat, nslots, nrecs, nev = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.fs_fused_plan_device_begin(_lib.ptr(conn_d), self.E, int(plan.n_nodes), _lib.ptr(nbr_ptr), _lib.ptr(nbr),
+                                                  _lib.ptr(node_patch_d), self.max_patch_elems, ctypes.byref(h),
+                                                  ctypes.byref(npat), ctypes.byref(nslots), ctypes.byref(nrecs),
+                                                  ctypes.byref(nev), _lib.stream_ptr()), "fs_fused_plan_device_begin")
+        self.n_patches, self.n_elem_slots, self.n_recs, self.n_evals = (int(npat.value), int(nslots.value),
+                                                                        int(nrecs.value), int(nev.value))
+        try:
+            self._d = {"pat_eptr": torch.empty(self.n_patches + 1, dtype=torch.int64, device=dev),
+                       "pat_elems": torch.empty(self.n_elem_slots, dtype=torch.int32, device=dev),
+                       "pat_rptr": torch.empty(self.n_patches + 1, dtype=torch.int64, device=dev),
+                       "recs": torch.empty(self.n_recs * REC_DTYPE.itemsize, dtype=torch.uint8, device=dev)}
+        except BaseException:
+            lib.fs_fused_plan_device_free(h)
+            raise
+        d = self._d
+        _lib.check(lib.fs_fused_plan_device_finish(h, _lib.ptr(d["pat_eptr"]), _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]),
+                                                   _lib.ptr(d["recs"]), _lib.stream_ptr()), "fs_fused_plan_device_finish")
+
+    def stats(self):
+        import torch
+        d = self._d
+        rounds = int(((torch.diff(d["pat_rptr"]) + 255) // 256).sum())
+        tiles = int(((torch.diff(d["pat_eptr"]) + 15) // 16).sum())
+        return {"patches": self.n_patches, "elements_per_patch": self.n_elem_slots / max(self.n_patches, 1),
+                "stage1_recompute": self.n_elem_slots / max(self.E, 1),
+                "stage1_tile_fill": self.n_elem_slots / max(tiles * 16, 1),
+                "stage2_lane_fill": self.n_evals / max(rounds * 512, 1),
+                "stage2_wave_fill": self.n_evals / max(2 * self.n_recs, 1),
+                "record_bytes_per_element": self.n_recs * REC_DTYPE.itemsize / max(self.E, 1)}
+
+    def to_device(self, device):
+        return self._d
+
+    def to_host(self):
+        """The four arrays as NumPy (tests, diagnostics)."""
+        d = self._d
+        return {"pat_eptr": d["pat_eptr"].cpu().numpy(), "pat_elems": d["pat_elems"].cpu().numpy(),
+                "pat_rptr": d["pat_rptr"].cpu().numpy(), "recs": d["recs"].cpu().numpy().view(REC_DTYPE)}
+
+    # host views with FusedQuadPlan's names, copied from the device when somebody asks (tests, diagnostics)
+    pat_eptr = property(lambda self: self._d["pat_eptr"].cpu().numpy())
+    pat_elems = property(lambda self: self._d["pat_elems"].cpu().numpy())
+    pat_rptr = property(lambda self: self._d["pat_rptr"].cpu().numpy())
+    recs = property(lambda self: self._d["recs"].cpu().numpy().view(REC_DTYPE))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -424,6 +424,28 @@ int fs_fused_plan_export(const fs_fused_plan *plan, int64_t *pat_eptr, int32_t *
 void fs_fused_plan_free(fs_fused_plan *plan);
 
 /*
+ * The same plan built ON THE DEVICE (csrc/femshell_fused_plan_dev.hip): every pointer is DEVICE memory, the four plan
+ * arrays come out bit for bit as fs_fused_plan_build / _export would give them, without the node graph travelling to the
+ * host and gigabytes of records travelling back.  Two calls, like fs_csr_symbolic_begin / _finish:
+ *   begin   sorts the (node, element) incidences and the lead nodes by patch (rocPRIM), counts elements and lanes of
+ *           every patch with one workgroup per patch and returns the sizes the caller allocates: n_patches + 1,
+ *           n_elem_slots, n_patches + 1, n_recs entries (n_evals, optional: number of contributions).  Synchronises
+ *           `stream`; allocates and frees its own work space.  conn / nbr_ptr / nbr must stay alive until finish.
+ *   finish  fills the caller's arrays (the same kernel, now writing) and frees the handle, also on failure.
+ * node_patch: patch ids >= 0 (nodes without a block row are ignored).  Errors (FS_EINVAL) as fs_fused_plan_build; in
+ * addition "device plan capacity exceeded" when a patch is beyond what one workgroup holds in LDS (more than 640 blocks
+ * or 1024 lanes: pattern-only blocks of a distributed plan, or many chains of more than 4 contributions) -- such a mesh
+ * goes through the host builder.  No counterpart in the reference (its loops need no plan).
+ */
+typedef struct fs_fused_plan_dev fs_fused_plan_dev;
+int fs_fused_plan_device_begin(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                               const int64_t *node_patch, int32_t max_patch_elems, fs_fused_plan_dev **plan,
+                               int64_t *n_patches, int64_t *n_elem_slots, int64_t *n_recs, int64_t *n_evals, void *stream);
+int fs_fused_plan_device_finish(fs_fused_plan_dev *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_rptr,
+                                fs_fused_rec *recs, void *stream);
+void fs_fused_plan_device_free(fs_fused_plan_dev *plan);
+
+/*
  * Fused evaluate-and-assemble, HEXA8 (3 dofs per node, full 2 x 2 x 2 rule): the CSR values of K straight from the
  * coordinates, no element matrices in memory.  Replaces the element evaluations HEXA8.K (elements/SOLID.py:543-567 with
  * _compute_jacobian / compute_B_matrix :164-266 and the rule / shape functions :1744-1818) TOGETHER with the

@@ -24,3 +24,12 @@ for rep in range(2):
     d = fp.to_device(asm.device); torch.cuda.synchronize(); t.append(time.perf_counter())
     names = ["partition (device) + D2H of the map", "node graph D2H", "native builder + export", "upload of the plan"]
     print(f"rep {rep}: " + ", ".join(f"{n} {b - a:.3f} s" for n, a, b in zip(names, t[:-1], t[1:])), f"total {t[-1] - t[0]:.3f} s; records {fp.recs.nbytes / 1e9:.2f} GB")
+    del fp, d
+# the device builder (fs_fused_plan_device_begin / _finish)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    patch = fused.partition_nodes_device(mesh.node_count, g["conn_d"], 64, as_host=False); torch.cuda.synchronize(); t1 = time.perf_counter()
+    fpd = fused.FusedQuadPlanDevice(asm._plan, g["conn_d"], patch, 64); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"device rep {rep}: partition {t1 - t0:.3f} s, device builder {t2 - t1:.3f} s, total {t2 - t0:.3f} s; "
+          f"{fpd.n_patches} patches, {fpd.n_recs * 64 / 1e9:.2f} GB of records")
+    del fpd
