@@ -7,8 +7,11 @@
 // per PATCH of nodes:
 //   phase 1  lane = (element slot, Gauss point): Jacobian, inverse, w detJ and the physical gradients of the 8 shape
 //            functions (SOLID.py:164-266, rule :1745-1766, N :1768-1818) with the expressions of solid_kernel, scaled by
-//            sqrt(w detJ), into LDS: [slot][q][node][3], 193 doubles per slot (odd stride: lanes of different slots hit
-//            different banks).  Elements of the one-element halo are evaluated by every patch that touches them.
+//            sqrt(w detJ), into LDS as 16-byte pieces, so that phase 2 reads with ds_read_b128 (256 B per LDS clock;
+//            ds_read2_b64 on 8-byte aligned triples moves half of that): (g_x, g_y) at [slot][q][node], g_z of two
+//            Gauss points at [slot][q / 2][node]; odd slot strides (65 and 33 pieces) spread the slots over the banks,
+//            and the lanes of a wave are numbered (slot fastest) so that the stores of a lane group are conflict-free.
+//            Elements of the one-element halo are evaluated by every patch that touches them.
 //   phase 2  lane = up to 8 contributions (element slot, local node pair) in a row.  C is constant over the element, so
 //            a contribution contracts over the Gauss points first: G = sum_q g_i g_j^T (72 FMA), K = C : G (81 FMA with
 //            C in scalar registers when the model has one material, as every SOLID-family model of the reference has).
@@ -30,9 +33,10 @@
 
 namespace {
 
-constexpr int HX_GS = 193;                       // doubles per element slot (8 x 8 x 3 + 1)
+constexpr int HX_SA = 65, HX_SB = 33;            // 16-byte pieces per element slot: (g_x, g_y) and g_z pairs, + 1 (odd)
+constexpr int HX_PIECES = FS_HEX_MAX_PATCH_ELEMS * (HX_SA + HX_SB);
 constexpr int HX_NT = FS_HEX_MAX_PATCH_LANES;    // 512
-static_assert(FS_HEX_STAGE_DOUBLES == FS_HEX_MAX_PATCH_ELEMS * HX_GS, "staging overlays the gradient image");
+static_assert(FS_HEX_STAGE_DOUBLES <= 2 * HX_PIECES, "staging overlays the gradient image");
 
 #define HX_SLOT(r) ((int)((r) & 127u))
 #define HX_LI(r) ((int)(((r) >> 7) & 7u))
@@ -55,7 +59,9 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                                                           const int64_t *__restrict__ pat_rptr, const fs_hex_run *__restrict__ runs,
                                                           const int64_t *__restrict__ pat_lptr, const uint32_t *__restrict__ steps,
                                                           double *__restrict__ data, int32_t *__restrict__ status) {
-    __shared__ double s_g[FS_HEX_STAGE_DOUBLES];          // gradients, later the staging image of the patch's CSR slabs
+    __shared__ double2 s_mem[HX_PIECES];                  // gradients, later the staging image of the patch's CSR slabs
+    double2 *const s_a = s_mem, *const s_b = s_mem + FS_HEX_MAX_PATCH_ELEMS * HX_SA;
+    double *const s_g = reinterpret_cast<double *>(s_mem);
     __shared__ int s_pid[UNI ? 1 : FS_HEX_MAX_PATCH_ELEMS];
     __shared__ fs_hex_node s_node[FS_HEX_MAX_PATCH_NODES];
     __shared__ fs_hex_run s_run[FS_HEX_MAX_PATCH_NODES];  // copy-out runs of the patch (at most one per node)
@@ -86,9 +92,10 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
         if (tid < nn) s_node[tid] = nodes[n0 + tid];
         if (tid >= 64 && tid - 64 < nr) s_run[tid - 64] = runs[r0 + tid - 64];     // (read after three barriers)
         // ---------------- phase 1: gradients of (slot, Gauss point) ----------------
-        for (int t = tid; t < ne * 8; t += HX_NT) {
+        for (int t = tid; t < ((ne + 7) & ~7) * 8; t += HX_NT) {
 #pragma clang fp contract(fast)
-            const int slot = t >> 3, q = t & 7;
+            const int slot = (t >> 6) * 8 + (t & 7), q = (t >> 3) & 7;     // a wave: 8 slots (fastest) x 8 Gauss points
+            if (slot >= ne) continue;
             const int64_t e = pat_elems[e0 + slot];
             const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp, zeta = (q & 4) ? gp : -gp;
             double N[8], dxi[8], deta[8], dzeta[8];
@@ -117,12 +124,16 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                 inv[2][2] = divr(J[0][0] * J[1][1] - J[0][1] * J[1][0], det, rdet);
             }
             const double sw = __builtin_sqrt(det);          // weights are 1: w detJ = detJ
-            double *g = s_g + slot * HX_GS + q * 24;
+            double2 *ga = s_a + slot * HX_SA + q * 8;
+            double *gb = reinterpret_cast<double *>(s_b + slot * HX_SB + (q >> 1) * 8) + (q & 1);
 #pragma unroll
-            for (int i = 0; i < 8; i++)
+            for (int i = 0; i < 8; i++) {
+                double gr[3];
 #pragma unroll
-                for (int a = 0; a < 3; a++)
-                    g[3 * i + a] = sw * (inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i]);
+                for (int a = 0; a < 3; a++) gr[a] = sw * (inv[a][0] * dxi[i] + inv[a][1] * deta[i] + inv[a][2] * dzeta[i]);
+                ga[i] = make_double2(gr[0], gr[1]);
+                gb[2 * i] = gr[2];
+            }
             if (!UNI && q == 0) s_pid[slot] = safe_pid(prop_id[e], n_props);
         }
         __syncthreads();
@@ -139,15 +150,20 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                 if (HX_ACTIVE(r)) {
                     const int li = HX_LI(r), lj = HX_LJ(r);
                     const int ci = li < lj ? li : lj, cj = li < lj ? lj : li;
-                    const double *ga = s_g + HX_SLOT(r) * HX_GS + 3 * ci, *gb = s_g + HX_SLOT(r) * HX_GS + 3 * cj;
+                    const double2 *pa = s_a + HX_SLOT(r) * HX_SA, *pb = s_b + HX_SLOT(r) * HX_SB;
                     double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const double a0 = ga[q * 24], a1 = ga[q * 24 + 1], a2 = ga[q * 24 + 2];
-                        const double b0 = gb[q * 24], b1 = gb[q * 24 + 1], b2 = gb[q * 24 + 2];
-                        G[0][0] = FMA(a0, b0, G[0][0]); G[0][1] = FMA(a0, b1, G[0][1]); G[0][2] = FMA(a0, b2, G[0][2]);
-                        G[1][0] = FMA(a1, b0, G[1][0]); G[1][1] = FMA(a1, b1, G[1][1]); G[1][2] = FMA(a1, b2, G[1][2]);
-                        G[2][0] = FMA(a2, b0, G[2][0]); G[2][1] = FMA(a2, b1, G[2][1]); G[2][2] = FMA(a2, b2, G[2][2]);
+                    for (int qp = 0; qp < 4; qp++) {
+                        const double2 az = pb[qp * 8 + ci], bz = pb[qp * 8 + cj];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const double2 axy = pa[(2 * qp + h) * 8 + ci], bxy = pa[(2 * qp + h) * 8 + cj];
+                            const double a0 = axy.x, a1 = axy.y, a2 = h ? az.y : az.x;
+                            const double b0 = bxy.x, b1 = bxy.y, b2 = h ? bz.y : bz.x;
+                            G[0][0] = FMA(a0, b0, G[0][0]); G[0][1] = FMA(a0, b1, G[0][1]); G[0][2] = FMA(a0, b2, G[0][2]);
+                            G[1][0] = FMA(a1, b0, G[1][0]); G[1][1] = FMA(a1, b1, G[1][1]); G[1][2] = FMA(a1, b2, G[1][2]);
+                            G[2][0] = FMA(a2, b0, G[2][0]); G[2][1] = FMA(a2, b1, G[2][1]); G[2][2] = FMA(a2, b2, G[2][2]);
+                        }
                     }
                     double C[6][6];
                     if (UNI) {
