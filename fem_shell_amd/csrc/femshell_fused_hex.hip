@@ -13,12 +13,14 @@
 //            and the lanes of a wave are numbered (slot fastest) so that the stores of a lane group are conflict-free.
 //            Elements of the one-element halo are evaluated by every patch that touches them.
 //   phase 2  lane = up to 8 contributions (element slot, local node pair) in a row.  C is constant over the element, so
-//            a contribution contracts over the Gauss points first: G = sum_q g_i g_j^T (72 FMA), K = C : G (81 FMA with
-//            C in scalar registers when the model has one material, as every SOLID-family model of the reference has).
-//            It is formed for the ordered pair (min, max) and transposed where the block wants (max, min); diagonal
-//            ones are symmetrised (SOLID.py:565) -- the assembled matrix is exactly symmetric.  The contributions of a
-//            CSR block follow each other on one lane and are added in element order, 0 + x0 + x1 + ...; a finished
-//            block stays in registers until the phase ends.
+//            a contribution contracts over the Gauss points first: G = sum_q g_i g_j^T (72 FMA), K = C : G (81 FMA).
+//            The contributions of a CSR block follow each other on one lane and are added in element order,
+//            0 + x0 + x1 + ...; with ONE material in the model (every SOLID-family model of the reference has one) the
+//            G of the block's elements are added in that order and contracted once per block with C in scalar
+//            registers (sum_e C : G_e = C : sum_e G_e: the same products re-associated).  A contribution is formed for
+//            the pair ordered by GLOBAL node index and transposed where the block is (larger, smaller); diagonal ones
+//            are symmetrised (SOLID.py:565) -- the assembled matrix is exactly symmetric.  A finished block stays in
+//            registers until the phase ends.
 //   stores   the blocks go to an LDS image of the patch's CSR slabs (overlaying the gradients) and leave as contiguous
 //            runs: the 3 rows of a node are adjacent in CSR, and so are the slabs of consecutively numbered nodes.
 #include <hip/hip_runtime.h>
@@ -45,6 +47,7 @@ static_assert(FS_HEX_STAGE_DOUBLES <= 2 * HX_PIECES, "staging overlays the gradi
 #define HX_FLUSH(r) ((((r) >> 14) & 1u) != 0)
 #define HX_NODE(r) ((int)(((r) >> 15) & 63u))
 #define HX_RANK(r) ((int)(((r) >> 21) & 127u))
+#define HX_TR(r) ((((r) >> 28) & 1u) != 0)
 
 // Voigt row of the strain component (alpha, gamma): [xx, yy, zz, xy, yz, zx] (SOLID.py:218-266)
 __device__ __forceinline__ constexpr int voigt(int a, int g) {
@@ -143,15 +146,43 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
         {
 #pragma clang fp contract(fast)
             const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            // UNI: the Gauss-point sums G of the block's contributions, added in element order (K = C : sum of G: one
+            // contraction per block); else the contributions K_e = C_e : G_e themselves, added in element order
             double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // K[al][be] = sum over (ga, de) of C[voigt(al, ga)][voigt(be, de)] G[ga][de], then oriented: the plan names
+            // the local nodes of a contribution in the order (smaller, larger) of their GLOBAL indices, so blocks (I, J)
+            // and (J, I) form the same numbers and one of them (HX_TR) stores the transpose; diagonal blocks are
+            // symmetrised (SOLID.py:565)
+            auto contract = [&](const double (&C)[6][6], const double *G, bool tr, bool dg, double *K) {
+#pragma unroll
+                for (int al = 0; al < 3; al++)
+#pragma unroll
+                    for (int be = 0; be < 3; be++) {
+                        double v = C[voigt(al, 0)][voigt(be, 0)] * G[0];
+#pragma unroll
+                        for (int t = 1; t < 9; t++) v = FMA(C[voigt(al, t / 3)][voigt(be, t % 3)], G[t], v);
+                        K[3 * al + be] = v;
+                    }
+#pragma unroll
+                for (int al = 0; al < 3; al++)
+#pragma unroll
+                    for (int be = al + 1; be < 3; be++) {
+                        const double u = K[3 * al + be], l = K[3 * be + al], mean = 0.5 * (u + l);
+                        K[3 * al + be] = dg ? mean : (tr ? l : u);
+                        K[3 * be + al] = dg ? mean : (tr ? u : l);
+                    }
+            };
+            bool dg = false;
 #pragma unroll
             for (int s = 0; s < 8; s++) {
                 const uint32_t r = rec[s];
                 if (HX_ACTIVE(r)) {
-                    const int li = HX_LI(r), lj = HX_LJ(r);
-                    const int ci = li < lj ? li : lj, cj = li < lj ? lj : li;
+                    const int ci = HX_LI(r), cj = HX_LJ(r);
+                    dg = ci == cj;
                     const double2 *pa = s_a + HX_SLOT(r) * HX_SA, *pb = s_b + HX_SLOT(r) * HX_SB;
-                    double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                    double G[9];
+#pragma unroll
+                    for (int c = 0; c < 9; c++) G[c] = UNI ? acc[c] : 0.0;
 #pragma unroll
                     for (int qp = 0; qp < 4; qp++) {
                         const double2 az = pb[qp * 8 + ci], bz = pb[qp * 8 + cj];
@@ -160,45 +191,33 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                             const double2 axy = pa[(2 * qp + h) * 8 + ci], bxy = pa[(2 * qp + h) * 8 + cj];
                             const double a0 = axy.x, a1 = axy.y, a2 = h ? az.y : az.x;
                             const double b0 = bxy.x, b1 = bxy.y, b2 = h ? bz.y : bz.x;
-                            G[0][0] = FMA(a0, b0, G[0][0]); G[0][1] = FMA(a0, b1, G[0][1]); G[0][2] = FMA(a0, b2, G[0][2]);
-                            G[1][0] = FMA(a1, b0, G[1][0]); G[1][1] = FMA(a1, b1, G[1][1]); G[1][2] = FMA(a1, b2, G[1][2]);
-                            G[2][0] = FMA(a2, b0, G[2][0]); G[2][1] = FMA(a2, b1, G[2][1]); G[2][2] = FMA(a2, b2, G[2][2]);
+                            G[0] = FMA(a0, b0, G[0]); G[1] = FMA(a0, b1, G[1]); G[2] = FMA(a0, b2, G[2]);
+                            G[3] = FMA(a1, b0, G[3]); G[4] = FMA(a1, b1, G[4]); G[5] = FMA(a1, b2, G[5]);
+                            G[6] = FMA(a2, b0, G[6]); G[7] = FMA(a2, b1, G[7]); G[8] = FMA(a2, b2, G[8]);
                         }
                     }
-                    double C[6][6];
                     if (UNI) {
-                        for (int a = 0; a < 36; a++) (&C[0][0])[a] = (&Cu[0][0])[a];
+#pragma unroll
+                        for (int c = 0; c < 9; c++) acc[c] = G[c];
                     } else {
                         const double *pr = props + 37 * (int64_t)s_pid[HX_SLOT(r)];
+                        double C[6][6], K[9];
                         for (int a = 0; a < 6; a++)
                             for (int b = a; b < 6; b++) { const double v = 0.5 * (pr[a * 6 + b] + pr[b * 6 + a]); C[a][b] = v; C[b][a] = v; }
+                        contract(C, G, HX_TR(r), dg, K);
+#pragma unroll
+                        for (int c = 0; c < 9; c++) acc[c] = acc[c] + K[c];
                     }
-                    // K[al][be] = sum over (ga, de) of C[voigt(al, ga)][voigt(be, de)] G[ga][de]
-                    double K[3][3];
-#pragma unroll
-                    for (int al = 0; al < 3; al++)
-#pragma unroll
-                        for (int be = 0; be < 3; be++) {
-                            double v = C[voigt(al, 0)][voigt(be, 0)] * G[0][0];
-#pragma unroll
-                            for (int t = 1; t < 9; t++) v = FMA(C[voigt(al, t / 3)][voigt(be, t % 3)], G[t / 3][t % 3], v);
-                            K[al][be] = v;
-                        }
-                    const bool tr = li > lj, dg = li == lj;
-#pragma unroll
-                    for (int al = 0; al < 3; al++)
-#pragma unroll
-                        for (int be = al + 1; be < 3; be++) {
-                            const double u = K[al][be], l = K[be][al], mean = 0.5 * (u + l);
-                            K[al][be] = dg ? mean : (tr ? l : u);
-                            K[be][al] = dg ? mean : (tr ? u : l);
-                        }
-#pragma unroll
-                    for (int c = 0; c < 9; c++) acc[c] = acc[c] + (&K[0][0])[c];
                 }
                 if ((s & 1) && HX_FLUSH(r)) {
+                    if (UNI) {
+                        contract(Cu, acc, HX_TR(r), dg, Kout[s >> 1]);      // a pattern-only block: C : 0 = 0
 #pragma unroll
-                    for (int c = 0; c < 9; c++) { Kout[s >> 1][c] = acc[c]; acc[c] = 0.0; }
+                        for (int c = 0; c < 9; c++) acc[c] = 0.0;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 9; c++) { Kout[s >> 1][c] = acc[c]; acc[c] = 0.0; }
+                    }
                 }
             }
         }

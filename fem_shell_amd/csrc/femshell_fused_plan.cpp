@@ -407,7 +407,9 @@ struct fs_fused_hex_plan {
 
 namespace {
 
-struct HexBlock { int rank; int n; uint32_t ev[8]; };    // one CSR block of a node: contributions slot | li << 7 | lj << 10
+// one CSR block (I, J) of a node: contributions slot | la << 7 | lb << 10 with la / lb the local index of the SMALLER /
+// LARGER of the two global nodes in that element; tr = the block is the transpose of that ordered pair's (I > J)
+struct HexBlock { int rank; int n; uint32_t tr; uint32_t ev[8]; };
 
 // returns 0 or a negative code (-1: a node pair shared by more than 8 elements, -2: element missing from the patch,
 // -6: limits of the step record exceeded)
@@ -430,6 +432,7 @@ int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, i
             HexBlock hb;
             hb.rank = (int)(b - r0);
             hb.n = 0;
+            hb.tr = I > J ? (1u << 28) : 0u;
             const int32_t *eJ = m.n2e.data() + m.n2e_ptr[J], *eJe = m.n2e.data() + m.n2e_ptr[J + 1];
             const int32_t *a = eI, *c = eJ;
             while (a != eIe && c != eJe) {
@@ -443,7 +446,7 @@ int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, i
                     const int64_t slot = find_sorted(elems, elems + ne, e);
                     if (slot < 0) return -2;
                     if (hb.n >= 8) return -1;
-                    hb.ev[hb.n++] = (uint32_t)slot | ((uint32_t)li << 7) | ((uint32_t)lj << 10);
+                    hb.ev[hb.n++] = (uint32_t)slot | ((uint32_t)(I > J ? lj : li) << 7) | ((uint32_t)(I > J ? li : lj) << 10) | hb.tr;
                     a++; c++;
                 }
             }
@@ -471,7 +474,7 @@ int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, i
                 uint32_t *st = out_steps->data() + (size_t)(lane0 + (int64_t)l) * 8 + fill[l];
                 for (int c = 0; c < need; c++) {
                     uint32_t r = c < hb.n ? (hb.ev[c] | (1u << 13)) : 0u;
-                    if (c == need - 1) r |= (1u << 14) | ((uint32_t)q << 15) | ((uint32_t)hb.rank << 21);
+                    if (c == need - 1) r |= (1u << 14) | ((uint32_t)q << 15) | ((uint32_t)hb.rank << 21) | hb.tr;
                     st[c] = r;
                 }
             }

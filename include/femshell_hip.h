@@ -458,18 +458,22 @@ void fs_fused_plan_device_free(fs_fused_plan_dev *plan);
  * and stores them as contiguous runs (the three rows of consecutively numbered nodes are adjacent in CSR).
  * C is constant over an element, so a contribution is contracted over the Gauss points FIRST:
  *     K_e[i][j] = sum_q w detJ B_i^T C B_j = C : G,   G = sum_q (w detJ) grad N_i grad N_j^T   (3 x 3),
- * 8 x 9 + 81 multiply-adds instead of 8 x 90 (the same sum of products re-associated: eps-level differences).  Every
- * contribution is formed for the ordered local pair (min, max) and transposed where the block wants (max, min), the
- * diagonal ones are symmetrised (SOLID.py:565), so the assembled matrix is EXACTLY symmetric; a block's contributions are
- * added in element order, 0 + x0 + x1 + ... (the reference's insertion order).
+ * 8 x 9 + 81 multiply-adds instead of 8 x 90 (the same sum of products re-associated: eps-level differences).  A
+ * block's contributions are added in element order, 0 + x0 + x1 + ... (the reference's insertion order); when the model
+ * has ONE property row the G of the block's elements are added in that order and contracted once per block
+ * (sum_e C : G_e = C : sum_e G_e).  Every contribution is formed for the node pair ordered by GLOBAL index and transposed
+ * where the block is (larger, smaller), the diagonal ones are symmetrised (SOLID.py:565), so the assembled matrix is
+ * EXACTLY symmetric.
  *   pat_eptr / pat_elems   elements of each patch (ascending; position = LDS slot), <= FS_HEX_MAX_PATCH_ELEMS per patch
  *   pat_nptr / nodes       per patch node (ascending node index): offset of its slab in the patch's staging image
  *                          (doubles) and its number of neighbours m (slab = 3 rows x 3 m values)
  *   pat_rptr / runs        copy-out runs of the staging image: `len` doubles from staging offset `sbase` to data[gdst...]
  *   pat_lptr / steps       lanes of each patch (multiples of 64, <= FS_HEX_MAX_PATCH_LANES), 8 step words per lane:
- *                          slot | li << 7 | lj << 10 | active << 13 | flush << 14 | node_local << 15 | rank << 21 --
- *                          contribution (element in `slot`, local nodes li of I and lj of J); `flush`: the block
- *                          (node_local, rank-th neighbour) is complete after this step.  Blocks start at EVEN steps and
+ *                          slot | la << 7 | lb << 10 | active << 13 | flush << 14 | node_local << 15 | rank << 21 |
+ *                          transposed << 28 -- contribution of the element in `slot` to block (I, J): la / lb = local
+ *                          index of the smaller / larger of the global nodes I, J in that element, `transposed` (on
+ *                          every step of the block): I > J, the block is the transpose of what (la, lb) gives; `flush`:
+ *                          the block (node_local, rank-th neighbour) is complete after this step.  Blocks start at EVEN steps and
  *                          flush at ODD ones (a block with an odd number of contributions ends in an idle step; a
  *                          pattern-only block is two idle steps, the second flushing zeros)
  *   props [n_props][37] as for fs_solid_batch; status [E] (FS_ST_BAD_JAC where det J <= 1e-14, OR-ed in: zero it) or NULL
@@ -481,7 +485,7 @@ FS_STATIC_ASSERT(sizeof(fs_hex_node) == 8 && sizeof(fs_hex_run) == 16, "fused HE
 #define FS_HEX_MAX_PATCH_ELEMS 100
 #define FS_HEX_MAX_PATCH_NODES 64
 #define FS_HEX_MAX_PATCH_LANES 512
-#define FS_HEX_STAGE_DOUBLES 19300      /* FS_HEX_MAX_PATCH_ELEMS x 193: the gradient image the staging overlays */
+#define FS_HEX_STAGE_DOUBLES 19300      /* staging image of a patch's CSR slabs (overlays the gradient image, 19 600 doubles) */
 int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props, int64_t E,
                            int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
                            const fs_hex_node *nodes, const int64_t *pat_rptr, const fs_hex_run *runs,
