@@ -95,11 +95,15 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
         if (tid < nn) s_node[tid] = nodes[n0 + tid];
         if (tid >= 64 && tid - 64 < nr) s_run[tid - 64] = runs[r0 + tid - 64];     // (read after three barriers)
         // ---------------- phase 1: gradients of (slot, Gauss point) ----------------
-        for (int t = tid; t < ((ne + 7) & ~7) * 8; t += HX_NT) {
+        // at most FS_HEX_MAX_PATCH_ELEMS x 8 = 800 (slot, point) pairs: two passes of the workgroup, written out so that
+        // the element indices and coordinates of BOTH passes are requested before the first one computes (a loop exposes
+        // two dependent global round trips per pass)
+        static_assert(2 * HX_NT >= ((FS_HEX_MAX_PATCH_ELEMS + 7) & ~7) * 8, "two passes cover a patch");
+        const int q1 = (tid >> 3) & 7;                                // a wave: 8 slots (fastest) x 8 Gauss points
+        const int slotA = (tid >> 6) * 8 + (tid & 7), slotB = slotA + HX_NT / 8;
+        const int64_t eA = pat_elems[e0 + (slotA < ne ? slotA : ne - 1)], eB = pat_elems[e0 + (slotB < ne ? slotB : ne - 1)];
+        auto gradients = [&](int slot, int q, int64_t e) {
 #pragma clang fp contract(fast)
-            const int slot = (t >> 6) * 8 + (t & 7), q = (t >> 3) & 7;     // a wave: 8 slots (fastest) x 8 Gauss points
-            if (slot >= ne) continue;
-            const int64_t e = pat_elems[e0 + slot];
             const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp, zeta = (q & 4) ? gp : -gp;
             double N[8], dxi[8], deta[8], dzeta[8];
             solid_shape<8>(xi, eta, zeta, N, dxi, deta, dzeta);
@@ -138,7 +142,9 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                 gb[2 * i] = gr[2];
             }
             if (!UNI && q == 0) s_pid[slot] = safe_pid(prop_id[e], n_props);
-        }
+        };
+        if (slotA < ne) gradients(slotA, q1, eA);
+        if (slotB < ne) gradients(slotB, q1, eB);
         __syncthreads();
 
         // ---------------- phase 2: eight steps per lane ----------------
