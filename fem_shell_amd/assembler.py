@@ -438,7 +438,11 @@ class MeshAssembler:
             host_view = lambda: p if not on_device else SimpleNamespace(
                 d=p.d, n_nodes=p.n_nodes, nbr_ptr=p.nbr_ptr.cpu().numpy(), nbr=p.nbr.cpu().numpy())
             if self._family == ElementFamily.SOLID:
-                self._fplan = FusedHexPlan(host_view(), self._conn, self._coords)
+                from .fused import partition_nodes_hex_device
+                node_patch = None
+                if on_device:        # structured numbering: the node -> patch map on the device (None: NumPy partition)
+                    node_patch = partition_nodes_hex_device(int(self.mesh.node_count), self._groups[0]["conn_d"])
+                self._fplan = FusedHexPlan(host_view(), self._conn, self._coords, node_patch=node_patch)
                 self._fused_flags = 0
             else:
                 g = self._groups[0]

@@ -430,6 +430,59 @@ def partition_nodes_hex(coords, conn, max_elems=100, max_nodes=48, max_lanes=512
     raise RuntimeError("partition_nodes_hex did not converge")
 
 
+def partition_nodes_hex_device(n_nodes, conn_d, max_elems=100, max_nodes=48, max_lanes=512):
+    """partition_nodes_hex for brick meshes numbered like a structured block (node index = (k * Nj + j) * Ni + i: the
+    element edges join indices that differ by 1, Ni and Ni * Nj, whatever the geometry), on the device (torch integer
+    plumbing): cells of HEX_CELL nodes on the (i, j, k) lattice, patch ids in grid order.  Exactly 4 x 4 x 3 nodes per
+    interior patch (the coordinate bins of the NumPy version catch a fifth node now and then on jittered meshes and are
+    bisected: 45 nodes per patch on configs[4]'s block).  Returns the int64 [N] map as a HOST array, or None when the
+    mesh is not numbered that way or a patch would exceed a limit (the NumPy version then takes over)."""
+    import torch
+    conn = conn_d.to(torch.int64)
+    E, N = int(conn.shape[0]), int(n_nodes)
+    if E < 8 or conn.shape[1] != 8:
+        return None
+    c0 = conn[:, 0]
+    d = torch.stack([(conn[:, 1] - c0).abs(), (conn[:, 3] - c0).abs(), (conn[:, 4] - c0).abs()], dim=1)
+    d, _ = torch.sort(d, dim=1)
+
+    def mode(v):
+        vals, cnts = torch.unique(v, return_counts=True)
+        return int(vals[int(torch.argmax(cnts))])
+    L1, L2 = mode(d[:, 1]), mode(d[:, 2])
+    if L1 < 2 or L2 < 2 * L1 or L2 % L1:
+        return None
+    # all 12 edges of an element: 4 along each lattice direction
+    ea = torch.tensor([0, 3, 4, 7, 0, 1, 4, 5, 0, 1, 2, 3], device=conn.device)
+    eb = torch.tensor([1, 2, 5, 6, 3, 2, 7, 6, 4, 5, 6, 7], device=conn.device)
+    de, _ = torch.sort((conn[:, eb] - conn[:, ea]).abs(), dim=1)
+    want = torch.tensor([1] * 4 + [L1] * 4 + [L2] * 4, device=conn.device)
+    if float((de == want).all(dim=1).double().mean()) < 0.9:
+        return None
+    used = torch.zeros(N, dtype=torch.bool, device=conn.device)
+    used[conn.reshape(-1)] = True
+    idx = torch.arange(N, dtype=torch.int64, device=conn.device)
+    lat = (idx % L1, (idx // L1) % (L2 // L1), idx // L2)
+    key, mult = torch.zeros_like(idx), 1
+    for ax in range(3):
+        lo = int(lat[ax][used].min())
+        b = torch.where(used, (lat[ax] - lo) // HEX_CELL[ax], torch.zeros_like(idx))
+        key = key + b * mult
+        mult *= int(b.max()) + 1
+    _, patch = torch.unique(key, return_inverse=True)
+    npat = int(patch.max()) + 1
+    pc, _ = torch.sort(patch[conn], dim=1)
+    first = torch.ones_like(pc, dtype=torch.bool)
+    first[:, 1:] = pc[:, 1:] != pc[:, :-1]
+    cnt = torch.bincount(pc[first], minlength=npat)
+    nn = torch.bincount(patch[used], minlength=npat)
+    valence = torch.bincount(conn.reshape(-1), minlength=N)
+    lanes = torch.bincount(patch[used], weights=torch.ceil(valence[used].clamp(min=1).double() * 1.125), minlength=npat)
+    if int(cnt.max()) > max_elems or int(nn.max()) > max_nodes or float(lanes.max()) > max_lanes:
+        return None
+    return patch.cpu().numpy()
+
+
 class FusedHexPlan:
     """Host arrays of fs_fused_assemble_hex8's plan (layout: include/femshell_hip.h), built by the native
     fs_fused_hex_plan_build (csrc/femshell_fused_plan.cpp)."""

@@ -139,3 +139,27 @@ def test_hex_plan_check_rejects_malformed_plans():
     rc, msg = check(steps=st); assert rc == -22 and "rank" in msg
     lp = fp.pat_lptr.copy(); lp[1:] += 1
     assert check(pat_lptr=lp)[0] == -22
+
+
+def test_device_hex_partition_on_structured_and_renumbered_blocks(oracle):
+    """fused.partition_nodes_hex_device: 4 x 4 x 3-node cells on the lattice of the node numbering (whatever the
+    jitter), within the plan's limits; None for a renumbered mesh (the coordinate partition takes over); the matrix
+    does not depend on the partition beyond rounding."""
+    from fem_shell_amd import fused
+    dev = torch.device("cuda", 0)
+    coords, conn = brick_block(13, 9, 7, jitter=0.25)
+    p = fused.partition_nodes_hex_device(coords.shape[0], torch.from_numpy(conn).to(dev))
+    assert p is not None and p.dtype == np.int64 and p.shape == (coords.shape[0],)
+    assert np.bincount(p).max() == 48                                          # 4 x 4 x 3 nodes, whatever the jitter
+    touched = {(int(q), e) for e in range(conn.shape[0]) for q in p[conn[e]]}
+    assert np.bincount([q for q, _ in touched]).max() <= 100
+    perm = np.random.default_rng(3).permutation(coords.shape[0])
+    assert fused.partition_nodes_hex_device(coords.shape[0], torch.from_numpy(perm[conn]).to(dev)) is None
+    asm = _asm(coords, conn)
+    K = asm.assemble_stiffness_matrix(recompute=True)
+    assert asm._fplan is not None and asm._fplan.nodes.shape[0] / asm._fplan.n_patches > 30
+    plan_np = fused.FusedHexPlan(asm._plan.host() if hasattr(asm._plan, "host") else asm._plan, conn, coords)   # NumPy partition
+    ref = asm.assemble_stiffness_matrix(recompute=True, fused=False)
+    scale = float(ref.data.abs().max())
+    assert float((K.data - ref.data).abs().max()) <= 1e-13 * scale
+    assert plan_np.n_patches >= asm._fplan.n_patches
