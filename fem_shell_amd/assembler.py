@@ -273,7 +273,7 @@ class MeshAssembler:
         self._desc_d = self._plan_d["desc"]
         # K of every element now (this is also the geometry check of the reference's constructor loop); M on first use
         # (assemble_mass_matrix / _me_array): the reference evaluates both up front, here that would only cost memory
-        if self._cache_blocks or not (self.can_fuse and fam == ElementFamily.SHELL):
+        if self._cache_blocks or not (self.can_fuse and fam == ElementFamily.SHELL and g0["nn"] == 4):
             self.refresh_element_matrices(want_K=True, want_M=False)
         else:
             self._status = [self._geometry_status()]
@@ -419,12 +419,13 @@ class MeshAssembler:
     # ------------------------------------------------------------------ fused evaluate-and-assemble
     @property
     def can_fuse(self):
-        """The fused kernels cover uniform MITC4+ meshes (one quad group, 6 dofs per node) and uniform HEXA8 meshes with
-        the full 2 x 2 x 2 rule (3 dofs per node) whose patch plan can be built (see fused_ready)."""
+        """The fused kernels cover uniform MITC4+ meshes (one quad group, 6 dofs per node), uniform MITC3+ meshes and
+        uniform HEXA8 meshes with the full 2 x 2 x 2 rule (3 dofs per node) whose patch plan can be built (see
+        fused_ready)."""
         if self._fplan_error is not None or len(self._groups) != 1 or self._groups[0]["pos"] is not None:
             return False
         if self._family == ElementFamily.SHELL:
-            return self._groups[0]["nn"] == 4
+            return self._groups[0]["nn"] in (3, 4)                     # fs_fused_assemble_tri / fs_fused_assemble_quad
         return self._groups[0]["nn"] == 8 and not self._reduced      # HEXA8, full rule: fs_fused_assemble_hex8
 
     def fused_plan(self):
@@ -443,6 +444,10 @@ class MeshAssembler:
                 if on_device:        # structured numbering: the node -> patch map on the device (None: NumPy partition)
                     node_patch = partition_nodes_hex_device(int(self.mesh.node_count), self._groups[0]["conn_d"])
                 self._fplan = FusedHexPlan(host_view(), self._conn, self._coords, node_patch=node_patch)
+                self._fused_flags = 0
+            elif self._groups[0]["nn"] == 3:
+                from .fused import FusedTriPlan
+                self._fplan = FusedTriPlan(host_view(), self._conn, self._coords)
                 self._fused_flags = 0
             else:
                 g = self._groups[0]
@@ -510,6 +515,16 @@ class MeshAssembler:
                                                   _lib.ptr(d["steps"]), _lib.ptr(data), _lib.ptr(status), _lib.stream_ptr()),
                        "fs_fused_assemble_hex8")
             return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
+        if g["nn"] == 3:
+            # MITC3.K / MITC3Composite.K of every element (elements/MITC3.py:935-1103) and the ADD_VALUES loop
+            if mass:
+                raise NotImplementedError("the fused MITC3+ kernel forms K (the mass matrix keeps the two-kernel route)")
+            _lib.check(lib.fs_fused_assemble_tri(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+                                                 len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
+                                                 _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_nptr"]), _lib.ptr(d["nodes"]),
+                                                 _lib.ptr(d["pat_lptr"]), _lib.ptr(d["steps"]), _lib.ptr(data),
+                                                 _lib.ptr(status), _lib.stream_ptr()), "fs_fused_assemble_tri")
+            return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
         _lib.check(lib.fs_fused_assemble_quad(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
                                               len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
                                               _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]),
@@ -543,7 +558,8 @@ class MeshAssembler:
         mass matrices in memory; `_me_array` still materialises them on demand); fused=False forces element kernel +
         assembly kernel (same bits)."""
         fused = self.use_fused if fused is None else fused
-        if (recompute or self._M_blk is None) and fused and self._family == ElementFamily.SHELL and self.fused_ready():
+        if ((recompute or self._M_blk is None) and fused and self._family == ElementFamily.SHELL
+                and self._groups[0]["nn"] == 4 and self.fused_ready()):
             return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True, check=False)

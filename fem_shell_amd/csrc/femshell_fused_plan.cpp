@@ -610,3 +610,201 @@ int fs_fused_hex_plan_export(const fs_fused_hex_plan *plan, int64_t *pat_eptr, i
 void fs_fused_hex_plan_free(fs_fused_hex_plan *plan) { delete plan; }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Plan of fs_fused_assemble_tri (include/femshell_hip.h, "Fused evaluate-and-assemble, MITC3+"): the step layout of the
+// HEXA8 plan with 6 x 6 blocks that leave from registers -- no staging image, no copy-out runs; a node record names where
+// the node's CSR slab begins.  Interior node of a structured triangulation: 6 | 2 x 6 contributions = 3 lanes of 6 steps.
+// ------------------------------------------------------------------------------------------------------------------
+struct fs_fused_tri_plan {
+    std::vector<int64_t> pat_eptr, pat_nptr, pat_lptr;
+    std::vector<int32_t> pat_elems;
+    std::vector<fs_tri_node> nodes;
+    std::vector<uint32_t> steps;      // [lanes][8]
+    int64_t n_evals = 0;
+};
+
+namespace {
+
+struct TriBlock { int q; int rank; int n; uint32_t ev[8]; };    // contributions slot | li << 8 | lj << 10 (li of I, lj of J)
+
+// returns 0 or a negative code (-1: a node pair shared by more than 8 elements, -2: element missing from the patch,
+// -6: limits of the step record exceeded)
+int tri_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, int nn, const int32_t *elems, int ne,
+                     std::vector<fs_tri_node> *out_nodes, std::vector<uint32_t> *out_steps, int64_t *n_lanes, int64_t *n_evals) {
+    if (nn > FS_TRI_MAX_PATCH_NODES || ne > FS_TRI_MAX_PATCH_ELEMS) return -6;
+    int64_t evals = 0;
+    std::vector<TriBlock> blocks;
+    for (int q = 0; q < nn; q++) {
+        const int64_t I = nodes[q];
+        const int64_t r0 = m.nbr_ptr[I], r1 = m.nbr_ptr[I + 1];
+        const int mI = (int)(r1 - r0);
+        if (mI > 128) return -6;
+        const int32_t *eI = m.n2e.data() + m.n2e_ptr[I], *eIe = m.n2e.data() + m.n2e_ptr[I + 1];
+        for (int64_t b = r0; b < r1; b++) {
+            const int64_t J = m.nbr[b];
+            TriBlock tb;
+            tb.q = q;
+            tb.rank = (int)(b - r0);
+            tb.n = 0;
+            const int32_t *eJ = m.n2e.data() + m.n2e_ptr[J], *eJe = m.n2e.data() + m.n2e_ptr[J + 1];
+            const int32_t *a = eI, *c = eJ;
+            while (a != eIe && c != eJe) {
+                if (*a < *c) a++;
+                else if (*c < *a) c++;
+                else {
+                    const int32_t e = *a;
+                    const int64_t *cn = conn + (int64_t)e * 3;
+                    int li = -1, lj = -1;
+                    for (int k = 0; k < 3; k++) { if (cn[k] == I && li < 0) li = k; if (cn[k] == J && lj < 0) lj = k; }
+                    const int64_t slot = find_sorted(elems, elems + ne, e);
+                    if (slot < 0) return -2;
+                    if (tb.n >= 8) return -1;
+                    tb.ev[tb.n++] = (uint32_t)slot | ((uint32_t)li << 8) | ((uint32_t)lj << 10);
+                    a++; c++;
+                }
+            }
+            evals += tb.n;
+            blocks.push_back(tb);
+        }
+        if (out_nodes) out_nodes->push_back(fs_tri_node{36 * r0, (int32_t)mI, 0});
+    }
+    // The blocks of the whole patch, first fit by decreasing contribution count (stable: node order survives inside a
+    // class, so neighbouring lanes store neighbouring blocks).  A block takes max(n, 1) steps (a pattern-only block
+    // flushes its zeros); lanes are filled to SIX steps -- 6 | 2 + 2 + 2 on a structured triangulation: every lane full,
+    // all four waves of the workgroup busy -- and only a block of 7 or 8 contributions uses the last two.
+    std::vector<int> ord(blocks.size());
+    for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return blocks[x].n > blocks[y].n; });
+    std::vector<int> fill;
+    size_t first_open = 0;                               // lanes before it are full
+    for (int bi : ord) {
+        const TriBlock &tb = blocks[bi];
+        const int need = tb.n > 0 ? tb.n : 1;
+        const int cap = need > 6 ? 8 : 6;
+        size_t l = first_open;
+        while (l < fill.size() && fill[l] + need > cap) l++;
+        if (l == fill.size()) {
+            fill.push_back(0);
+            if (out_steps) out_steps->resize(fill.size() * 8, 0u);
+        }
+        if (out_steps) {
+            uint32_t *st = out_steps->data() + l * 8 + fill[l];
+            for (int c = 0; c < need; c++) {
+                uint32_t r = c < tb.n ? (tb.ev[c] | (1u << 13)) : 0u;
+                if (c == need - 1) r |= (1u << 14) | ((uint32_t)tb.q << 15) | ((uint32_t)tb.rank << 22);
+                st[c] = r;
+            }
+        }
+        fill[l] += need;
+        while (first_open < fill.size() && fill[first_open] >= 6) first_open++;
+    }
+    *n_lanes = ((int64_t)fill.size() + 63) / 64 * 64;
+    if (out_steps) out_steps->resize((size_t)*n_lanes * 8, 0u);
+    *n_evals = evals;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_fused_tri_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                            const int64_t *node_patch, fs_fused_tri_plan **plan, int64_t *n_patches, int64_t *n_elem_slots,
+                            int64_t *n_pat_nodes, int64_t *n_lanes) {
+    if (!conn || !nbr_ptr || !nbr || !node_patch || !plan || !n_patches || !n_elem_slots || !n_pat_nodes || !n_lanes)
+        return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_build: null argument", 0);
+    if (E < 0 || n_nodes <= 0 || E > INT32_MAX) return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_build: bad sizes", 0);
+    for (int64_t i = 0; i < E * 3; i++)
+        if (conn[i] < 0 || conn[i] >= n_nodes) return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_build: connectivity out of range", 0);
+    fs_fused_tri_plan *P = new (std::nothrow) fs_fused_tri_plan;
+    if (!P) return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_build: out of memory", 0);
+    try {
+        Mesh m{conn, E, n_nodes, nbr_ptr, nbr, {}, {}};
+        build_node_to_elements(conn, E, 3, n_nodes, m.n2e_ptr, m.n2e);
+        if (m.n2e_ptr[n_nodes] != E * 3) {
+            delete P;
+            return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_build: an element lists a node twice", 0);
+        }
+        std::vector<int64_t> order, pstart;
+        nodes_by_patch(n_nodes, nbr_ptr, node_patch, order, pstart);
+        const int64_t np = (int64_t)pstart.size() - 1;
+        std::vector<int64_t> ne(np, 0), nl(np, 0), nev(np, 0);
+        std::vector<std::vector<int32_t>> els(np);
+        std::vector<std::vector<fs_tri_node>> pnodes(np);
+        std::vector<std::vector<uint32_t>> steps(np);
+        int err = 0;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t p = 0; p < np; p++) {
+            const int64_t *nodes = order.data() + pstart[p];
+            const int nn = (int)(pstart[p + 1] - pstart[p]);
+            std::vector<int32_t> &el = els[p];
+            for (int q = 0; q < nn; q++)
+                el.insert(el.end(), m.n2e.begin() + m.n2e_ptr[nodes[q]], m.n2e.begin() + m.n2e_ptr[nodes[q] + 1]);
+            std::sort(el.begin(), el.end());
+            el.erase(std::unique(el.begin(), el.end()), el.end());
+            ne[p] = (int64_t)el.size();
+            int rc = 0;
+            if ((int64_t)el.size() > FS_TRI_MAX_PATCH_ELEMS) rc = -4;
+            else rc = tri_patch_layout(m, conn, nodes, nn, el.data(), (int)el.size(), &pnodes[p], &steps[p], &nl[p], &nev[p]);
+            if (!rc && nl[p] > FS_TRI_MAX_PATCH_LANES) rc = -7;
+            if (rc) {
+#pragma omp atomic write
+                err = rc;
+            }
+        }
+        if (err) {
+            delete P;
+            const char *msg = err == -4 ? "fs_fused_tri_plan_build: a patch touches more than FS_TRI_MAX_PATCH_ELEMS elements"
+                            : err == -1 ? "fs_fused_tri_plan_build: a node pair is shared by more than 8 elements"
+                            : err == -7 ? "fs_fused_tri_plan_build: a patch needs more than FS_TRI_MAX_PATCH_LANES lanes"
+                            : err == -6 ? "fs_fused_tri_plan_build: too many nodes in a patch or more than 128 neighbours of a node"
+                                        : "fs_fused_tri_plan_build: inconsistent connectivity";
+            return fs_fail_(FS_EINVAL, msg, 0);
+        }
+        P->pat_eptr.assign(np + 1, 0); P->pat_nptr.assign(np + 1, 0); P->pat_lptr.assign(np + 1, 0);
+        for (int64_t p = 0; p < np; p++) {
+            P->pat_eptr[p + 1] = P->pat_eptr[p] + ne[p];
+            P->pat_nptr[p + 1] = P->pat_nptr[p] + (int64_t)pnodes[p].size();
+            P->pat_lptr[p + 1] = P->pat_lptr[p] + nl[p];
+            P->n_evals += nev[p];
+        }
+        P->pat_elems.resize(P->pat_eptr[np]);
+        P->nodes.resize(P->pat_nptr[np]);
+        P->steps.resize((size_t)P->pat_lptr[np] * 8);
+#pragma omp parallel for schedule(static)
+        for (int64_t p = 0; p < np; p++) {
+            std::copy(els[p].begin(), els[p].end(), P->pat_elems.begin() + P->pat_eptr[p]);
+            std::copy(pnodes[p].begin(), pnodes[p].end(), P->nodes.begin() + P->pat_nptr[p]);
+            std::copy(steps[p].begin(), steps[p].end(), P->steps.begin() + (size_t)P->pat_lptr[p] * 8);
+        }
+        *plan = P;
+        *n_patches = np;
+        *n_elem_slots = P->pat_eptr[np];
+        *n_pat_nodes = P->pat_nptr[np];
+        *n_lanes = P->pat_lptr[np];
+        return FS_OK;
+    } catch (const std::bad_alloc &) {
+        delete P;
+        return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_build: out of memory", 0);
+    }
+}
+
+int fs_fused_tri_plan_export(const fs_fused_tri_plan *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_nptr,
+                             fs_tri_node *nodes, int64_t *pat_lptr, uint32_t *steps, int64_t *n_evals) {
+    if (!plan || !pat_eptr || !pat_elems || !pat_nptr || !nodes || !pat_lptr || !steps)
+        return fs_fail_(FS_EINVAL, "fs_fused_tri_plan_export: null argument", 0);
+    std::copy(plan->pat_eptr.begin(), plan->pat_eptr.end(), pat_eptr);
+    std::copy(plan->pat_nptr.begin(), plan->pat_nptr.end(), pat_nptr);
+    std::copy(plan->pat_lptr.begin(), plan->pat_lptr.end(), pat_lptr);
+    std::copy(plan->pat_elems.begin(), plan->pat_elems.end(), pat_elems);
+    std::copy(plan->nodes.begin(), plan->nodes.end(), nodes);
+    std::copy(plan->steps.begin(), plan->steps.end(), steps);
+    if (n_evals) *n_evals = plan->n_evals;
+    return FS_OK;
+}
+
+void fs_fused_tri_plan_free(fs_fused_tri_plan *plan) { delete plan; }
+
+}  // extern "C"

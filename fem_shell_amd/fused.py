@@ -355,6 +355,29 @@ HEX_CELL = (4, 4, 3)       # nodes per patch along the numbering direction, the 
                            # 5 x 5 x 4 = 100 elements (FS_HEX_MAX_PATCH_ELEMS: the LDS image of one workgroup)
 
 
+def _bisect_patches(patch, coords, hk, used, bad, npat):
+    """One round of median bisection, in place: every patch flagged in `bad` is cut in two along its longest extent
+    (measured in node spacings hk); the upper halves get new ids npat, npat + 1, ..."""
+    nodes = np.flatnonzero(bad[patch] & used)
+    pb = patch[nodes]
+    o = np.argsort(pb, kind="stable")
+    nodes, pb = nodes[o], pb[o]
+    starts = np.flatnonzero(np.r_[True, pb[1:] != pb[:-1]])
+    seg = np.cumsum(np.r_[False, pb[1:] != pb[:-1]])
+    size = np.diff(np.r_[starts, pb.shape[0]])
+    c = coords[nodes]
+    ext = (np.maximum.reduceat(c, starts, axis=0) - np.minimum.reduceat(c, starts, axis=0)) / hk
+    axis = np.argmax(ext, axis=1)
+    val = c[np.arange(c.shape[0]), axis[seg]]
+    o2 = np.lexsort((val, seg))
+    rank = np.empty(o2.shape[0], dtype=np.int64)
+    rank[o2] = np.arange(o2.shape[0]) - starts[seg[o2]]
+    upper = rank >= (size[seg] + 1) // 2
+    if (size < 2).any():
+        raise ValueError("a single node touches more elements than one patch may hold")
+    patch[nodes[upper]] = npat + seg[upper]
+
+
 def partition_nodes_hex(coords, conn, max_elems=100, max_nodes=48, max_lanes=512):
     """node -> patch id for the fused HEXA8 kernel: bins of HEX_CELL nodes on the coordinates (spacing = mean element
     extent per axis; the axis along which consecutive node indices run is the fastest one, so the CSR slabs of a patch
@@ -409,24 +432,7 @@ def partition_nodes_hex(coords, conn, max_elems=100, max_nodes=48, max_lanes=512
         bad = (cnt > max_elems) | (nn > max_nodes) | (lanes > max_lanes)
         if not bad.any():
             return patch
-        nodes = np.flatnonzero(bad[patch] & used)
-        pb = patch[nodes]
-        o = np.argsort(pb, kind="stable")
-        nodes, pb = nodes[o], pb[o]
-        starts = np.flatnonzero(np.r_[True, pb[1:] != pb[:-1]])
-        seg = np.cumsum(np.r_[False, pb[1:] != pb[:-1]])
-        size = np.diff(np.r_[starts, pb.shape[0]])
-        c = coords[nodes]
-        ext = (np.maximum.reduceat(c, starts, axis=0) - np.minimum.reduceat(c, starts, axis=0)) / hk
-        axis = np.argmax(ext, axis=1)
-        val = c[np.arange(c.shape[0]), axis[seg]]
-        o2 = np.lexsort((val, seg))
-        rank = np.empty(o2.shape[0], dtype=np.int64)
-        rank[o2] = np.arange(o2.shape[0]) - starts[seg[o2]]
-        upper = rank >= (size[seg] + 1) // 2
-        if (size < 2).any():
-            raise ValueError("a single node touches more elements than one patch may hold")
-        patch[nodes[upper]] = npat + seg[upper]
+        _bisect_patches(patch, coords, hk, used, bad, npat)
     raise RuntimeError("partition_nodes_hex did not converge")
 
 
@@ -538,3 +544,138 @@ class FusedHexPlan:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(device)
         return {k: t(getattr(self, k)) for k in ("pat_eptr", "pat_elems", "pat_nptr", "nodes", "pat_rptr", "runs",
                                                  "pat_lptr", "steps")}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MITC3+ (fs_fused_assemble_tri)
+# ---------------------------------------------------------------------------------------------------------------------
+TRI_NODE_DTYPE = np.dtype([("gbase", "i8"), ("m", "i4"), ("pad", "i4")])
+TRI_CELL = (7, 10)         # nodes per patch along the numbering direction and across it: 70 nodes touch 2 x 8 x 11 = 176
+                           # triangles of a structured triangulation (FS_TRI_MAX_PATCH_ELEMS: the LDS image of a workgroup)
+
+
+def _tri_lattice(conn, N):
+    """(i, j) lattice indices of the nodes when the triangles are the halves of a structured grid's cells (node index =
+    j * L + i: the edges of a triangle join indices that differ by 1, L and L +- 1), else None."""
+    if conn.shape[0] < 4:
+        return None
+    c0, c1, c2 = conn[:, 0], conn[:, 1], conn[:, 2]
+    d = np.sort(np.abs(np.stack([c1 - c0, c2 - c1, c2 - c0], axis=1)), axis=1)
+
+    def mode(v):
+        vals, cnts = np.unique(v, return_counts=True)
+        return int(vals[np.argmax(cnts)])
+    a, b = mode(d[:, 1]), mode(d[:, 2])
+    if mode(d[:, 0]) != 1 or b != a + 1 or a < 2:
+        return None
+    if ((d[:, 0] == 1) & (d[:, 1] == a) & (d[:, 2] == b)).mean() < 0.9:
+        return None
+    cand = [L for L in (a, b) if N % L == 0]
+    if len(cand) != 1:
+        return None                      # diagonal direction not decidable from the indices alone
+    L = cand[0]
+    idx = np.arange(N, dtype=np.int64)
+    return np.stack([idx % L, idx // L], axis=1).astype(np.float64)
+
+
+def partition_nodes_tri(coords, conn, max_elems=176, max_nodes=96, max_lanes=256):
+    """node -> patch id for the fused MITC3+ kernel: cells of TRI_CELL nodes on the lattice of the node numbering when the
+    mesh is a triangulated structured grid (curved shells included), else on the coordinates (node spacing = median
+    edge length per axis), then median bisection of the patches beyond a limit (elements touched, nodes, lanes: 3 lanes
+    of 8 steps per interior node -- 6 + 6 x 2 contributions)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    conn = np.asarray(conn, dtype=np.int64)
+    N, E = coords.shape[0], conn.shape[0]
+    if E == 0:
+        return np.zeros(N, dtype=np.int64)
+    used = np.zeros(N, dtype=bool)
+    used[conn.reshape(-1)] = True
+    lat = _tri_lattice(conn, N)
+    if lat is not None:
+        coords, hk, ax = lat, np.ones(2), 0
+    else:
+        x = coords[conn]
+        edges = np.abs(np.concatenate([x[:, 1] - x[:, 0], x[:, 2] - x[:, 1], x[:, 0] - x[:, 2]]))
+        hk = np.maximum(edges.mean(axis=0), 1e-300)
+        hk = np.maximum(hk, 1e-3 * float(hk.max()))
+        ax = _numbering_axis(coords, used)
+    nd = coords.shape[1]
+    cell = np.full(nd, float(TRI_CELL[1]))
+    cell[ax] = float(TRI_CELL[0])
+    if nd == 3:
+        cell[:] = 8.0          # a surface in space: cubes of 8 spacings (~64 nodes), cut by the bisection pass where needed
+    side = cell * hk
+    lo = coords[used].min(axis=0) - 0.5 * hk
+    cc = np.where(used[:, None], coords, lo)
+    b = np.clip(np.floor((cc - lo) / side).astype(np.int64), 0, None)
+    nb = b[used].max(axis=0) + 1
+    b = np.minimum(b, nb - 1)
+    key = np.zeros(N, dtype=np.int64)
+    for k in reversed([ax] + [k for k in range(nd) if k != ax]):
+        key = key * nb[k] + b[:, k]
+    _, patch = np.unique(key, return_inverse=True)
+    patch = patch.astype(np.int64)
+    valence = np.bincount(conn.reshape(-1), minlength=N)
+    for _ in range(64):
+        npat = int(patch.max()) + 1
+        cnt = _elements_per_patch(patch, conn, npat)
+        nn = np.bincount(patch[used], minlength=npat)
+        lanes = np.bincount(patch[used], weights=np.ceil(np.maximum(valence[used], 1) * 0.375 + 0.75), minlength=npat)
+        bad = (cnt > max_elems) | (nn > max_nodes) | (lanes > max_lanes)
+        if not bad.any():
+            return patch
+        _bisect_patches(patch, coords, hk, used, bad, npat)
+    raise RuntimeError("partition_nodes_tri did not converge")
+
+
+class FusedTriPlan:
+    """Host arrays of fs_fused_assemble_tri's plan (layout: include/femshell_hip.h), built by the native
+    fs_fused_tri_plan_build (csrc/femshell_fused_plan.cpp)."""
+
+    def __init__(self, plan, conn, coords, node_patch=None):
+        import ctypes
+        from . import _lib
+        conn = np.ascontiguousarray(conn, dtype=np.int64)
+        if plan.d != 6 or conn.ndim != 2 or conn.shape[1] != 3:
+            raise ValueError("the fused MITC3+ kernel is built for uniform 3-node shell meshes (6 dofs per node)")
+        self.E = int(conn.shape[0])
+        if node_patch is None:
+            node_patch = partition_nodes_tri(coords, conn)
+        node_patch = np.ascontiguousarray(node_patch, dtype=np.int64)
+        nbr_ptr = np.ascontiguousarray(plan.nbr_ptr, dtype=np.int64)
+        nbr = np.ascontiguousarray(plan.nbr, dtype=np.int32)
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        c = [ctypes.c_int64() for _ in range(4)]
+        _lib.check(lib.fs_fused_tri_plan_build(conn.ctypes.data, self.E, int(plan.n_nodes), nbr_ptr.ctypes.data, nbr.ctypes.data,
+                                               node_patch.ctypes.data, ctypes.byref(h), *[ctypes.byref(v) for v in c]),
+                   "fs_fused_tri_plan_build")
+        try:
+            npat, nslots, nnodes, nlanes = (int(v.value) for v in c)
+            self.n_patches, self.n_elem_slots, self.n_lanes = npat, nslots, nlanes
+            self.pat_eptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_nptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_lptr = np.empty(npat + 1, dtype=np.int64)
+            self.pat_elems = np.empty(nslots, dtype=np.int32)
+            self.nodes = np.empty(nnodes, dtype=TRI_NODE_DTYPE)
+            self.steps = np.empty((nlanes, 8), dtype=np.uint32)
+            nev = ctypes.c_int64()
+            _lib.check(lib.fs_fused_tri_plan_export(h, self.pat_eptr.ctypes.data, self.pat_elems.ctypes.data,
+                                                    self.pat_nptr.ctypes.data, self.nodes.ctypes.data,
+                                                    self.pat_lptr.ctypes.data, self.steps.ctypes.data, ctypes.byref(nev)),
+                       "fs_fused_tri_plan_export")
+            self.n_evals = int(nev.value)
+        finally:
+            lib.fs_fused_tri_plan_free(h)
+
+    def stats(self):
+        return {"patches": self.n_patches, "elements_per_patch": self.n_elem_slots / max(self.n_patches, 1),
+                "stage1_recompute": self.n_elem_slots / max(self.E, 1),
+                "nodes_per_patch": self.nodes.shape[0] / max(self.n_patches, 1),
+                "step_fill": self.n_evals / max(self.steps.size, 1),
+                "record_bytes_per_element": (self.steps.nbytes + self.nodes.nbytes) / max(self.E, 1)}
+
+    def to_device(self, device):
+        import torch
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(device)
+        return {k: t(getattr(self, k)) for k in ("pat_eptr", "pat_elems", "pat_nptr", "nodes", "pat_lptr", "steps")}

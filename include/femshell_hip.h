@@ -510,6 +510,56 @@ int fs_fused_hex_plan_export(const fs_fused_hex_plan *plan, int64_t *pat_eptr, i
                              int64_t *n_evals);
 void fs_fused_hex_plan_free(fs_fused_hex_plan *plan);
 
+/*
+ * Fused evaluate-and-assemble, MITC3+ (3-node shells, 6 dofs per node): the CSR values of K straight from the coordinates,
+ * no element matrices in memory.  Replaces MITC3.K / MITC3Composite.K of every element (elements/MITC3.py:935-1103,
+ * MITC3_composite.py:204-240) TOGETHER with the setValuesLocal(ADD_VALUES) loop over them (core/assembler.py:287-303).
+ * Gather form over PATCHES of nodes in the step layout of fs_fused_assemble_hex8: a workgroup (256 lanes) evaluates, for
+ * every element touching its patch, frame, area and the shape / tying data of the three nodal functions and the bubble
+ * at the 3 Hammer points into LDS, then forms the COMPLETE 6-row CSR slabs of the patch's nodes.  A lane works through
+ * eight steps, one contribution (element, local node pair) each: the 6 x 6 block of the ordered local pair with the
+ * device function of the element kernel (fs_shell_tri_batch forms the same bits), transposed where the block is
+ * (larger, smaller); the contributions of a CSR block follow each other on one lane and are added in ELEMENT ORDER,
+ * 0 + x0 + x1 + ... (the reference's insertion order); finished blocks leave from registers as 16-byte stores.
+ *   xyz [E][3][3], prop_id [E], props / n_props as for fs_shell_tri_batch
+ *   pat_eptr / pat_elems   elements of each patch (ascending; position = LDS slot), <= FS_TRI_MAX_PATCH_ELEMS per patch
+ *   pat_nptr / nodes       per patch node (ascending node index): gbase = offset of entry (0, 0) of its first block in
+ *                          `data` (36 x the node's first block index) and its number of neighbours m (row stride 6 m)
+ *   pat_lptr / steps       lanes of each patch (multiples of 64, <= FS_TRI_MAX_PATCH_LANES), 8 step words per lane:
+ *                          slot | li << 8 | lj << 10 | active << 13 | flush << 14 | node_local << 15 | rank << 22 --
+ *                          contribution of the element in `slot` to block (I, J), li / lj = local index of I / J in that
+ *                          element; `flush`: the block (node_local, rank-th neighbour) is complete after this step and is
+ *                          stored (a pattern-only block is one idle step that flushes zeros)
+ *   status [E] FS_ST_* bits (frame / area checks of the element kernel, FS_ST_BAD_PROP) or NULL
+ * No counterpart in the reference beyond the lines above.
+ */
+typedef struct fs_tri_node { int64_t gbase; int32_t m; int32_t pad; } fs_tri_node;       /* 16 bytes */
+FS_STATIC_ASSERT(sizeof(fs_tri_node) == 16, "fused MITC3+ plan records");
+#define FS_TRI_MAX_PATCH_ELEMS 176
+#define FS_TRI_MAX_PATCH_NODES 96
+#define FS_TRI_MAX_PATCH_LANES 256
+int fs_fused_assemble_tri(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props, int64_t E,
+                          int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
+                          const fs_tri_node *nodes, const int64_t *pat_lptr, const uint32_t *steps, double *data,
+                          int32_t *status, void *stream);
+/* The kernel trusts its plan; a plan that does not come from fs_fused_tri_plan_build must pass this check once before its
+ * first launch (device pointers; synchronises `stream`, allocates 24 bytes): FS_EINVAL (fs_last_error names the first
+ * violated rule) instead of a GPU fault. */
+int fs_fused_tri_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
+                            const fs_tri_node *nodes, const int64_t *pat_lptr, const uint32_t *steps, int64_t E, int64_t nnz,
+                            void *stream);
+/* Host-side plan builder (all pointers host memory; OpenMP over patches).  conn [E][3]; nbr_ptr / nbr: node graph of the
+ * CSR pattern (neighbours ascending); node_patch [n_nodes].  FS_EINVAL when a patch exceeds a limit above, when a node
+ * pair is shared by more than 8 elements (a node of valence > 8) or when an element lists a node twice -- callers then
+ * keep the two-kernel route. */
+typedef struct fs_fused_tri_plan fs_fused_tri_plan;
+int fs_fused_tri_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, const int64_t *nbr_ptr, const int32_t *nbr,
+                            const int64_t *node_patch, fs_fused_tri_plan **plan, int64_t *n_patches, int64_t *n_elem_slots,
+                            int64_t *n_pat_nodes, int64_t *n_lanes);
+int fs_fused_tri_plan_export(const fs_fused_tri_plan *plan, int64_t *pat_eptr, int32_t *pat_elems, int64_t *pat_nptr,
+                             fs_tri_node *nodes, int64_t *pat_lptr, uint32_t *steps, int64_t *n_evals);
+void fs_fused_tri_plan_free(fs_fused_tri_plan *plan);
+
 /* Symbolic companion of fs_csr_numeric_desc (pattern of core/assembler.py:222-241 for uniform-d
  * meshes): fills indptr[N*d+1] (int64) and indices[nnz] (int32) from the node graph:
  *   nbr_ptr [N+1] row pointer of the node graph (block rows), blk_row [nblk] node I and nbr [nblk] node J of
