@@ -8,7 +8,8 @@
 //   phase 1  lane = (element slot, function f = node 0..2 or bubble): triangle frame, area and the shape / tying data
 //            of f at the 3 Hammer points (tri_geometry, tri_fn: the device functions of mitc3_k_lds_kernel) into an LDS
 //            image fn[23][4 slots], geo[10][slots]; elements of the one-element halo are evaluated by every patch that
-//            touches them.
+//            touches them.  Three passes of the workgroup from registers: element indices, coordinates and property
+//            ids travel one patch ahead, under phase 2 of the previous patch.
 //   phase 2  the patch forms the COMPLETE 6-row CSR slabs of its nodes (7 blocks for an interior node of a structured
 //            triangulation).  A lane works through eight steps, one contribution (element slot, local node pair) each:
 //            the 6 x 6 block of the ordered local pair (tri_pair_block, shared with mitc3_k_lds_kernel: the same
@@ -42,6 +43,19 @@ constexpr int TR_NT = FS_TRI_MAX_PATCH_LANES;    // 256
 #define TR_NODE(r) ((int)(((r) >> 15) & 127u))
 #define TR_RANK(r) ((int)(((r) >> 22) & 127u))
 
+// the members of a property row that tri_pair_block reads
+struct TriProp { double A[9], B[9], D[9], Cs[4], k_drill; int32_t flags; };
+__device__ __forceinline__ void load_tri_prop(const fs_shell_prop *src, TriProp &o) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) { o.A[c] = src->A[c]; o.B[c] = src->B[c]; o.D[c] = src->D[c]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) o.Cs[c] = src->Cs[c];
+    o.k_drill = src->k_drill;
+    o.flags = src->flags;
+}
+
+// UNI: the model has ONE property row (every lane reads the same numbers: scalar registers, loaded once)
+template <bool UNI>
 __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restrict__ xyz, const int32_t *__restrict__ prop_id,
                                                          const fs_shell_prop *__restrict__ props, int32_t n_props, int64_t n_pat,
                                                          const int64_t *__restrict__ pat_eptr, const int32_t *__restrict__ pat_elems,
@@ -57,9 +71,37 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
     const int xcd = blockIdx.x & 7, wpx = (int)(gridDim.x >> 3);
     const int64_t per_xcd = (n_pat + 7) / 8;
     const int64_t pend = ((xcd + 1) * per_xcd < n_pat) ? (xcd + 1) * per_xcd : n_pat;
-    for (int64_t p = xcd * per_xcd + (blockIdx.x >> 3); p < pend; p += wpx) {
+    // The inputs of phase 1 travel ONE PATCH AHEAD: the element indices of the next patch are requested at the top of the
+    // current one, its coordinates and property ids after the phase-1 barrier, so that they arrive under phase 2 (one wave
+    // per SIMD: nothing else hides a global round trip, and a plain loop exposes six of them per patch).
+    const int64_t pfirst = xcd * per_xcd + (blockIdx.x >> 3);
+    TriProp Pu;
+    if (UNI) load_tri_prop(props, Pu);
+    static_assert(3 * TR_NT >= 4 * TR_S, "three passes of the workgroup cover the (slot, function) pairs of a patch");
+    int32_t el[3] = {0, 0, 0}, pidn[3] = {0, 0, 0};
+    double xs[3][9];
+    auto fetch_ids = [&](int64_t pp) {
+        const int64_t e1 = pat_eptr[pp];
+        const int ne1 = (int)(pat_eptr[pp + 1] - e1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int slot = (tid + k * TR_NT) >> 2;
+            el[k] = pat_elems[e1 + (slot < ne1 ? slot : ne1 - 1)];
+        }
+    };
+    auto fetch_inputs = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int c = 0; c < 9; c++) xs[k][c] = xyz[(int64_t)el[k] * 9 + c];
+            pidn[k] = prop_id[el[k]];
+        }
+    };
+    if (pfirst < pend) { fetch_ids(pfirst); fetch_inputs(); }
+    for (int64_t p = pfirst; p < pend; p += wpx) {
         const int64_t e0 = pat_eptr[p], n0 = pat_nptr[p], l0 = pat_lptr[p];
         const int ne = (int)(pat_eptr[p + 1] - e0), nn = (int)(pat_nptr[p + 1] - n0), nl = (int)(pat_lptr[p + 1] - l0);
+        (void)e0;
         // this lane's eight steps (used after phase 1: the loads travel under it)
         uint4 sa = make_uint4(0, 0, 0, 0), sb = sa;
         if (tid < nl) {
@@ -67,12 +109,16 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
             sa = sp[0]; sb = sp[1];
         }
         if (tid < nn) s_node[tid] = nodes[n0 + tid];
-        // ---------------- phase 1: (slot, function) ----------------
-        for (int t = tid; t < ne * 4; t += TR_NT) {
-            const int slot = t >> 2, f = t & 3;
-            const int64_t e = pat_elems[e0 + slot];
+        // ---------------- phase 1: (slot, function), three passes from registers ----------------
+        int32_t ecur[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ecur[k] = el[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int t = tid + k * TR_NT, slot = t >> 2, f = t & 3;
+            if (slot >= ne) continue;
             double x[3][3];
-            for (int c = 0; c < 9; c++) (&x[0][0])[c] = xyz[e * 9 + c];
+            for (int c = 0; c < 9; c++) (&x[0][0])[c] = xs[k][c];
             TriGeom geo;
             tri_geometry(x, geo);
             TriFn F;
@@ -90,33 +136,44 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
             s_fn[22 * TR_FS + t] = F.dhy;
             if (f == 0) {
                 s_geo[0 * TR_S + slot] = geo.area;
-                for (int k = 0; k < 3; k++) {
-                    s_geo[(1 + k) * TR_S + slot] = geo.e1[k];
-                    s_geo[(4 + k) * TR_S + slot] = geo.e2[k];
-                    s_geo[(7 + k) * TR_S + slot] = geo.e3[k];
+                for (int k2 = 0; k2 < 3; k2++) {
+                    s_geo[(1 + k2) * TR_S + slot] = geo.e1[k2];
+                    s_geo[(4 + k2) * TR_S + slot] = geo.e2[k2];
+                    s_geo[(7 + k2) * TR_S + slot] = geo.e3[k2];
                 }
-                const int32_t pid = prop_id[e];
+                const int32_t pid = pidn[k];
                 s_pid[slot] = safe_pid(pid, n_props);
                 // every patch that touches the element writes the same word
-                if (status) status[e] = geo.status | ((pid < 0 || pid >= n_props) ? FS_ST_BAD_PROP : 0);
+                if (status) status[ecur[k]] = geo.status | ((pid < 0 || pid >= n_props) ? FS_ST_BAD_PROP : 0);
             }
         }
+        if (p + wpx < pend) fetch_ids(p + wpx);
         __syncthreads();
+        if (p + wpx < pend) fetch_inputs();                  // arrive under phase 2
         // ---------------- phase 2: eight steps per lane ----------------
         double acc[6][6];
 #pragma unroll
         for (int a = 0; a < 36; a++) (&acc[0][0])[a] = 0.0;
-#pragma unroll 1
-        for (int s = 0; s < 8; s++) {
+        auto step_word = [&](int s) {
             const uint32_t lo = (s & 2) ? ((s & 1) ? sa.w : sa.z) : ((s & 1) ? sa.y : sa.x);
             const uint32_t hi = (s & 2) ? ((s & 1) ? sb.w : sb.z) : ((s & 1) ? sb.y : sb.x);
-            const uint32_t r = (s & 4) ? hi : lo;
+            return (s & 4) ? hi : lo;
+        };
+#pragma unroll 1
+        for (int s = 0; s < 8; s++) {
+            const uint32_t r = step_word(s);
             if (TR_ACTIVE(r)) {
                 const int li = TR_LI(r), lj = TR_LJ(r), slot = TR_SLOT(r);
                 const int ti = li < lj ? li : lj, tj = li < lj ? lj : li;
                 const bool tr = li > lj;
                 double G[6][6];
-                tri_pair_block<TR_FS, TR_S>(s_fn, s_geo, slot, ti, tj, props + s_pid[slot], G);
+                if (UNI) {
+                    tri_pair_block<TR_FS, TR_S>(s_fn, s_geo, slot, ti, tj, &Pu, G);
+                } else {
+                    TriProp pr;
+                    load_tri_prop(props + s_pid[slot], pr);
+                    tri_pair_block<TR_FS, TR_S>(s_fn, s_geo, slot, ti, tj, &pr, G);
+                }
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -210,8 +267,12 @@ extern "C" int fs_fused_assemble_tri(const double *xyz, const int32_t *prop_id, 
     if (wgs < 8) wgs = 8;
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(fused_tri_kernel, dim3((unsigned)wgs), dim3(TR_NT), 0, s, xyz, prop_id, props, n_props, n_patches,
-                       pat_eptr, pat_elems, pat_nptr, nodes, pat_lptr, steps, data, status);
+    if (n_props == 1)
+        hipLaunchKernelGGL(fused_tri_kernel<true>, dim3((unsigned)wgs), dim3(TR_NT), 0, s, xyz, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_lptr, steps, data, status);
+    else
+        hipLaunchKernelGGL(fused_tri_kernel<false>, dim3((unsigned)wgs), dim3(TR_NT), 0, s, xyz, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_lptr, steps, data, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_tri_kernel", (int)e);
     return FS_OK;

@@ -162,9 +162,10 @@ __device__ __forceinline__ double tri_dy(const TriG &F, const double *c5) {
 // the frame rows.  Gauss point by Gauss point (only one point's data is live), bubble condensation, membrane CST,
 // drilling, rotation to global axes; diagonal blocks symmetrised.  Shared by mitc3_k_lds_kernel and the fused kernel
 // (femshell_fused_tri.hip), so both form the same bits.
-template <int FS, int GS>
+// PROP: fs_shell_prop or any type with its members A, B, D, Cs, k_drill, flags (a register copy of the row).
+template <int FS, int GS, class PROP>
 __device__ __forceinline__ void tri_pair_block(const double *fn, const double *geo, int qq, int ti, int tj,
-                                               const fs_shell_prop *pr, double (&G)[6][6]) {
+                                               const PROP *pr, double (&G)[6][6]) {
 #pragma clang fp contract(fast)
     const int qi = qq * 4 + ti, qj = qq * 4 + tj, qb = qq * 4 + 3;
     const double area = geo[qq];
