@@ -271,8 +271,9 @@ def hex8_leg(torch, steps=5):
 
 
 def c2_leg(torch, steps=20):
-    """configs[1]: pinched hemisphere with an 18 degree cut-out, 256 x 256, MITC4+ (65 536 quads: the fused kernel) and
-    MITC3+ (131 072 triangles: element kernel + assembly kernel) on one GPU."""
+    """configs[1]: pinched hemisphere with an 18 degree cut-out, 256 x 256, MITC4+ (65 536 quads: the fused quad kernel)
+    and MITC3+ (131 072 triangles: the fused MITC3+ kernel, element kernel + assembly kernel beside it) on one GPU
+    (SURVEY.md 8d C2)."""
     import fem_shell_amd as fsa
     from fem_shell_amd import meshes
     from fem_shell_amd.assembler import MeshAssembler
@@ -287,6 +288,15 @@ def c2_leg(torch, steps=20):
         ms = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=True), steps)
         out[tag] = {"elements": E, "nnz": int(K.nnz), "ms_per_step": ms, "elements_per_s": E / (ms * 1e-3)}
         if tri:
+            # the step is the fused MITC3+ kernel (one launch); the two-kernel route it replaced, for comparison
+            fb = 72 + 4 + 4 + 8 * int(K.nnz) / E          # coordinates, property id, status in; CSR values out
+            out[tag]["fused"] = asm.fused_ready()
+            out[tag]["fused_plan"] = {k: asm.fused_plan().stats()[k] for k in ("patches", "stage1_recompute", "step_fill")}
+            out[tag]["roofline"] = {"kernel": "fused_tri_kernel", "kernel_ms": ms, "bound": "hbm",
+                                    "achieved": E * fb / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": E * fb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_element": fb,
+                                    "note": "962 patches on 256 CUs: launch latency and the tail weigh in at this size"}
+            out[tag]["two_kernel_ms_per_step"] = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=True, fused=False), steps)
             k_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=True, want_M=False, check=False), steps)
             kb = 72 + 4 + 4 + 6 * 288          # 3 nodes in, 6 upper node-pair blocks out
             out[tag]["kernels"] = {"mitc3_k_lds_kernel": {
