@@ -295,7 +295,10 @@ class FusedQuadPlanDevice:
         conn_d = conn_d.contiguous()
         node_patch_d = node_patch_d.to(device=dev, dtype=torch.int64).contiguous()
         nbr_ptr, nbr = plan.nbr_ptr.contiguous(), plan.nbr.contiguous()
-        assert nbr_ptr.dtype == torch.int64 and nbr.dtype == torch.int32
+        if nbr_ptr.dtype != torch.int64 or nbr.dtype != torch.int32 or nbr_ptr.numel() != int(plan.n_nodes) + 1:
+            raise ValueError("the device plan builder needs the node graph of a DeviceBlockPlan (int64 nbr_ptr, int32 nbr)")
+        if node_patch_d.numel() != int(plan.n_nodes):
+            raise ValueError("node_patch must hold one patch id per node of the plan")
         self.E, self.max_patch_elems = int(conn_d.shape[0]), int(max_patch_elems)
         lib = _lib.load()
         h = ctypes.c_void_p()
