@@ -411,10 +411,71 @@ namespace {
 // LARGER of the two global nodes in that element; tr = the block is the transpose of that ordered pair's (I > J)
 struct HexBlock { int rank; int n; uint32_t tr; uint32_t ev[8]; };
 
+// LDS slots of a patch's elements that make phase 2's gathers conflict-free on structured patches.  When the (ascending)
+// element indices form a box ix + s2 iy + s3 iz (the numbering of a structured block), element (ix, iy, iz) gets a slot
+// congruent to ix + 4 iy + g(iz) modulo 16 -- the 16-byte bank slot of its gradients in LDS.  The 16 lanes of a hardware
+// ds_read_b128 group then hold the k-th lanes of a 4 x 4 square of nodes of one layer (hex_patch_layout orders them so),
+// whose elements form a 4 x 4 square as well: 16 consecutive residues, no two on one bank.  The layer shifts g are
+// chosen greedily so that the slots stay dense (5 x 5 x 4 elements: shifts 0, 5, 10, 15 fill slots 0..99 exactly); a
+// smaller box leaves a few slots unused (they repeat the first element).  Returns false (slots = positions in the
+// ascending list) for anything else.
+bool lattice_slots(const int32_t *el, int ne, int max_slots, std::vector<int> &slot_of, int &n_slots) {
+    if (ne < 8) return false;
+    int nx = 1;
+    while (nx < ne && el[nx] == el[0] + nx) nx++;
+    if (nx > 8 || ne % nx) return false;
+    const int rows = ne / nx;
+    const int64_t s2 = rows > 1 ? (int64_t)el[nx] - el[0] : 0;
+    int ny = 1;
+    while (ny < rows && (int64_t)el[ny * nx] == el[0] + ny * s2) ny++;
+    if (rows % ny) return false;
+    const int nz = rows / ny;
+    const int64_t s3 = nz > 1 ? (int64_t)el[ny * nx] - el[0] : 0;
+    for (int iz = 0; iz < nz; iz++)
+        for (int iy = 0; iy < ny; iy++)
+            for (int ix = 0; ix < nx; ix++)
+                if ((int64_t)el[(iz * ny + iy) * nx + ix] != el[0] + ix + iy * s2 + iz * s3) return false;
+    int m[16] = {0};
+    for (int iy = 0; iy < ny; iy++)
+        for (int ix = 0; ix < nx; ix++) m[(ix + 4 * iy) & 15]++;
+    auto need = [](const int *load) {
+        int P = 0;
+        for (int r = 0; r < 16; r++)
+            if (load[r] > 0 && (load[r] - 1) * 16 + r + 1 > P) P = (load[r] - 1) * 16 + r + 1;
+        return P;
+    };
+    int load[16] = {0}, shift[16];
+    if (nz > 16) return false;
+    for (int iz = 0; iz < nz; iz++) {
+        int best_g = 0, best_need = 1 << 30, best_max = 1 << 30;
+        for (int g = 0; g < 16; g++) {
+            int l[16], mx = 0;
+            for (int r = 0; r < 16; r++) { l[r] = load[r] + m[(r - g) & 15]; if (l[r] > mx) mx = l[r]; }
+            const int nd = need(l);
+            if (nd < best_need || (nd == best_need && mx < best_max)) { best_need = nd; best_max = mx; best_g = g; }
+        }
+        shift[iz] = best_g;
+        for (int r = 0; r < 16; r++) load[r] += m[(r - best_g) & 15];
+    }
+    n_slots = need(load);
+    if (n_slots > max_slots) return false;
+    int next_free[16];
+    for (int r = 0; r < 16; r++) next_free[r] = r;
+    slot_of.assign(ne, 0);
+    for (int iz = 0; iz < nz; iz++)
+        for (int iy = 0; iy < ny; iy++)
+            for (int ix = 0; ix < nx; ix++) {
+                const int r = (ix + 4 * iy + shift[iz]) & 15;
+                slot_of[(iz * ny + iy) * nx + ix] = next_free[r];
+                next_free[r] += 16;
+            }
+    return true;
+}
+
 // returns 0 or a negative code (-1: a node pair shared by more than 8 elements, -2: element missing from the patch,
 // -6: limits of the step record exceeded)
 int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, int nn, const int32_t *elems, int ne,
-                     std::vector<fs_hex_node> *out_nodes, std::vector<fs_hex_run> *out_runs, std::vector<uint32_t> *out_steps,
+                     const int *slot_of, std::vector<fs_hex_node> *out_nodes, std::vector<fs_hex_run> *out_runs, std::vector<uint32_t> *out_steps,
                      int64_t *n_lanes, int64_t *n_evals, int64_t *stage_len) {
     if (nn > FS_HEX_MAX_PATCH_NODES || ne > 128) return -6;
     int64_t lanes = 0, evals = 0, sbase = 0;
@@ -443,7 +504,8 @@ int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, i
                     const int64_t *cn = conn + (int64_t)e * 8;
                     int li = -1, lj = -1;
                     for (int k = 0; k < 8; k++) { if (cn[k] == I && li < 0) li = k; if (cn[k] == J && lj < 0) lj = k; }
-                    const int64_t slot = find_sorted(elems, elems + ne, e);
+                    const int64_t at = find_sorted(elems, elems + ne, e);
+                    const int64_t slot = at < 0 ? -1 : (slot_of ? slot_of[at] : at);
                     if (slot < 0) return -2;
                     if (hb.n >= 8) return -1;
                     hb.ev[hb.n++] = (uint32_t)slot | ((uint32_t)(I > J ? lj : li) << 7) | ((uint32_t)(I > J ? li : lj) << 10) | hb.tr;
@@ -493,7 +555,41 @@ int hex_patch_layout(const Mesh &m, const int64_t *conn, const int64_t *nodes, i
         sbase += 9 * (int64_t)mI;
     }
     *n_lanes = (lanes + 63) / 64 * 64;
-    if (out_steps) out_steps->resize((size_t)*n_lanes * 8, 0u);
+    if (out_steps) {
+        out_steps->resize((size_t)*n_lanes * 8, 0u);
+        // Lane order.  Phase 2 of the kernel gathers its operands from LDS with ds_read_b128, which the hardware serves in
+        // groups of 16 lanes: {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of every 32.  Lanes of ONE node name unrelated
+        // (element, local node) pairs -- a random gather, 3 LDS cycles per group instead of 1 --, whereas the k-th lanes
+        // of CONSECUTIVE nodes of a structured patch name element slots that differ like the nodes do: so the lanes are
+        // ordered k-major (k = position of the lane among its node's lanes), nodes ascending inside a k, and every run of
+        // 16 goes to one hardware group.  Which lane forms a block is invisible in the result (a flush names its node
+        // and neighbour rank).
+        std::vector<std::pair<int, int>> key;                  // (k, first lane of the node) of every lane
+        key.reserve((size_t)lanes);
+        {
+            const uint32_t *st = out_steps->data();
+            int prev_q = -1, k = 0;
+            for (int64_t l = 0; l < lanes; l++) {
+                int q = -1;                                    // node of the lane: the one its flushes name
+                for (int c = 0; c < 8 && q < 0; c++)
+                    if ((st[l * 8 + c] >> 14) & 1u) q = (int)((st[l * 8 + c] >> 15) & 63u);
+                k = (q == prev_q) ? k + 1 : 0;
+                prev_q = q;
+                key.push_back({k, q});
+            }
+        }
+        std::vector<int64_t> ord((size_t)lanes);
+        for (int64_t l = 0; l < lanes; l++) ord[l] = l;
+        std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+        static const int group_lane[32] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27,
+                                           4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+        std::vector<uint32_t> re((size_t)*n_lanes * 8, 0u);
+        for (int64_t i = 0; i < lanes; i++) {
+            const int64_t dst = (i / 32) * 32 + group_lane[i % 32];
+            std::copy(out_steps->begin() + ord[i] * 8, out_steps->begin() + ord[i] * 8 + 8, re.begin() + dst * 8);
+        }
+        out_steps->swap(re);
+    }
     *n_evals = evals;
     *stage_len = sbase;
     return 0;
@@ -542,7 +638,19 @@ int fs_fused_hex_plan_build(const int64_t *conn, int64_t E, int64_t n_nodes, con
             int rc = 0;
             int64_t stage = 0;
             if ((int64_t)el.size() > FS_HEX_MAX_PATCH_ELEMS) rc = -4;
-            else rc = hex_patch_layout(m, conn, nodes, nn, el.data(), (int)el.size(), &pnodes[p], &runs[p], &steps[p], &nl[p], &nev[p], &stage);
+            else {
+                std::vector<int> slot_of;
+                int n_slots = (int)el.size();
+                const bool lat = lattice_slots(el.data(), (int)el.size(), FS_HEX_MAX_PATCH_ELEMS, slot_of, n_slots);
+                rc = hex_patch_layout(m, conn, nodes, nn, el.data(), (int)el.size(), lat ? slot_of.data() : nullptr, &pnodes[p],
+                                      &runs[p], &steps[p], &nl[p], &nev[p], &stage);
+                if (lat) {                                   // pat_elems in slot order; unused slots repeat the first element
+                    std::vector<int32_t> by_slot((size_t)n_slots, el[0]);
+                    for (size_t i = 0; i < el.size(); i++) by_slot[slot_of[i]] = el[i];
+                    el.swap(by_slot);
+                    ne[p] = (int64_t)el.size();
+                }
+            }
             if (!rc && (nl[p] > FS_HEX_MAX_PATCH_LANES || stage > FS_HEX_STAGE_DOUBLES)) rc = -7;
             if (rc) {
 #pragma omp atomic write

@@ -464,7 +464,9 @@ void fs_fused_plan_device_free(fs_fused_plan_dev *plan);
  * (sum_e C : G_e = C : sum_e G_e).  Every contribution is formed for the node pair ordered by GLOBAL index and transposed
  * where the block is (larger, smaller), the diagonal ones are symmetrised (SOLID.py:565), so the assembled matrix is
  * EXACTLY symmetric.
- *   pat_eptr / pat_elems   elements of each patch (ascending; position = LDS slot), <= FS_HEX_MAX_PATCH_ELEMS per patch
+ *   pat_eptr / pat_elems   elements of each patch, position = LDS slot, <= FS_HEX_MAX_PATCH_ELEMS per patch (ascending; on
+ *                          structured patches the builder picks a slot order that frees phase 2's LDS gathers of bank
+ *                          conflicts, in which a few slots may repeat an element: any order is valid)
  *   pat_nptr / nodes       per patch node (ascending node index): offset of its slab in the patch's staging image
  *                          (doubles) and its number of neighbours m (slab = 3 rows x 3 m values)
  *   pat_rptr / runs        copy-out runs of the staging image: `len` doubles from staging offset `sbase` to data[gdst...]
