@@ -7,7 +7,7 @@
 // persistent, XCD-contiguous patch ranges) per PATCH of nodes, in the step layout of the fused HEXA8 kernel:
 //   phase 1  lane = (element slot, function f = node 0..2 or bubble): triangle frame, area and the shape / tying data
 //            of f at the 3 Hammer points (tri_geometry, tri_fn: the device functions of mitc3_k_lds_kernel) into an LDS
-//            image fn[23][4 slots], geo[10][slots]; elements of the one-element halo are evaluated by every patch that
+//            image fn[23][4][slots + 8], geo[10][slots]; elements of the one-element halo are evaluated by every patch that
 //            touches them.  Three passes of the workgroup from registers: element indices, coordinates and property
 //            ids travel one patch ahead, under phase 2 of the previous patch.
 //   phase 2  the patch forms the COMPLETE 6-row CSR slabs of its nodes (7 blocks for an interior node of a structured
@@ -32,7 +32,9 @@
 namespace {
 
 constexpr int TR_S = FS_TRI_MAX_PATCH_ELEMS;     // element slots of a patch
-constexpr int TR_FS = 4 * TR_S;                  // entries per component of the function image
+constexpr int TR_SS = TR_S + 8;                  // entries per (component, function): 184 = 24 mod 32 -- the four functions
+                                                 // of a slot start 24, 16, 8 eight-byte banks apart, neighbouring slots 1
+constexpr int TR_FS = 4 * TR_SS;                 // entries per component of the function image
 constexpr int TR_NT = FS_TRI_MAX_PATCH_LANES;    // 256
 
 #define TR_SLOT(r) ((int)((r) & 255u))
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
                                                          const int64_t *__restrict__ pat_nptr, const fs_tri_node *__restrict__ nodes,
                                                          const int64_t *__restrict__ pat_lptr, const uint32_t *__restrict__ steps,
                                                          double *__restrict__ data, int32_t *__restrict__ status) {
-    __shared__ double s_fn[23 * TR_FS];                   // shape / tying data [component][slot * 4 + f]
+    __shared__ double s_fn[23 * TR_FS];                   // shape / tying data [component][f][slot]
     __shared__ double s_geo[10 * TR_S];                   // area, frame rows [component][slot]
     __shared__ int32_t s_pid[TR_S];
     __shared__ fs_tri_node s_node[FS_TRI_MAX_PATCH_NODES];
@@ -123,17 +125,18 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
             tri_geometry(x, geo);
             TriFn F;
             tri_fn(geo, f, F);
+            const int w = f * TR_SS + slot;
             for (int g = 0; g < 3; g++) {
-                s_fn[(0 + g) * TR_FS + t] = F.fx[g];
-                s_fn[(3 + g) * TR_FS + t] = F.fy[g];
-                s_fn[(6 + 2 * g) * TR_FS + t] = F.gx[g][0];
-                s_fn[(7 + 2 * g) * TR_FS + t] = F.gx[g][1];
-                s_fn[(12 + 2 * g) * TR_FS + t] = F.gy[g][0];
-                s_fn[(13 + 2 * g) * TR_FS + t] = F.gy[g][1];
-                s_fn[(18 + g) * TR_FS + t] = F.h[g];
+                s_fn[(0 + g) * TR_FS + w] = F.fx[g];
+                s_fn[(3 + g) * TR_FS + w] = F.fy[g];
+                s_fn[(6 + 2 * g) * TR_FS + w] = F.gx[g][0];
+                s_fn[(7 + 2 * g) * TR_FS + w] = F.gx[g][1];
+                s_fn[(12 + 2 * g) * TR_FS + w] = F.gy[g][0];
+                s_fn[(13 + 2 * g) * TR_FS + w] = F.gy[g][1];
+                s_fn[(18 + g) * TR_FS + w] = F.h[g];
             }
-            s_fn[21 * TR_FS + t] = F.dhx;
-            s_fn[22 * TR_FS + t] = F.dhy;
+            s_fn[21 * TR_FS + w] = F.dhx;
+            s_fn[22 * TR_FS + w] = F.dhy;
             if (f == 0) {
                 s_geo[0 * TR_S + slot] = geo.area;
                 for (int k2 = 0; k2 < 3; k2++) {
@@ -168,11 +171,11 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
                 const bool tr = li > lj;
                 double G[6][6];
                 if (UNI) {
-                    tri_pair_block<TR_FS, TR_S>(s_fn, s_geo, slot, ti, tj, &Pu, G);
+                    tri_pair_block<TR_FS, TR_S, 1, TR_SS>(s_fn, s_geo, slot, ti, tj, &Pu, G);
                 } else {
                     TriProp pr;
                     load_tri_prop(props + s_pid[slot], pr);
-                    tri_pair_block<TR_FS, TR_S>(s_fn, s_geo, slot, ti, tj, &pr, G);
+                    tri_pair_block<TR_FS, TR_S, 1, TR_SS>(s_fn, s_geo, slot, ti, tj, &pr, G);
                 }
 #pragma unroll
                 for (int a = 0; a < 6; a++)

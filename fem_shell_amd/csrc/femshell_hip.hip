@@ -1784,7 +1784,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int64_t e_raw = e0 + qq;
     const int64_t e = e_raw < E ? e_raw : E - 1;
     double G[6][6];
-    tri_pair_block<40, M3_EPW>(lds + M3_FN, lds + M3_GEO, qq, ti, tj, props + safe_pid(prop_id[e], n_props), G);
+    tri_pair_block<40, M3_EPW, 4, 1>(lds + M3_FN, lds + M3_GEO, qq, ti, tj, props + safe_pid(prop_id[e], n_props), G);
     // ---------------- output: 60 blocks = 1080 contiguous 16-byte chunks, 30 blocks per pass ----------------
     const int64_t nblk_total = E * 6;
     const int64_t blk0 = e0 * 6;

@@ -162,12 +162,15 @@ __device__ __forceinline__ double tri_dy(const TriG &F, const double *c5) {
 // the frame rows.  Gauss point by Gauss point (only one point's data is live), bubble condensation, membrane CST,
 // drilling, rotation to global axes; diagonal blocks symmetrised.  Shared by mitc3_k_lds_kernel and the fused kernel
 // (femshell_fused_tri.hip), so both form the same bits.
+// Function f of element qq sits at entry qq * QS + f * FST of a component (element kernel: QS = 4, FST = 1; the fused
+// kernel keeps the functions apart, QS = 1, FST = slots + pad, so that lanes reading one function of neighbouring
+// elements hit neighbouring banks).
 // PROP: fs_shell_prop or any type with its members A, B, D, Cs, k_drill, flags (a register copy of the row).
-template <int FS, int GS, class PROP>
+template <int FS, int GS, int QS, int FST, class PROP>
 __device__ __forceinline__ void tri_pair_block(const double *fn, const double *geo, int qq, int ti, int tj,
                                                const PROP *pr, double (&G)[6][6]) {
 #pragma clang fp contract(fast)
-    const int qi = qq * 4 + ti, qj = qq * 4 + tj, qb = qq * 4 + 3;
+    const int qi = qq * QS + ti * FST, qj = qq * QS + tj * FST, qb = qq * QS + 3 * FST;
     const double area = geo[qq];
     const double idhx = fn[21 * FS + qi], idhy = fn[22 * FS + qi];
     const double jdhx = fn[21 * FS + qj], jdhy = fn[22 * FS + qj];
