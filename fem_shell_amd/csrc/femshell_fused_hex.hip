@@ -27,8 +27,6 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#include <mutex>
-
 #include "femshell_hip.h"
 #include "femshell_internal.h"
 #include "femshell_geom.h"
@@ -300,26 +298,6 @@ __global__ __launch_bounds__(256) void hex_plan_check_kernel(int64_t n_pat, cons
     }
 }
 
-constexpr int kMaxDev = 64;
-int g_cus[kMaxDev] = {};
-std::mutex g_mu;
-
-int cu_count(int *out) {
-    int dev = -1;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return fs_fail_(FS_EHIP, "hipGetDevice", (int)e);
-    if (dev < 0 || dev >= kMaxDev) return fs_fail_(FS_EINVAL, "device index out of range", 0);
-    std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_cus[dev]) {
-        int n = 0;
-        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess || n <= 0) return fs_fail_(FS_EHIP, "hipDeviceGetAttribute(MultiprocessorCount)", (int)e);
-        g_cus[dev] = n;
-    }
-    *out = g_cus[dev];
-    return FS_OK;
-}
-
 }  // namespace
 
 extern "C" int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props,
@@ -333,7 +311,7 @@ extern "C" int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id,
         !steps || !data)
         return fs_fail_(FS_EINVAL, "fs_fused_assemble_hex8: null argument", 0);
     int cus = 0;
-    if (int rc = cu_count(&cus)) return rc;
+    if (int rc = fs_device_cu_count_(&cus)) return rc;
     int64_t wgs = ((int64_t)cus / 8) * 8;
     if (wgs < 8) wgs = 8;
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;

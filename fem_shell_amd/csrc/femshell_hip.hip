@@ -3413,3 +3413,5 @@ int fs_gather_dofs(const double *u, const int64_t *dofs, int64_t n, double *u_e,
 }
 
 }  // extern "C"
+
+int fs_device_cu_count_(int *out) { return device_cu_count(out); }
