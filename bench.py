@@ -252,6 +252,10 @@ def hex8_leg(torch, steps=5):
                                       "Gauss points first (K = C : sum_q g g^T): about 15 kflop per element executed incl. the "
                                       "halo, against 47 kflop of the B^T C B form (SURVEY.md 8d)"}}
         del Kf, K2
+        # the consistent mass matrix through the same plan (fs_fused_assemble_hex8_mass) against its two-kernel route
+        fused["mass_ms_per_step"] = avg_ms(torch, lambda: asm.assemble_mass_matrix(recompute=True), steps)
+        fused["mass_two_kernel_ms_per_step"] = avg_ms(torch, lambda: asm.assemble_mass_matrix(recompute=True, fused=False), steps)
+        asm._M_blk = None
     flop = 47000.0                    # SURVEY.md 8(d) estimate for the 2x2x2 HEXA8 stiffness (not re-derived)
     # element kernel: 192 B coordinates in, 36 upper 3x3 node-pair blocks out; assembly: those blocks in, CSR values out
     a_bytes = 36 * 72 + 8.0 * K.nnz / E
@@ -263,7 +267,9 @@ def hex8_leg(torch, steps=5):
             "kernels": {
                 "solid_kernel<8>": {"kernel_ms": k_ms, "bound": "valu_fp64", "achieved": E * flop / (k_ms * 1e-3) / 1e12,
                                     "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": E * flop / (k_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "flop_per_element": flop},
+                                    "frac": E * flop / (k_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "flop_per_element": flop,
+                                    "note": "priced with the 47 kflop of the B^T C B form (SURVEY.md 8d); the kernel "
+                                            "contracts over the Gauss points first and executes about 13 kflop"},
                 "csr_numeric_desc3_lds_kernel": {"kernel_ms": a_ms, "bound": "hbm", "achieved": E * a_bytes / (a_ms * 1e-3) / 1e9,
                                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                  "frac": E * a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

@@ -504,8 +504,14 @@ class MeshAssembler:
         data = torch.empty(self._plan.nnz, dtype=torch.float64, device=self.device)
         if self._family == ElementFamily.SOLID:
             # HEXA8.K of every element (elements/SOLID.py:543-567) and the ADD_VALUES loop (core/assembler.py:287-303)
-            if mass:
-                raise NotImplementedError("the fused HEXA8 kernel forms K (the mass matrix keeps the two-kernel route)")
+            if mass:          # SolidElement.M of every element (elements/SOLID.py:569-597) and the loop of :305-336
+                _lib.check(lib.fs_fused_assemble_hex8_mass(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+                                                           len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
+                                                           _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_nptr"]), _lib.ptr(d["nodes"]),
+                                                           _lib.ptr(d["pat_rptr"]), _lib.ptr(d["runs"]), _lib.ptr(d["pat_lptr"]),
+                                                           _lib.ptr(d["steps"]), _lib.ptr(data), _lib.stream_ptr()),
+                           "fs_fused_assemble_hex8_mass")
+                return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
             if status is not None:
                 status.zero_()                     # the kernel ORs FS_ST_BAD_JAC in
             _lib.check(lib.fs_fused_assemble_hex8(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
@@ -554,12 +560,12 @@ class MeshAssembler:
         return self._assemble(self._K_blk)
 
     def assemble_mass_matrix(self, recompute=False, fused=None) -> CsrMatrix:
-        """core/assembler.py:305-336.  On uniform MITC4+ meshes a (re-)evaluation goes through the fused kernel (no element
+        """core/assembler.py:305-336.  On uniform MITC4+ and HEXA8 meshes a (re-)evaluation goes through the fused kernels (no element
         mass matrices in memory; `_me_array` still materialises them on demand); fused=False forces element kernel +
         assembly kernel (same bits)."""
         fused = self.use_fused if fused is None else fused
-        if ((recompute or self._M_blk is None) and fused and self._family == ElementFamily.SHELL
-                and self._groups[0]["nn"] == 4 and self.fused_ready()):
+        if ((recompute or self._M_blk is None) and fused and self._groups[0]["nn"] in (4, 8)      # MITC4+ and HEXA8
+                and self.fused_ready()):
             return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True, check=False)

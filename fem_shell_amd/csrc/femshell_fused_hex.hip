@@ -258,6 +258,113 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
     }
 }
 
+// Consistent mass matrix of HEXA8 (SolidElement.M, elements/SOLID.py:569-597: rho * sum_q N^T N detJ w) through the same
+// plan and the same skeleton: phase 1 keeps sqrt(rho detJ) N_i(q) per (slot, point) -- 65 doubles per slot --, a step is
+// m = sum_q n_i n_j (8 multiply-adds), the contributions of a block are added in element order and the block is m I_3.
+// Products commute and blocks (I, J), (J, I) add the same numbers in the same order: exactly symmetric.
+constexpr int HX_MS = 65;
+__global__ __launch_bounds__(HX_NT) void fused_hex8_mass_kernel(const double *__restrict__ xyz, const int32_t *__restrict__ prop_id,
+                                                               const double *__restrict__ props, int32_t n_props, int64_t n_pat,
+                                                               const int64_t *__restrict__ pat_eptr, const int32_t *__restrict__ pat_elems,
+                                                               const int64_t *__restrict__ pat_nptr, const fs_hex_node *__restrict__ nodes,
+                                                               const int64_t *__restrict__ pat_rptr, const fs_hex_run *__restrict__ runs,
+                                                               const int64_t *__restrict__ pat_lptr, const uint32_t *__restrict__ steps,
+                                                               double *__restrict__ data) {
+    __shared__ double s_g[FS_HEX_STAGE_DOUBLES];          // shape values, later the staging image of the patch's CSR slabs
+    __shared__ fs_hex_node s_node[FS_HEX_MAX_PATCH_NODES];
+    __shared__ fs_hex_run s_run[FS_HEX_MAX_PATCH_NODES];
+    static_assert(FS_HEX_MAX_PATCH_ELEMS * HX_MS <= FS_HEX_STAGE_DOUBLES, "the shape values fit the staging image");
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, wpx = (int)(gridDim.x >> 3);
+    const int64_t per_xcd = (n_pat + 7) / 8;
+    const int64_t pend = ((xcd + 1) * per_xcd < n_pat) ? (xcd + 1) * per_xcd : n_pat;
+    const double gp = kGP;
+    for (int64_t p = xcd * per_xcd + (blockIdx.x >> 3); p < pend; p += wpx) {
+        const int64_t e0 = pat_eptr[p], n0 = pat_nptr[p], r0 = pat_rptr[p], l0 = pat_lptr[p];
+        const int ne = (int)(pat_eptr[p + 1] - e0), nn = (int)(pat_nptr[p + 1] - n0), nr = (int)(pat_rptr[p + 1] - r0);
+        const int nl = (int)(pat_lptr[p + 1] - l0);
+        uint4 sa = make_uint4(0, 0, 0, 0), sb = sa;
+        if (tid < nl) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(steps + (l0 + tid) * 8);
+            sa = sp[0]; sb = sp[1];
+        }
+        if (tid < nn) s_node[tid] = nodes[n0 + tid];
+        if (tid >= 64 && tid - 64 < nr) s_run[tid - 64] = runs[r0 + tid - 64];
+        for (int t = tid; t < ne * 8; t += HX_NT) {
+#pragma clang fp contract(fast)
+            const int slot = t >> 3, q = t & 7;
+            const int64_t e = pat_elems[e0 + slot];
+            const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp, zeta = (q & 4) ? gp : -gp;
+            double N[8], dxi[8], deta[8], dzeta[8];
+            solid_shape<8>(xi, eta, zeta, N, dxi, deta, dzeta);
+            double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            const double *x = xyz + e * 24;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double xc = x[3 * i + c];
+                    J[0][c] += dxi[i] * xc; J[1][c] += deta[i] * xc; J[2][c] += dzeta[i] * xc;
+                }
+            const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                               J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            const double rho = props[(int64_t)safe_pid(prop_id[e], n_props) * 37 + 36];
+            const double sw = __builtin_sqrt(rho * det);          // weights are 1
+            double *g = s_g + slot * HX_MS + q * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) g[i] = sw * N[i];
+        }
+        __syncthreads();
+        double Mout[4];
+        {
+#pragma clang fp contract(fast)
+            const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            double acc = 0.0;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const uint32_t r = rec[s];
+                if (HX_ACTIVE(r)) {
+                    const double *ga = s_g + HX_SLOT(r) * HX_MS + HX_LI(r), *gb = s_g + HX_SLOT(r) * HX_MS + HX_LJ(r);
+                    double m = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) m = FMA(ga[q * 8], gb[q * 8], m);
+                    acc = acc + m;
+                }
+                if ((s & 1) && HX_FLUSH(r)) { Mout[s >> 1] = acc; acc = 0.0; }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+            for (int s = 1; s < 8; s += 2) {
+                const uint32_t r = rec[s];
+                if (HX_FLUSH(r)) {
+                    const fs_hex_node nd = s_node[HX_NODE(r)];
+                    double *o = s_g + nd.sbase + 3 * HX_RANK(r);
+                    const int stride = 3 * nd.m;
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int l = 0; l < 3; l++) o[k * stride + l] = k == l ? Mout[s >> 1] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < nr; rr++) {
+            const fs_hex_run run = s_run[rr];
+            const int head = (int)(run.gdst & 1), np2 = (run.len - head) >> 1;
+            double *dst = data + run.gdst + head;
+            const double *src = s_g + run.sbase + head;
+            for (int c = tid; c < np2; c += HX_NT)
+                *reinterpret_cast<double2 *>(dst + 2 * c) = make_double2(src[2 * c], src[2 * c + 1]);
+            if (tid == 0 && head) dst[-1] = src[-1];
+            if (tid == 64 && ((run.len - head) & 1)) dst[2 * np2] = src[2 * np2];
+        }
+        __syncthreads();
+    }
+}
+
 // Invariants fused_hex8_kernel relies on when it indexes LDS and `data` with values read from the plan
 // (fs_fused_hex_plan_check): workgroup per patch (grid-stride).  err[0] = violations, err[1] = first rule, err[2] = patch.
 __global__ __launch_bounds__(256) void hex_plan_check_kernel(int64_t n_pat, const int64_t *__restrict__ pat_eptr,
@@ -324,6 +431,28 @@ extern "C" int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id,
                            n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_rptr, runs, pat_lptr, steps, data, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_hex8_kernel", (int)e);
+    return FS_OK;
+}
+
+extern "C" int fs_fused_assemble_hex8_mass(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props,
+                                           int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
+                                           const int64_t *pat_nptr, const fs_hex_node *nodes, const int64_t *pat_rptr,
+                                           const fs_hex_run *runs, const int64_t *pat_lptr, const uint32_t *steps, double *data,
+                                           void *stream) {
+    if (E < 0 || n_props <= 0 || n_patches < 0) return fs_fail_(FS_EINVAL, "fs_fused_assemble_hex8_mass: bad sizes", 0);
+    if (E == 0 || n_patches == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !pat_eptr || !pat_elems || !pat_nptr || !nodes || !pat_rptr || !runs || !pat_lptr ||
+        !steps || !data)
+        return fs_fail_(FS_EINVAL, "fs_fused_assemble_hex8_mass: null argument", 0);
+    int cus = 0;
+    if (int rc = fs_device_cu_count_(&cus)) return rc;
+    int64_t wgs = ((int64_t)cus / 8) * 8;
+    if (wgs < 8) wgs = 8;
+    if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
+    hipLaunchKernelGGL(fused_hex8_mass_kernel, dim3((unsigned)wgs), dim3(HX_NT), 0, (hipStream_t)stream, xyz, prop_id, props,
+                       n_props, n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_rptr, runs, pat_lptr, steps, data);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_hex8_mass_kernel", (int)e);
     return FS_OK;
 }
 

@@ -492,6 +492,13 @@ int fs_fused_assemble_hex8(const double *xyz, const int32_t *prop_id, const doub
                            int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
                            const fs_hex_node *nodes, const int64_t *pat_rptr, const fs_hex_run *runs,
                            const int64_t *pat_lptr, const uint32_t *steps, double *data, int32_t *status, void *stream);
+/* The consistent MASS matrix through the same plan and skeleton (SolidElement.M, elements/SOLID.py:569-597: rho sum_q
+ * N^T N detJ w, blocks m I_3; and the loop of MeshAssembler.assemble_mass_matrix, core/assembler.py:305-336): the values
+ * of M straight from the coordinates, <= 1e-15 from fs_solid_batch(FS_WANT_M) + fs_csr_numeric_desc, exactly symmetric. */
+int fs_fused_assemble_hex8_mass(const double *xyz, const int32_t *prop_id, const double *props, int32_t n_props, int64_t E,
+                                int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
+                                const fs_hex_node *nodes, const int64_t *pat_rptr, const fs_hex_run *runs,
+                                const int64_t *pat_lptr, const uint32_t *steps, double *data, void *stream);
 /* The kernel trusts its plan.  A plan that does not come from fs_fused_hex_plan_build must pass this check once before
  * its first launch (device pointers; synchronises `stream`, allocates 24 bytes): patch sizes within the limits above,
  * element indices in [0, E), node slabs and copy-out runs inside the staging image and inside [0, nnz), active steps
