@@ -532,24 +532,48 @@ def newton_leg(torch, steps=10):
         torch.cuda.synchronize()
         gms = (time.perf_counter() - t0) / steps * 1e3
         E = mesh.element_count
+        # the route this one replaced: element kernel on the cached linear blocks + descriptor assembly + vector scatter
+        asm.newton_on_assembled = False
+        asm.assemble_tangent_and_forces(field * 1e-3)
+        old_ms = avg_ms(torch, lambda: asm.assemble_tangent_and_forces(field * 2e-3), steps)
+        asm.newton_on_assembled = True
         out[tag] = {"elements": E, "ms_per_reassembly": ms, "reassemblies_per_s": 1e3 / ms,
-                    "elements_per_s": E / (ms * 1e-3), "ms_per_reassembly_hip_graph": gms}
-        if E > 1_000_000:      # per-kernel roofline of the two element kernels this leg and the mass path run
-            u = field * 1e-3
+                    "elements_per_s": E / (ms * 1e-3), "ms_per_reassembly_hip_graph": gms,
+                    "element_block_route_ms_per_reassembly": old_ms}
+        if E > 1_000_000:      # per-kernel rooflines of the Newton path and of the kernels of the element-block route
+            u = (field * 1e-3).contiguous()
+            k_lin = asm._linear_csr()
+            nnz = k_lin.numel()
+            kt_ms = avg_ms(torch, lambda: asm._tangent_on_assembled(u, k_lin), 10)
+            asm.tangent_flags = 1
+            kt1_ms = avg_ms(torch, lambda: asm._tangent_on_assembled(u, k_lin), 10)
+            asm.tangent_flags = 0
+            f_ms = avg_ms(torch, lambda: asm._forces_on_assembled(u, k_lin), 10)
+            # K_T: coordinates, connectivity, u, id, the upper block triangle of K in (half the values + the diagonal
+            # blocks' other half ~ nnz / 2), all values out
+            kt_b = E * (96 + 32 + 48 + 4) + 8 * nnz * 1.5
+            f_b = 8 * nnz + E * (96 + 32 + 48 + 4 + 2 * 192) + asm.dofs_count * 8 * 3
             nl_ms = avg_ms(torch, lambda: asm._nl_pass(u, True, True), 5)
             nb = 96 + 4 + 192 + 2880 + 2880 + 192        # coordinates, id, u_e, linear blocks in; K_T blocks, f_int out
             m_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=False, want_M=True, check=False), 5)
             mb = 96 + 4 + 4 + 2880
+            roof = lambda ms_, by: {"kernel_ms": ms_, "bound": "hbm", "achieved": by / (ms_ * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                    "unit": "GB/s", "frac": by / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes": by}
             out["kernels"] = {
-                "mitc4_nl_tiled_kernel (+ fs_gather_dofs)": {
+                "fused_quad_dkt_kernel<32> (K_T = K_csr + corrections, two workgroups per CU)": roof(kt_ms, kt_b),
+                "fused_quad_dkt_kernel<64> (one workgroup per CU)": roof(kt1_ms, kt_b),
+                "f_int: mitc4_nl_tiled_kernel (nonlinear part) + fs_vec_gather_sum + blk_matvec_kernel<6>": roof(f_ms, f_b),
+                "mitc4_nl_tiled_kernel (+ fs_gather_dofs), element-block route": {
                     "kernel_ms": nl_ms, "bound": "hbm", "achieved": E * nb / (nl_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": E * nb / (nl_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_element": nb},
                 "mitc4_m_tiled_kernel": {
                     "kernel_ms": m_ms, "bound": "hbm", "achieved": E * mb / (m_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": E * mb / (m_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_element": mb}}
         del asm
-    out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate: gather u_e, TL tangent / internal-force kernel on " \
-                  "the cached linear blocks, CSR assembly, vector scatter"
+    out["what"] = "K_T(u_k) and f_int(u_k) re-assembled per Newton iterate on the ASSEMBLED linear matrix (kept once): " \
+                  "K_T = K_csr + element-order sums of the geometric corrections in one fused launch, f_int = K_csr u + " \
+                  "nonlinear membrane forces; element_block_route_*: gather u_e, TL kernel on the cached element blocks, " \
+                  "CSR assembly, vector scatter (the route of rounds 1-2)"
     return out
 
 

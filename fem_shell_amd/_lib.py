@@ -14,6 +14,7 @@ FS_SOLID_STRESS_GP, FS_SOLID_STRESS_MEAN, FS_SOLID_STRESS_NODES = 0, 1, 2
 FS_INERTIAL_CENTRIFUGAL, FS_INERTIAL_CORIOLIS, FS_INERTIAL_EULER = 1, 2, 4
 FS_FUSED_HAS_COUPLED = 1
 FS_FUSED_MASS = 2
+FS_TANGENT_ONE_WG_PER_CU = 1
 FS_FUSED_MAX_PATCH_ELEMS = 64
 FS_HEX_MAX_PATCH_ELEMS, FS_HEX_MAX_PATCH_NODES, FS_HEX_MAX_PATCH_LANES = 100, 64, 512
 
@@ -28,6 +29,9 @@ SIGNATURES = {
     "fs_shell_quad_fint_noalloc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
     "fs_fused_assemble_quad": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _u32,
                                               _vp, _vp, _vp]),
+    "fs_fused_assemble_quad_tangent": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32,
+                                                      _vp, _vp, _u32, _vp]),
+    "fs_shell_quad_fint_nl": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "fs_fused_plan_check": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp]),
     "fs_shell_quad_geom_status": (ctypes.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "fs_fused_assemble_hex8": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -74,6 +78,7 @@ SIGNATURES = {
     "fs_csr_reduce_fill": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_expand_solution": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fs_csr_row_sums": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "fs_csr_blk_matvec": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "fs_halo_pack": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_halo_add": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "fs_gather_dofs": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),

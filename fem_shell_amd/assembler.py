@@ -92,6 +92,9 @@ class MeshAssembler:
     use_fused = True             # uniform MITC4+ meshes: assemble_stiffness_matrix(recompute=True) is ONE fused
                                  # evaluate-and-assemble launch (fs_fused_assemble_quad), bitwise the two-kernel result
     fused_max_patch_elems = 64   # elements per patch of the fused plan (<= 80)
+    newton_on_assembled = True   # uniform MITC4+ meshes: K_T(u) = K_csr + element-order sums of the geometric corrections
+                                 # (fs_fused_assemble_quad_tangent), f_int(u) = K_csr u + nonlinear membrane forces
+                                 # (fs_csr_blk_matvec + fs_shell_quad_fint_nl): no element blocks in the Newton loop
     _FAMILY_PROPERTIES = {ElementFamily.SHELL: (6, 3), ElementFamily.PLANE: (2, 2),
                           ElementFamily.SOLID: (3, 3)}
 
@@ -112,6 +115,7 @@ class MeshAssembler:
         self._row_nnz: Optional[np.ndarray] = None
         self._is_mixed_mesh = False
         self._K_blk = self._M_blk = None
+        self._K_lin_csr = None    # values of the assembled linear K the Newton path works on (see _linear_csr)
         self._fplan = self._fplan_d = None
         self._fplan_error = None
         self._precompute_elements()
@@ -554,8 +558,10 @@ class MeshAssembler:
             st = self._status[0] if self._status and self._status[0].numel() == self._groups[0]["E"] else None
             if recompute:
                 self._K_blk = None
+                self._K_lin_csr = None
             return self.assemble_stiffness_fused(status=st)
         if recompute or self._K_blk is None:
+            self._K_lin_csr = None
             self.refresh_element_matrices(want_K=True, want_M=False, check=self._K_blk is None)
         return self._assemble(self._K_blk)
 
@@ -632,17 +638,72 @@ class MeshAssembler:
                                          _lib.ptr(f), _lib.stream_ptr()), "fs_vec_gather_sum")
         return f
 
+    # --- the Newton path on the ASSEMBLED linear matrix (uniform MITC4+ meshes) ---------------------
+    def _newton_fused(self):
+        """K does not depend on u: on uniform MITC4+ meshes with a patch plan the Newton re-assembly works on the
+        assembled linear matrix (kept once, 2 592 B per element) instead of streaming 2 880 B of element blocks per
+        element through an element kernel and an assembly kernel every iterate."""
+        return (self.newton_on_assembled and self.use_fused and self._family == ElementFamily.SHELL
+                and len(self._groups) == 1 and self._groups[0]["nn"] == 4 and self._groups[0]["pos"] is None
+                and self.fused_ready())
+
+    def _linear_csr(self):
+        """Values of the assembled linear K (fs_fused_assemble_quad), evaluated on first use and after a
+        recompute=True assembly; reuse_linear_blocks=False re-evaluates them on every call."""
+        if self._K_lin_csr is None or not self.reuse_linear_blocks:
+            self._K_lin_csr = self.assemble_stiffness_fused().data
+        return self._K_lin_csr
+
+    def _u_nodes(self, u):
+        u = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
+        if u.numel() != self.dofs_count:
+            raise ValueError(f"Expected {self.dofs_count} DOFs, got {u.numel()}")
+        return u
+
+    def _tangent_on_assembled(self, u, k_lin) -> CsrMatrix:
+        lib, fp, d, g = _lib.load(), self.fused_plan(), self._fplan_d, self._groups[0]
+        data = torch.empty(self._plan.nnz, dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_fused_assemble_quad_tangent(
+            _lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+            len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]), _lib.ptr(d["pat_elems"]),
+            _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]), fp.max_patch_elems, _lib.ptr(k_lin), _lib.ptr(data),
+            self.tangent_flags, _lib.stream_ptr()), "fs_fused_assemble_quad_tangent")
+        return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
+
+    tangent_flags = 0            # FS_TANGENT_* flags of fs_fused_assemble_quad_tangent
+
+    def _forces_on_assembled(self, u, k_lin):
+        """f_int = K u (assembled matrix) + element-order sums of the nonlinear membrane forces."""
+        lib, g, pd = _lib.load(), self._groups[0], self._plan_d
+        fe = torch.empty((g["E"], 24), dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_shell_quad_fint_nl(_lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]),
+                                             _lib.ptr(self._props_d), len(self._prop_table), g["E"], _lib.ptr(fe),
+                                             _lib.stream_ptr()), "fs_shell_quad_fint_nl")
+        f_nl = self._scatter_vector(fe.reshape(-1))
+        f = torch.empty(self.dofs_count, dtype=torch.float64, device=self.device)
+        _lib.check(lib.fs_csr_blk_matvec(_lib.ptr(pd["nbr_ptr"]), _lib.ptr(pd["nbr"]), _lib.ptr(pd["blk_row"]),
+                                         int(self._plan.n_nodes), self.dofs_per_node, _lib.ptr(k_lin), _lib.ptr(u),
+                                         _lib.ptr(f_nl), _lib.ptr(f), _lib.stream_ptr()), "fs_csr_blk_matvec")
+        return f
+
     def assemble_tangent_stiffness(self, u) -> CsrMatrix:
         """K_T(u): per element update_configuration(u[dofs]); compute_tangent_stiffness()
         (elements/MITC4.py:1067-1084,1246-1298), scatter-added like K."""
+        if self._newton_fused():
+            return self._tangent_on_assembled(self._u_nodes(u), self._linear_csr())
         return self._assemble(self._nl_pass(u, True, False)["KT"])
 
     def assemble_internal_forces(self, u):
         """f_int(u): per element compute_internal_forces() (elements/MITC4.py:1300-1341),
         scatter-added in element order. Returns a device vector [dofs_count]."""
+        if self._newton_fused():
+            return self._forces_on_assembled(self._u_nodes(u), self._linear_csr())
         return self._scatter_vector(self._nl_pass(u, False, True)["f_int"])
 
     def assemble_tangent_and_forces(self, u):
+        if self._newton_fused():
+            u, k_lin = self._u_nodes(u), self._linear_csr()
+            return self._tangent_on_assembled(u, k_lin), self._forces_on_assembled(u, k_lin)
         out = self._nl_pass(u, True, True)
         return self._assemble(out["KT"]), self._scatter_vector(out["f_int"])
 

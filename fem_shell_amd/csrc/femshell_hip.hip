@@ -1323,8 +1323,13 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
                                                             const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                             const double *__restrict__ ue, int64_t E,
                                                             const double *k0, double *kt, int want_kt,
-                                                            double *__restrict__ fe) {
+                                                            double *__restrict__ fe,
+                                                            const int64_t *__restrict__ conn = nullptr,
+                                                            const double *__restrict__ u_nodes = nullptr) {
     // k0: the linear blocks K (read); kt: K_T (written when want_kt).  They may be the same buffer (in place).
+    // k0 == nullptr (fs_shell_quad_fint_nl): no blocks are streamed, fe receives the NONLINEAR part of the internal
+    // forces only (the caller adds K u from the assembled matrix).  conn / u_nodes: gather the nodal displacements
+    // through the connectivity instead of reading ue.
     __shared__ double lds[NLT_LDS];
     const int lane = threadIdx.x;
     const int Q = lane >> 2, g = lane & 3;
@@ -1335,8 +1340,18 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
     {
         const double2 *p = reinterpret_cast<const double2 *>(xyz + e * 12);
         for (int t = 0; t < 6; t++) { const double2 v = p[t]; (&x[0][0])[2 * t] = v.x; (&x[0][0])[2 * t + 1] = v.y; }
-        const double2 *q = reinterpret_cast<const double2 *>(ue + e * 24);
-        for (int t = 0; t < 12; t++) { const double2 v = q[t]; (&u[0][0])[2 * t] = v.x; (&u[0][0])[2 * t + 1] = v.y; }
+        if (conn) {
+            const longlong2 *cp = reinterpret_cast<const longlong2 *>(conn + e * 4);
+            const longlong2 c01 = cp[0], c23 = cp[1];
+            const int64_t nid[4] = {c01.x, c01.y, c23.x, c23.y};
+            for (int i = 0; i < 4; i++) {
+                const double2 *q = reinterpret_cast<const double2 *>(u_nodes + nid[i] * 6);
+                for (int t = 0; t < 3; t++) { const double2 v = q[t]; u[i][2 * t] = v.x; u[i][2 * t + 1] = v.y; }
+            }
+        } else {
+            const double2 *q = reinterpret_cast<const double2 *>(ue + e * 24);
+            for (int t = 0; t < 12; t++) { const double2 v = q[t]; (&u[0][0])[2 * t] = v.x; (&u[0][0])[2 * t + 1] = v.y; }
+        }
     }
     const fs_shell_prop *pr = props + safe_pid(prop_id[e], n_props);
     QuadGeom geo;
@@ -1490,7 +1505,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
     }
     __syncthreads();
     // ---- stream the tile: K u (linear blocks) and K_T = K + R^T sym(dL) R ----
-    for (int round = 0; round < 3; round++) {
+    for (int round = 0; round < (k0 ? 3 : 0); round++) {
 #pragma clang fp contract(fast)
         int ti, tj;
         if (round == 0) { ti = g; tj = g; }
@@ -3316,6 +3331,17 @@ int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const 
     hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E, ws, ws, 0, fe);
     FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
     return check_props(prop_id, E, n_props, status, 0, s);
+}
+
+int fs_shell_quad_fint_nl(const double *xyz, const int64_t *conn, const double *u, const int32_t *prop_id,
+                          const fs_shell_prop *props, int32_t n_props, int64_t E, double *fe, void *stream) {
+    if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_quad_fint_nl: bad sizes");
+    if (E == 0) return FS_OK;
+    if (!xyz || !conn || !u || !prop_id || !props || !fe) return fail(FS_EINVAL, "fs_shell_quad_fint_nl: null argument");
+    hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, (hipStream_t)stream, xyz, prop_id,
+                       props, n_props, (const double *)nullptr, E, (const double *)nullptr, (double *)nullptr, 0, fe, conn, u);
+    FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
+    return FS_OK;
 }
 
 int fs_fused_assemble_quad(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,

@@ -178,6 +178,72 @@ __global__ __launch_bounds__(64) void fp64_fma_kernel(double *__restrict__ out, 
     out[(int64_t)blockIdx.x * 64 + threadIdx.x] = s;
 }
 
+// y = A x (+ y0) for the block-structured CSR of fs_csr_pattern_blk (D dofs per node: the D rows of node I are
+// contiguous, row r holds the D-entry pieces of the node's blocks one after the other).  A lane owns a node-pair BLOCK:
+// its D row pieces (neighbouring lanes read neighbouring pieces of every row: whole lines), x of its column node once,
+// D dot products to LDS; then a lane per matrix row adds the partial products of its blocks from left to right --
+// one writer per row, the same sum in every run.
+constexpr int MV_NB = 28;      // nodes per workgroup (28 x 9 blocks = 252 lanes on a structured quad mesh)
+constexpr int MV_CAP = 512;    // blocks per pass through LDS
+template <int D>
+__global__ __launch_bounds__(256) void blk_matvec_kernel(const int64_t *__restrict__ nbr_ptr, const int32_t *__restrict__ nbr,
+                                                         const int32_t *__restrict__ blk_row, int64_t n_nodes,
+                                                         const double *__restrict__ data, const double *__restrict__ x,
+                                                         const double *__restrict__ y0, double *__restrict__ y) {
+    __shared__ double s_p[D * MV_CAP];
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * MV_NB;
+    const int64_t n1 = (n0 + MV_NB < n_nodes) ? n0 + MV_NB : n_nodes;
+    const int64_t T0 = nbr_ptr[n0], T1 = nbr_ptr[n1];
+    // phase-B role of this lane: row r of node In
+    const int64_t In = n0 + tid / D;
+    const int r_own = tid % D;
+    const bool owner = In < n1;
+    int64_t b0 = 0, b1 = 0;
+    if (owner) { b0 = nbr_ptr[In]; b1 = nbr_ptr[In + 1]; }
+    double acc = 0.0;
+    for (int64_t t0 = T0; t0 < T1; t0 += MV_CAP) {
+        const int64_t t1 = (t0 + MV_CAP < T1) ? t0 + MV_CAP : T1;
+        for (int64_t t = t0 + tid; t < t1; t += 256) {
+            const int64_t I = blk_row[t], J = nbr[t];
+            const int64_t f0 = nbr_ptr[I];
+            const int64_t L = (nbr_ptr[I + 1] - f0) * D;
+            const double *a = data + f0 * (D * D) + (t - f0) * D;
+            double xv[D], av[D][D];
+            if constexpr ((D & 1) == 0) {
+                for (int c = 0; c < D / 2; c++) {
+                    const double2 v = reinterpret_cast<const double2 *>(x + J * D)[c];
+                    xv[2 * c] = v.x; xv[2 * c + 1] = v.y;
+                }
+                for (int r = 0; r < D; r++)
+                    for (int c = 0; c < D / 2; c++) {
+                        const double2 v = reinterpret_cast<const double2 *>(a + r * L)[c];
+                        av[r][2 * c] = v.x; av[r][2 * c + 1] = v.y;
+                    }
+            } else {
+                for (int c = 0; c < D; c++) xv[c] = x[J * D + c];
+                for (int r = 0; r < D; r++)
+                    for (int c = 0; c < D; c++) av[r][c] = a[r * L + c];
+            }
+            for (int r = 0; r < D; r++) {
+                double v = av[r][0] * xv[0];
+                for (int c = 1; c < D; c++) v = __builtin_fma(av[r][c], xv[c], v);
+                s_p[r * MV_CAP + (int)(t - t0)] = v;
+            }
+        }
+        __syncthreads();
+        if (owner) {
+            const int64_t lo = (b0 > t0) ? b0 : t0, hi = (b1 < t1) ? b1 : t1;
+            for (int64_t t = lo; t < hi; t++) acc += s_p[r_own * MV_CAP + (int)(t - t0)];
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        const int64_t row = In * D + r_own;
+        y[row] = y0 ? acc + y0[row] : acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,6 +346,23 @@ int fs_csr_row_sums(const int64_t *indptr, const double *data, int64_t nrows, do
                        nrows, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FS_OK : fs_fail_(FS_EHIP, "row_sums_kernel", (int)e);
+}
+
+int fs_csr_blk_matvec(const int64_t *nbr_ptr, const int32_t *nbr, const int32_t *blk_row, int64_t n_nodes, int32_t d,
+                      const double *data, const double *x, const double *y0, double *y, void *stream) {
+    if (n_nodes <= 0) return n_nodes == 0 ? FS_OK : fs_fail_(FS_EINVAL, "fs_csr_blk_matvec: n_nodes < 0", 0);
+    if (!nbr_ptr || !nbr || !blk_row || !data || !x || !y) return fs_fail_(FS_EINVAL, "fs_csr_blk_matvec: null argument", 0);
+    if (d != 3 && d != 6) return fs_fail_(FS_EINVAL, "fs_csr_blk_matvec: d must be 3 or 6", 0);
+    if (y == x) return fs_fail_(FS_EINVAL, "fs_csr_blk_matvec: y must not alias x", 0);
+    const unsigned grid = grid_of(n_nodes, MV_NB);
+    if (d == 6)
+        hipLaunchKernelGGL(blk_matvec_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nbr_ptr, nbr, blk_row, n_nodes,
+                           data, x, y0, y);
+    else
+        hipLaunchKernelGGL(blk_matvec_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nbr_ptr, nbr, blk_row, n_nodes,
+                           data, x, y0, y);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FS_OK : fs_fail_(FS_EHIP, "blk_matvec_kernel", (int)e);
 }
 
 int fs_inertial_forces(const double *coords, const double *vel, const double *mass, int64_t N, double omega,

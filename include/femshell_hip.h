@@ -446,6 +446,41 @@ int fs_fused_plan_device_finish(fs_fused_plan_dev *plan, int64_t *pat_eptr, int3
 void fs_fused_plan_device_free(fs_fused_plan_dev *plan);
 
 /*
+ * The Newton path on the ASSEMBLED matrix: K_T(u) = K + sum_e dK_e(u) in one launch (csrc/femshell_fused_nl.hip).
+ * MITC4.compute_tangent_stiffness (elements/MITC4.py:1246-1298, after update_configuration :1067-1084; laminates
+ * MITC4_composite.py:499-621) returns the linear K plus the total-Lagrangian membrane correction T^T sym(K_L + K_sigma) T,
+ * which lives in the translational 3 x 3 sub-blocks only; the loop of core/assembler.py:287-303 then adds the element
+ * matrices.  K does not depend on u, so per Newton iterate this entry point reads the assembled linear matrix k_lin (the
+ * values fs_fused_assemble_quad or fs_csr_numeric_desc wrote: blocks (I,J) and (J,I) transposes of each other bit for
+ * bit), forms the corrections of every element from xyz, u and the property rows (rows with nonlinear == 0 add +0.0), adds
+ * them to the blocks IN ELEMENT ORDER and writes k_t -- no element matrices, 288 B read and 576 B written per node pair.
+ *   conn [E][4] node indices, u [n_nodes][6] nodal displacements (both device); plan arrays, max_patch_elems: the plan
+ *   of fs_fused_assemble_quad (fs_fused_plan_build / fs_fused_plan_device_*; fs_fused_plan_check applies);
+ *   k_lin, k_t [nnz]: k_t may be k_lin itself (the update then happens in place: only blocks with I <= J are read,
+ *   each by the workgroup that writes it); flags: FS_TANGENT_ONE_WG_PER_CU selects the 64-slot variant of the kernel
+ *   (one workgroup per CU) instead of the default (32 staging slots per wave, two workgroups per CU).
+ * Agreement with fs_shell_quad_batch(FS_WANT_KT) + fs_csr_numeric_desc: rounding level (the correction is summed apart
+ * from the linear blocks and evaluated without the cancellation of B~^T C B~ - B_L^T C B_L); same bits in every run.
+ */
+#define FS_TANGENT_ONE_WG_PER_CU 1u
+int fs_fused_assemble_quad_tangent(const double *xyz, const int64_t *conn, const double *u, const int32_t *prop_id,
+                                   const fs_shell_prop *props, int32_t n_props, int64_t E, int64_t n_patches,
+                                   const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
+                                   const fs_fused_rec *recs, int32_t max_patch_elems, const double *k_lin, double *k_t,
+                                   uint32_t flags, void *stream);
+
+/*
+ * The NONLINEAR part of the internal forces of MITC4.compute_internal_forces (elements/MITC4.py:1300-1341 after
+ * update_configuration :1067-1084): fe [E][24] = T^T ( sum_g detJ h (B_L + B_NL)^T C e_GL  -  K_m u_loc ) in the
+ * translational rows of each node, zeros in the rotational rows and for property rows with nonlinear == 0 -- what
+ * fs_shell_quad_batch(FS_WANT_FINT) adds to K_e u_e.  With it  f_int = K u + sum_e fe  needs no element blocks:
+ * fs_csr_blk_matvec on the assembled K (y0 = the element-order sums of fe, fs_vec_gather_sum).  u [n_nodes][6] is
+ * gathered through conn [E][4] (device).  Same kernel as the FS_WANT_FINT path, same bits for these terms.
+ */
+int fs_shell_quad_fint_nl(const double *xyz, const int64_t *conn, const double *u, const int32_t *prop_id,
+                          const fs_shell_prop *props, int32_t n_props, int64_t E, double *fe, void *stream);
+
+/*
  * Fused evaluate-and-assemble, HEXA8 (3 dofs per node, full 2 x 2 x 2 rule): the CSR values of K straight from the
  * coordinates, no element matrices in memory.  Replaces the element evaluations HEXA8.K (elements/SOLID.py:543-567 with
  * _compute_jacobian / compute_B_matrix :164-266 and the rule / shape functions :1744-1818) TOGETHER with the
@@ -638,6 +673,16 @@ int fs_csr_reduce_fill(const int64_t *indptr, const int32_t *indices, const doub
 int fs_expand_solution(const double *u_red, const int32_t *free_rank, const double *u_fixed, int64_t ndof,
                        double *u_full, void *stream);
 int fs_csr_row_sums(const int64_t *indptr, const double *data, int64_t nrows, double *out, void *stream);
+
+/*
+ * y = A x (+ y0, NULL = none) for a matrix in the block layout of fs_csr_pattern_blk (d = 3 or 6 dofs per node; the
+ * arrays of fs_csr_symbolic_finish).  New with the Newton path: the linear part K u of the internal forces
+ * (compute_internal_forces, elements/MITC4.py:1300-1341: f = K u_e + nonlinear membrane terms, summed by the loop of
+ * core/assembler.py) taken from the ASSEMBLED K instead of from 2 880 B of element blocks per element.  One writer per
+ * row, partial products added from left to right: the same bits in every run.  y must not alias x.
+ */
+int fs_csr_blk_matvec(const int64_t *nbr_ptr, const int32_t *nbr, const int32_t *blk_row, int64_t n_nodes, int32_t d,
+                      const double *data, const double *x, const double *y0, double *y, void *stream);
 
 /* f[dof] = sum of fe contributions in element order (core/assembler.py:338-384 and the new
  * assemble_internal_forces): same segmented form as fs_csr_numeric. */

@@ -188,6 +188,10 @@ def test_cache_blocks_false_keeps_no_element_matrices(oracle):
     lazy.check_status()
     u = 1e-3 * torch.from_numpy(np.random.default_rng(0).standard_normal(lazy.dofs_count)).to(lazy.device)
     (KT, f), (KTl, fl) = full.assemble_tangent_and_forces(u), lazy.assemble_tangent_and_forces(u)
+    assert lazy._K_blk is None                             # the Newton path works on the assembled matrix
+    assert bool((_bits(KT.data) == _bits(KTl.data)).all()) and torch.equal(f, fl)
+    full.newton_on_assembled = lazy.newton_on_assembled = False     # the element-block route
+    (KT, f), (KTl, fl) = full.assemble_tangent_and_forces(u), lazy.assemble_tangent_and_forces(u)
     assert lazy._K_blk is not None                         # evaluated on first use
     assert bool((_bits(KT.data) == _bits(KTl.data)).all()) and torch.equal(f, fl)
     assert np.array_equal(full._ke_array[:5], lazy._ke_array[:5])
