@@ -544,14 +544,14 @@ def newton_leg(torch, steps=10):
             u = (field * 1e-3).contiguous()
             k_lin = asm._linear_csr()
             nnz = k_lin.numel()
-            kt_ms = avg_ms(torch, lambda: asm._tangent_on_assembled(u, k_lin), 10)
-            asm.tangent_flags = 1
             kt1_ms = avg_ms(torch, lambda: asm._tangent_on_assembled(u, k_lin), 10)
+            asm.tangent_flags = 1
+            kt_ms = avg_ms(torch, lambda: asm._tangent_on_assembled(u, k_lin), 10)
             asm.tangent_flags = 0
             f_ms = avg_ms(torch, lambda: asm._forces_on_assembled(u, k_lin), 10)
-            # K_T: coordinates, connectivity, u, id, the upper block triangle of K in (half the values + the diagonal
-            # blocks' other half ~ nnz / 2), all values out
-            kt_b = E * (96 + 32 + 48 + 4) + 8 * nnz * 1.5
+            # K_T: coordinates, node ids, u, id and 64-byte plan records per lane in; the packed blocks I <= J of K in;
+            # all values out
+            kt_b = E * (96 + 16 + 48 + 4) + 64 * asm._fplan_d["recs"].numel() // 64 + 8 * 36 * asm._fplan_d["n_upper_blocks"] + 8 * nnz
             f_b = 8 * nnz + E * (96 + 32 + 48 + 4 + 2 * 192) + asm.dofs_count * 8 * 3
             nl_ms = avg_ms(torch, lambda: asm._nl_pass(u, True, True), 5)
             nb = 96 + 4 + 192 + 2880 + 2880 + 192        # coordinates, id, u_e, linear blocks in; K_T blocks, f_int out

@@ -14,7 +14,7 @@ FS_SOLID_STRESS_GP, FS_SOLID_STRESS_MEAN, FS_SOLID_STRESS_NODES = 0, 1, 2
 FS_INERTIAL_CENTRIFUGAL, FS_INERTIAL_CORIOLIS, FS_INERTIAL_EULER = 1, 2, 4
 FS_FUSED_HAS_COUPLED = 1
 FS_FUSED_MASS = 2
-FS_TANGENT_ONE_WG_PER_CU = 1
+FS_TANGENT_TWO_WGS_PER_CU = 1
 FS_FUSED_MAX_PATCH_ELEMS = 64
 FS_HEX_MAX_PATCH_ELEMS, FS_HEX_MAX_PATCH_NODES, FS_HEX_MAX_PATCH_LANES = 100, 64, 512
 
@@ -30,7 +30,9 @@ SIGNATURES = {
     "fs_fused_assemble_quad": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _u32,
                                               _vp, _vp, _vp]),
     "fs_fused_assemble_quad_tangent": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32,
-                                                      _vp, _vp, _u32, _vp]),
+                                                      _vp, _vp, _vp, _u32, _vp]),
+    "fs_fused_tangent_offsets": (ctypes.c_int, [_i64, _vp, _vp, ctypes.POINTER(_i64), _vp]),
+    "fs_fused_tangent_pack": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_shell_quad_fint_nl": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "fs_fused_plan_check": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp]),
     "fs_shell_quad_geom_status": (ctypes.c_int, [_vp, _vp, _i32, _i64, _vp, _vp]),

@@ -15,6 +15,8 @@ thickness, laminate, properties, extra element kwargs), same attributes (`dofs_p
 import warnings
 from typing import Dict, Optional
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -116,6 +118,7 @@ class MeshAssembler:
         self._is_mixed_mesh = False
         self._K_blk = self._M_blk = None
         self._K_lin_csr = None    # values of the assembled linear K the Newton path works on (see _linear_csr)
+        self._K_lin_packed = None # (those values, their packed upper block triangle): see _linear_packed
         self._fplan = self._fplan_d = None
         self._fplan_error = None
         self._precompute_elements()
@@ -660,14 +663,35 @@ class MeshAssembler:
             raise ValueError(f"Expected {self.dofs_count} DOFs, got {u.numel()}")
         return u
 
+    def _linear_packed(self, k_lin):
+        """The blocks I <= J of the linear matrix in the order the plan's waves emit them (fs_fused_tangent_pack): what
+        fs_fused_assemble_quad_tangent reads, made once per evaluation of the linear matrix."""
+        lib, d = _lib.load(), self._fplan_d
+        if self._K_lin_packed is None or self._K_lin_packed[0] is not k_lin:
+            n_recs = int(d["recs"].numel() if d["recs"].dtype != torch.uint8 else d["recs"].numel() // 64)
+            if "wave_off" not in d:
+                d["wave_off"] = torch.empty(n_recs // 64 + 1, dtype=torch.int64, device=self.device)
+                nb = ctypes.c_int64(0)
+                _lib.check(lib.fs_fused_tangent_offsets(n_recs, _lib.ptr(d["recs"]), _lib.ptr(d["wave_off"]),
+                                                        ctypes.byref(nb), _lib.stream_ptr()), "fs_fused_tangent_offsets")
+                d["n_upper_blocks"] = int(nb.value)
+            packed = torch.empty(36 * d["n_upper_blocks"], dtype=torch.float64, device=self.device)
+            _lib.check(lib.fs_fused_tangent_pack(n_recs, _lib.ptr(d["recs"]), _lib.ptr(d["wave_off"]), _lib.ptr(k_lin),
+                                                 _lib.ptr(packed), _lib.stream_ptr()), "fs_fused_tangent_pack")
+            self._K_lin_packed = (k_lin, packed)
+        return self._K_lin_packed[1]
+
     def _tangent_on_assembled(self, u, k_lin) -> CsrMatrix:
         lib, fp, d, g = _lib.load(), self.fused_plan(), self._fplan_d, self._groups[0]
+        if "pat_conn" not in d:       # connectivity rows of the plan's element slots (int32), built once
+            d["pat_conn"] = g["conn_d"][d["pat_elems"].to(torch.int64)].to(torch.int32).contiguous()
+        packed = self._linear_packed(k_lin)
         data = torch.empty(self._plan.nnz, dtype=torch.float64, device=self.device)
         _lib.check(lib.fs_fused_assemble_quad_tangent(
-            _lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+            _lib.ptr(g["xyz_d"]), _lib.ptr(d["pat_conn"]), _lib.ptr(u), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
             len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]), _lib.ptr(d["pat_elems"]),
-            _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]), fp.max_patch_elems, _lib.ptr(k_lin), _lib.ptr(data),
-            self.tangent_flags, _lib.stream_ptr()), "fs_fused_assemble_quad_tangent")
+            _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]), fp.max_patch_elems, _lib.ptr(d["wave_off"]), _lib.ptr(packed),
+            _lib.ptr(data), self.tangent_flags, _lib.stream_ptr()), "fs_fused_assemble_quad_tangent")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
 
     tangent_flags = 0            # FS_TANGENT_* flags of fs_fused_assemble_quad_tangent

@@ -10,14 +10,16 @@
 // the SAME patch plan:
 //   stage 1  lane = (element slot, Gauss point): frame, Jacobian, dN/dx, dN/dy, the displacement gradient H (GLOBAL
 //            components, local derivatives, MITC4.py:1092-1107) and the centre membrane stress -> LDS image of 72 doubles
-//            per element; u of the element's nodes is gathered through the connectivity (no u_e array);
+//            per element; u of the element's nodes is gathered through the plan's copy of the connectivity rows (no u_e array);
 //   stage 2  a lane forms up to two contributions (element, local node pair): with P_i = [[nx,0],[0,ny],[ny,nx]],
 //            M = P_i^T (detJ h C) P_j (2 x 2), F = [I2;0] + H the reference's  B~_i^T C B~_j - B_L,i^T C B_L,j  is
 //            H M F^T + [I2;0] M H^T (no cancellation), + K_sigma on the diagonal, summed over the Gauss points, rotated
 //            R^T X R; the contributions of a CSR block are added IN ELEMENT ORDER (DPP chains of the plan);
-//   stores   the blocks (I, J), I <= J, of the linear matrix are read in address order ahead of the evaluations, meet the
-//            corrections in the wave's staging area and leave as block (I, J) and, transposed, as block (J, I): 288 B
-//            read and 576 B written per block pair, no element matrices, no second pass over the matrix.
+//   stores   the blocks (I, J), I <= J, of the linear matrix are read ahead of the evaluations from a PACKED copy (36
+//            contiguous doubles per block, in the plan's slot order: fs_fused_tangent_pack, once per linear matrix --
+//            reading them from the CSR rows themselves costs 1.75 x the bytes, half-used lines), meet the corrections in
+//            the wave's staging area and leave as block (I, J) and, transposed, as block (J, I): 288 B read and 576 B
+//            written per block pair, no element matrices, no second pass over the matrix.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -25,6 +27,7 @@
 #include "femshell_hip.h"
 #include "femshell_internal.h"
 #include "femshell_geom.h"
+#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
@@ -115,11 +118,13 @@ __device__ __forceinline__ void dkt_eval(uint32_t ev, const double *lds, const i
 // SP staging slots per wave: 64 -> one workgroup per CU, 32 -> two
 template <int SP>
 __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel(
-    const double *__restrict__ xyz, const int64_t *__restrict__ conn, const double *__restrict__ u,
+    const double *__restrict__ xyz, const int4 *__restrict__ pat_conn, const double *__restrict__ u,
     const int32_t *__restrict__ prop_id, const fs_shell_prop *__restrict__ props, int32_t n_props, int64_t n_pat,
     const int64_t *__restrict__ pat_eptr, const int32_t *__restrict__ pat_elems, const int64_t *__restrict__ pat_rptr,
-    const fs_fused_rec *__restrict__ recs, const double *base, double *data) {
+    const fs_fused_rec *__restrict__ recs, const int64_t *__restrict__ wave_off, const double *__restrict__ packed,
+    double *__restrict__ data) {
     constexpr int NQ = (3 * SP + 63) / 64;          // direct-copy pieces per lane and pass
+    constexpr int NB = (18 * SP + 63) / 64;         // 16-byte pieces of the pass's linear blocks per lane
     __shared__ double lds[4 * NL_TILE];
     __shared__ int s_pid[64];
     __shared__ double2 s_stage[4 * NZ_SLOT * SP];
@@ -133,10 +138,56 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
     double2 *stg = s_stage + wave * (NZ_SLOT * SP);
     unsigned char *tab = s_tab + wave * 128;
 
-    for (int64_t p = xcd * per_xcd + (blockIdx.x >> 3); p < pend; p += wpx) {
-        const int64_t e0 = pat_eptr[p];
-        const int ne = (int)(pat_eptr[p + 1] - e0);
-        const int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
+    int64_t p = xcd * per_xcd + (blockIdx.x >> 3);
+    if (p >= pend) return;
+    // inputs of an element slot: coordinates, property id, u of its four nodes (ids from the plan's copy of the
+    // connectivity rows, so that they arrive together with the element index: two dependent loads, not three)
+    auto fetch_inputs = [&](int64_t e, int4 nid, double (&xo)[12], double (&uo)[24], int &pido) __attribute__((always_inline)) {
+        const double2 *xp = reinterpret_cast<const double2 *>(xyz + e * 12);
+        for (int t = 0; t < 6; t++) { const double2 v = xp[t]; xo[2 * t] = v.x; xo[2 * t + 1] = v.y; }
+        const int nn[4] = {nid.x, nid.y, nid.z, nid.w};
+        for (int i = 0; i < 4; i++) {
+            const double2 *up = reinterpret_cast<const double2 *>(u + (int64_t)nn[i] * 6);
+            for (int t = 0; t < 3; t++) { const double2 v = up[t]; uo[6 * i + 2 * t] = v.x; uo[6 * i + 2 * t + 1] = v.y; }
+        }
+        pido = prop_id[e];
+    };
+    // PF (one workgroup per CU): headers travel two patches ahead, element / node ids one patch ahead (fetched at the top
+    // of the current patch), coordinates / u / property id of the next patch are requested after stage 1 and arrive under
+    // stage 2.  Two workgroups per CU fetch on the spot (the other workgroup covers the latency; no registers to spare).
+    constexpr bool PF = SP > 32;
+    int64_t e0 = pat_eptr[p];
+    int ne = (int)(pat_eptr[p + 1] - e0);
+    int64_t r0 = pat_rptr[p], r1 = pat_rptr[p + 1];
+    int64_t e0n = e0, r0n = r0, r1n = r1;
+    int nen = ne;
+    double xc[12], uc[24];
+    int pidc = 0;
+    if constexpr (PF) {
+        if (p + wpx < pend) {
+            e0n = pat_eptr[p + wpx]; nen = (int)(pat_eptr[p + wpx + 1] - e0n);
+            r0n = pat_rptr[p + wpx]; r1n = pat_rptr[p + wpx + 1];
+        }
+        const int64_t si = e0 + ((slot < ne) ? slot : ne - 1);
+        fetch_inputs(pat_elems[si], pat_conn[si], xc, uc, pidc);
+    }
+    for (;;) {
+        const int64_t pn = p + wpx, pnn = pn + wpx;
+        const bool more = pn < pend;
+        int64_t e0nn = 0, r0nn = 0, r1nn = 0, en = 0;
+        int nenn = 0;
+        int4 nidn = make_int4(0, 0, 0, 0);
+        if constexpr (PF) {
+            // (unconditional loads from clamped indices: a load inside a branch is waited for at the end of the branch)
+            const int64_t sn = more ? e0n + ((slot < nen) ? slot : nen - 1) : e0;
+            en = pat_elems[sn]; nidn = pat_conn[sn];
+            const int64_t pq = (pnn < pend) ? pnn : p;
+            e0nn = pat_eptr[pq]; nenn = (int)(pat_eptr[pq + 1] - e0nn);
+            r0nn = pat_rptr[pq]; r1nn = pat_rptr[pq + 1];
+        } else {
+            e0 = pat_eptr[p]; ne = (int)(pat_eptr[p + 1] - e0);
+            r0 = pat_rptr[p]; r1 = pat_rptr[p + 1];
+        }
         // this lane's record of the first round: requested now, used after stage 1
         int4 pa = make_int4(-1, -1, -1, -1), pb = pa, pc4 = make_int4(0, 0, 0, 0), pd = make_int4(0, 0, 0, -1);
         if (r0 + tid < r1) {
@@ -146,20 +197,14 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
         // ---------------- stage 1 ----------------
         if (wave * 16 < ne) {
 #pragma clang fp contract(fast)
-            const int64_t e = pat_elems[e0 + ((slot < ne) ? slot : ne - 1)];
-            double x[4][3], ue[4][6];
-            {
-                const double2 *xp = reinterpret_cast<const double2 *>(xyz + e * 12);
-                for (int t = 0; t < 6; t++) { const double2 v = xp[t]; (&x[0][0])[2 * t] = v.x; (&x[0][0])[2 * t + 1] = v.y; }
-                const longlong2 *cp = reinterpret_cast<const longlong2 *>(conn + e * 4);
-                const longlong2 c01 = cp[0], c23 = cp[1];
-                const int64_t nid[4] = {c01.x, c01.y, c23.x, c23.y};
-                for (int i = 0; i < 4; i++) {
-                    const double2 *up = reinterpret_cast<const double2 *>(u + nid[i] * 6);
-                    for (int t = 0; t < 3; t++) { const double2 v = up[t]; ue[i][2 * t] = v.x; ue[i][2 * t + 1] = v.y; }
-                }
+            if constexpr (!PF) {
+                const int64_t si = e0 + ((slot < ne) ? slot : ne - 1);
+                fetch_inputs(pat_elems[si], pat_conn[si], xc, uc, pidc);
             }
-            const int pid = safe_pid(prop_id[e], n_props);
+            double x[4][3], ue[4][6];
+            for (int t = 0; t < 12; t++) (&x[0][0])[t] = xc[t];
+            for (int t = 0; t < 24; t++) (&ue[0][0])[t] = uc[t];
+            const int pid = safe_pid(pidc, n_props);
             const fs_shell_prop *pr = props + pid;
             QuadGeom geo;
             quad_geometry(x, geo);
@@ -223,6 +268,16 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
                 for (int t = 0; t < 3; t++) ee[(NL_SM + t) << 4] = nonlinear ? Sm[t] : 0.0;
             }
         }
+        // inputs of the next patch: its ids have arrived under stage 1 (the empty asm keeps the address arithmetic, and
+        // with it the wait for the ids, from moving to the top of the loop); they arrive under stage 2
+        double xn[12], un[24];
+        int pidn = 0;
+        if constexpr (PF) {
+            int64_t en_use = en;
+            int4 nid_use = nidn;
+            asm volatile("" : "+v"(en_use), "+v"(nid_use.x), "+v"(nid_use.y), "+v"(nid_use.z), "+v"(nid_use.w));
+            fetch_inputs(en_use, nid_use, xn, un, pidn);
+        }
         __syncthreads();
 
         // ---------------- stage 2 ----------------
@@ -269,30 +324,27 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             };
-            // the linear blocks (I, J) of the pass, in address order: lane <-> 48-byte row piece (unconditional loads from
-            // clamped addresses: a load inside a branch is waited for at the end of the branch)
-            double bvx[NQ][6], bvy[NQ][6];     // (scalars: an array of double2 filled from memory stays an alloca)
+            // the linear blocks (I, J), I <= J, of the wave's pass: 36 contiguous doubles each, in slot order, in the PACKED
+            // copy of the linear matrix (fs_fused_tangent_pack) -- lane <-> 16-byte piece, whole lines, no address needed
+            // (unconditional loads from clamped indices: a load inside a branch is waited for at the end of the branch)
+            double bvx[NB], bvy[NB];           // (scalars: an array of double2 filled from memory stays an alloca)
+            const int64_t wv = (rb >> 6) + ((rb + 64 * wave < r1) ? wave : 0);      // this wave of records (clamped: a patch's
+                                                                                   // last round may have fewer than four)
+            const double2 *pk = reinterpret_cast<const double2 *>(packed) + wave_off[wv] * 18;
             auto load_base = [&](int s0) __attribute__((always_inline)) {
                 const int nhere = (nd - s0 < SP) ? nd - s0 : SP;
-                for (int q = 0; q < NQ; q++) {
-                    const int pc = q * 64 + lane;
-                    const bool ok = pc < 3 * nhere;
-                    const int bk = ok ? (pc * 21846) >> 16 : 0, cc = pc - 3 * ((pc * 21846) >> 16);
-                    const double2 t = stg[bk * NZ_SLOT + 18];
-                    const int64_t d0 = ok ? (int64_t)__double_as_longlong(t.x) : 0;
-                    const int64_t str = ok ? (int64_t)__double_as_longlong(t.y) : 0;
-                    const double *d = base + d0 + 2 * cc;
-                    for (int k = 0; k < 6; k++) {
-                        const double2 t2 = *reinterpret_cast<const double2 *>(d + k * str);
-                        bvx[q][k] = t2.x; bvy[q][k] = t2.y;
-                    }
+                const double2 *pp = pk + (int64_t)s0 * 18;
+                for (int q = 0; q < NB; q++) {
+                    const int j = q * 64 + lane;
+                    const double2 t2 = pp[(j < 18 * nhere) ? j : 0];
+                    bvx[q] = t2.x; bvy[q] = t2.y;
                 }
             };
             // ---- passes over the wave's blocks: linear block + correction -> staging -> (I, J) and (J, I) ----
             double X[9], Y[9];
             for (int s0 = 0; s0 < nd; s0 += SP) {       // (a wave without output blocks has nothing to evaluate)
-                stage_addresses(s0);
                 load_base(s0);
+                stage_addresses(s0);
                 if (s0 == 0) {
                 // ---- the lane's two contributions, element-order sums (as fused_quad_k_kernel, on 9 values) ----
                 const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
@@ -318,13 +370,10 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
                 }
                 }
                 const int nhere = (nd - s0 < SP) ? nd - s0 : SP;
-                for (int q = 0; q < NQ; q++) {
-                    const int pc = q * 64 + lane;
-                    const int bk = (pc * 21846) >> 16, cc = pc - 3 * bk;
-                    if (pc < 3 * nhere) {
-                        double2 *sp = stg + bk * NZ_SLOT;
-                        for (int k = 0; k < 6; k++) sp[k * 3 + cc] = make_double2(bvx[q][k], bvy[q][k]);
-                    }
+                for (int q = 0; q < NB; q++) {
+                    const int j = q * 64 + lane;
+                    const int bk = (j * 3641) >> 16;            // j / 18 for j < 18 * 64
+                    if (j < 18 * nhere) stg[bk * NZ_SLOT + (j - 18 * bk)] = make_double2(bvx[q], bvy[q]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -381,36 +430,113 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (!more) break;
         __syncthreads();        // every wave is done with the image
+        p = pn;
+        if constexpr (PF) {
+            e0 = e0n; ne = nen; r0 = r0n; r1 = r1n;
+            e0n = e0nn; nen = nenn; r0n = r0nn; r1n = r1nn;
+            for (int t = 0; t < 12; t++) xc[t] = xn[t];
+            for (int t = 0; t < 24; t++) uc[t] = un[t];
+            pidc = pidn;
+        }
+    }
+}
+
+// number of output blocks (I <= J) of every wave-round of the plan
+__global__ __launch_bounds__(256) void tangent_count_kernel(const fs_fused_rec *__restrict__ recs, int64_t n_waves,
+                                                            int64_t *__restrict__ counts) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const uint32_t fl = recs[w * 64 + (threadIdx.x & 63)].flags;
+    const int n = __popcll(__ballot((fl & FS_FL_OUT0) != 0)) + __popcll(__ballot((fl & FS_FL_OUT1) != 0));
+    if ((threadIdx.x & 63) == 0) counts[w] = n;
+}
+
+// packed[wave_off[w] + slot] = block (I, J) of the CSR values, row-major 6 x 6
+__global__ __launch_bounds__(256) void tangent_pack_kernel(const fs_fused_rec *__restrict__ recs, int64_t n_waves,
+                                                           const int64_t *__restrict__ wave_off,
+                                                           const double *__restrict__ data, double *__restrict__ packed) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const fs_fused_rec r = recs[w * 64 + (threadIdx.x & 63)];
+    const int64_t off = wave_off[w];
+    for (int o = 0; o < 2; o++) {
+        if (!(r.flags & (o ? FS_FL_OUT1 : FS_FL_OUT0))) continue;
+        const int slot = (int)((r.slots >> (16 * o)) & 255u);
+        const double *src = data + r.dst[o];
+        double2 *dst = reinterpret_cast<double2 *>(packed + (off + slot) * 36);
+        for (int k = 0; k < 6; k++)
+            for (int c = 0; c < 3; c++) dst[k * 3 + c] = *reinterpret_cast<const double2 *>(src + (int64_t)k * r.stride[o] + 2 * c);
     }
 }
 
 }  // namespace
 
-extern "C" int fs_fused_assemble_quad_tangent(const double *xyz, const int64_t *conn, const double *u, const int32_t *prop_id,
+extern "C" int fs_fused_tangent_offsets(int64_t n_recs, const fs_fused_rec *recs, int64_t *wave_off, int64_t *n_blocks,
+                                        void *stream) {
+    if (!n_blocks) return fs_fail_(FS_EINVAL, "fs_fused_tangent_offsets: null output", 0);
+    *n_blocks = 0;
+    if (n_recs < 0 || (n_recs & 63)) return fs_fail_(FS_EINVAL, "fs_fused_tangent_offsets: the records of a plan are whole waves", 0);
+    if (!wave_off || (n_recs && !recs)) return fs_fail_(FS_EINVAL, "fs_fused_tangent_offsets: null argument", 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nw = n_recs >> 6;
+    hipError_t e = hipMemsetAsync(wave_off + nw, 0, sizeof(int64_t), s);
+    if (e == hipSuccess && nw) {
+        hipLaunchKernelGGL(tangent_count_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, recs, nw, wave_off);
+        e = hipGetLastError();
+    }
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    if (e == hipSuccess)
+        e = rocprim::exclusive_scan(nullptr, tmp_bytes, wave_off, wave_off, (int64_t)0, (size_t)(nw + 1), rocprim::plus<int64_t>(), s);
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+    if (e == hipSuccess)
+        e = rocprim::exclusive_scan(tmp, tmp_bytes, wave_off, wave_off, (int64_t)0, (size_t)(nw + 1), rocprim::plus<int64_t>(), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(n_blocks, wave_off + nw, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "fs_fused_tangent_offsets", (int)e);
+    return FS_OK;
+}
+
+extern "C" int fs_fused_tangent_pack(int64_t n_recs, const fs_fused_rec *recs, const int64_t *wave_off, const double *k_lin,
+                                     double *packed, void *stream) {
+    if (n_recs < 0 || (n_recs & 63)) return fs_fail_(FS_EINVAL, "fs_fused_tangent_pack: the records of a plan are whole waves", 0);
+    if (n_recs == 0) return FS_OK;
+    if (!recs || !wave_off || !k_lin || !packed) return fs_fail_(FS_EINVAL, "fs_fused_tangent_pack: null argument", 0);
+    const int64_t nw = n_recs >> 6;
+    hipLaunchKernelGGL(tangent_pack_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, (hipStream_t)stream, recs, nw, wave_off,
+                       k_lin, packed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "tangent_pack_kernel", (int)e);
+    return FS_OK;
+}
+
+extern "C" int fs_fused_assemble_quad_tangent(const double *xyz, const int32_t *pat_conn, const double *u, const int32_t *prop_id,
                                               const fs_shell_prop *props, int32_t n_props, int64_t E, int64_t n_patches,
                                               const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
-                                              const fs_fused_rec *recs, int32_t max_patch_elems, const double *k_lin,
-                                              double *k_t, uint32_t flags, void *stream) {
+                                              const fs_fused_rec *recs, int32_t max_patch_elems, const int64_t *wave_off,
+                                              const double *k_lin_packed, double *k_t, uint32_t flags, void *stream) {
     if (E < 0 || n_props <= 0 || n_patches < 0) return fs_fail_(FS_EINVAL, "fs_fused_assemble_quad_tangent: bad sizes", 0);
     if (E == 0 || n_patches == 0) return FS_OK;
-    if (!xyz || !conn || !u || !prop_id || !props || !pat_eptr || !pat_elems || !pat_rptr || !recs || !k_lin || !k_t)
+    if (!xyz || !pat_conn || !u || !prop_id || !props || !pat_eptr || !pat_elems || !pat_rptr || !recs || !wave_off || !k_lin_packed || !k_t)
         return fs_fail_(FS_EINVAL, "fs_fused_assemble_quad_tangent: null argument", 0);
     if (max_patch_elems <= 0 || max_patch_elems > FS_FUSED_MAX_PATCH_ELEMS)
         return fs_fail_(FS_EINVAL, "fs_fused_assemble_quad_tangent: a patch may hold at most FS_FUSED_MAX_PATCH_ELEMS elements", 0);
     int cus = 0;
     if (int rc = fs_device_cu_count_(&cus)) return rc;
-    const int per_cu = (flags & 1u) ? 1 : 2;
+    const int per_cu = (flags & FS_TANGENT_TWO_WGS_PER_CU) ? 2 : 1;
     int64_t wgs = ((int64_t)cus * per_cu / 8) * 8;
     if (wgs < 8) wgs = 8;
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
     if (per_cu == 1)
-        hipLaunchKernelGGL(fused_quad_dkt_kernel<64>, dim3((unsigned)wgs), dim3(256), 0, s, xyz, conn, u, prop_id, props, n_props,
-                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, k_lin, k_t);
+        hipLaunchKernelGGL(fused_quad_dkt_kernel<64>, dim3((unsigned)wgs), dim3(256), 0, s, xyz, reinterpret_cast<const int4 *>(pat_conn), u, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, wave_off, k_lin_packed, k_t);
     else
-        hipLaunchKernelGGL(fused_quad_dkt_kernel<32>, dim3((unsigned)wgs), dim3(256), 0, s, xyz, conn, u, prop_id, props, n_props,
-                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, k_lin, k_t);
+        hipLaunchKernelGGL(fused_quad_dkt_kernel<32>, dim3((unsigned)wgs), dim3(256), 0, s, xyz, reinterpret_cast<const int4 *>(pat_conn), u, prop_id, props, n_props,
+                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, wave_off, k_lin_packed, k_t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_quad_dkt_kernel", (int)e);
     return FS_OK;

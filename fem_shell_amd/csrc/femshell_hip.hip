@@ -1318,19 +1318,20 @@ constexpr int NLT_DL = NLT_STG + 32 * STG_SLOT;     // dL[p][k][l][Q]: 90 x 16
 constexpr int NLT_F = NLT_DL + 90 * 16;             // f[node][a][Q]: 24 x 16
 constexpr int NLT_LDS = NLT_F + 24 * 16;
 
+template <bool STREAM>
 __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__restrict__ xyz,
                                                             const int32_t *__restrict__ prop_id,
                                                             const fs_shell_prop *__restrict__ props, int32_t n_props,
                                                             const double *__restrict__ ue, int64_t E,
                                                             const double *k0, double *kt, int want_kt,
                                                             double *__restrict__ fe,
-                                                            const int64_t *__restrict__ conn = nullptr,
-                                                            const double *__restrict__ u_nodes = nullptr) {
+                                                            const int64_t *__restrict__ conn,
+                                                            const double *__restrict__ u_nodes) {
     // k0: the linear blocks K (read); kt: K_T (written when want_kt).  They may be the same buffer (in place).
-    // k0 == nullptr (fs_shell_quad_fint_nl): no blocks are streamed, fe receives the NONLINEAR part of the internal
-    // forces only (the caller adds K u from the assembled matrix).  conn / u_nodes: gather the nodal displacements
-    // through the connectivity instead of reading ue.
-    __shared__ double lds[NLT_LDS];
+    // STREAM == false (fs_shell_quad_fint_nl): no blocks are streamed and no LDS is held (more waves per CU), fe receives
+    // the NONLINEAR part of the internal forces only (the caller adds K u from the assembled matrix).  conn / u_nodes:
+    // gather the nodal displacements through the connectivity instead of reading ue.
+    __shared__ double lds[STREAM ? NLT_LDS : 16];
     const int lane = threadIdx.x;
     const int Q = lane >> 2, g = lane & 3;
     const int64_t e_raw = (int64_t)blockIdx.x * 16 + Q;
@@ -1362,9 +1363,10 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
     double fnl[3] = {0.0, 0.0, 0.0};    // nonlinear part of f for node g (global axes)
     {
 #pragma clang fp contract(fast)
-        if (want_kt)
+        if (STREAM && want_kt)
             for (int t = 0; t < 90; t++) if ((t & 3) == g) lds[NLT_DL + (t << 4) + Q] = 0.0;
-        for (int t = 0; t < 6; t++) lds[NLT_F + ((g * 6 + t) << 4) + Q] = 0.0;
+        if constexpr (STREAM)
+            for (int t = 0; t < 6; t++) lds[NLT_F + ((g * 6 + t) << 4) + Q] = 0.0;
         if (nonlinear) {
             const double h = pr->h;
             double C[3][3];
@@ -1433,7 +1435,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
                 for (int k = 0; k < 3; k++)
                     fm[i][k] = quad_sum(wh * (Bt[i][0][k] * sg[0] + Bt[i][1][k] * sg[1] + Bt[i][2][k] * sg[2]));
             }
-            if (want_kt) {   // K_L + K_sigma, translational sub-blocks of the pairs i <= j (local axes) -> LDS
+            if (STREAM && want_kt) {   // K_L + K_sigma, translational sub-blocks of the pairs i <= j (local axes) -> LDS
                 for (int i = 0; i < 4; i++)
                     for (int j = i; j < 4; j++) {
                         const int p = pidx[i][j];
@@ -1503,9 +1505,9 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
             }
         }
     }
-    __syncthreads();
+    if constexpr (STREAM) __syncthreads();
     // ---- stream the tile: K u (linear blocks) and K_T = K + R^T sym(dL) R ----
-    for (int round = 0; round < (k0 ? 3 : 0); round++) {
+    for (int round = 0; round < (STREAM ? 3 : 0); round++) {
 #pragma clang fp contract(fast)
         int ti, tj;
         if (round == 0) { ti = g; tj = g; }
@@ -1584,7 +1586,7 @@ __global__ __launch_bounds__(64) void mitc4_nl_tiled_kernel(const double *__rest
     }
     if (fe && valid) {
         for (int a = 0; a < 6; a++) {
-            const double v = lds[NLT_F + ((g * 6 + a) << 4) + Q] + ((a < 3) ? fnl[a] : 0.0);
+            const double v = (STREAM ? lds[NLT_F + ((g * 6 + a) << 4) + Q] : 0.0) + ((a < 3) ? fnl[a] : 0.0);
             fe[e * 24 + 6 * g + a] = v;
         }
     }
@@ -2876,8 +2878,9 @@ int fs_shell_quad_batch(const double *xyz, const int32_t *prop_id, const fs_shel
             FS_LAUNCH_CHECK("mitc4_k_kernel");
         }
         if (tiled)
-            hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E,
-                               k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr);
+            hipLaunchKernelGGL(mitc4_nl_tiled_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E,
+                               k_cached ? Ke : KTe, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr,
+                               (const int64_t *)nullptr, (const double *)nullptr);
         else
             hipLaunchKernelGGL(mitc4_nl_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e,
                                E, KTe, (want & FS_WANT_KT) ? 1 : 0, (want & FS_WANT_FINT) ? fe : nullptr, tiled, nullptr);
@@ -3328,7 +3331,8 @@ int fs_shell_quad_fint_noalloc(const double *xyz, const int32_t *prop_id, const 
     // before the force kernel reads it, so nothing of the previous call's contents has to be cleared
     hipLaunchKernelGGL(mitc4_k_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, E, ws, status);
     FS_LAUNCH_CHECK("mitc4_k_kernel");
-    hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E, ws, ws, 0, fe);
+    hipLaunchKernelGGL(mitc4_nl_tiled_kernel<true>, dim3(grid), dim3(64), 0, s, xyz, prop_id, props, n_props, u_e, E, ws, ws, 0, fe,
+                       (const int64_t *)nullptr, (const double *)nullptr);
     FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
     return check_props(prop_id, E, n_props, status, 0, s);
 }
@@ -3338,7 +3342,7 @@ int fs_shell_quad_fint_nl(const double *xyz, const int64_t *conn, const double *
     if (E < 0 || n_props <= 0) return fail(FS_EINVAL, "fs_shell_quad_fint_nl: bad sizes");
     if (E == 0) return FS_OK;
     if (!xyz || !conn || !u || !prop_id || !props || !fe) return fail(FS_EINVAL, "fs_shell_quad_fint_nl: null argument");
-    hipLaunchKernelGGL(mitc4_nl_tiled_kernel, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, (hipStream_t)stream, xyz, prop_id,
+    hipLaunchKernelGGL(mitc4_nl_tiled_kernel<false>, dim3((unsigned)((E + 15) / 16)), dim3(64), 0, (hipStream_t)stream, xyz, prop_id,
                        props, n_props, (const double *)nullptr, E, (const double *)nullptr, (double *)nullptr, 0, fe, conn, u);
     FS_LAUNCH_CHECK("mitc4_nl_tiled_kernel");
     return FS_OK;

@@ -450,24 +450,37 @@ void fs_fused_plan_device_free(fs_fused_plan_dev *plan);
  * MITC4.compute_tangent_stiffness (elements/MITC4.py:1246-1298, after update_configuration :1067-1084; laminates
  * MITC4_composite.py:499-621) returns the linear K plus the total-Lagrangian membrane correction T^T sym(K_L + K_sigma) T,
  * which lives in the translational 3 x 3 sub-blocks only; the loop of core/assembler.py:287-303 then adds the element
- * matrices.  K does not depend on u, so per Newton iterate this entry point reads the assembled linear matrix k_lin (the
- * values fs_fused_assemble_quad or fs_csr_numeric_desc wrote: blocks (I,J) and (J,I) transposes of each other bit for
- * bit), forms the corrections of every element from xyz, u and the property rows (rows with nonlinear == 0 add +0.0), adds
- * them to the blocks IN ELEMENT ORDER and writes k_t -- no element matrices, 288 B read and 576 B written per node pair.
- *   conn [E][4] node indices, u [n_nodes][6] nodal displacements (both device); plan arrays, max_patch_elems: the plan
- *   of fs_fused_assemble_quad (fs_fused_plan_build / fs_fused_plan_device_*; fs_fused_plan_check applies);
- *   k_lin, k_t [nnz]: k_t may be k_lin itself (the update then happens in place: only blocks with I <= J are read,
- *   each by the workgroup that writes it); flags: FS_TANGENT_ONE_WG_PER_CU selects the 64-slot variant of the kernel
- *   (one workgroup per CU) instead of the default (32 staging slots per wave, two workgroups per CU).
+ * matrices.  K does not depend on u, so per Newton iterate fs_fused_assemble_quad_tangent reads the blocks (I,J), I <= J,
+ * of the assembled linear matrix, forms the corrections of every element from xyz, u and the property rows (rows with
+ * nonlinear == 0 add +0.0), adds them to the blocks IN ELEMENT ORDER and writes block (I,J) and its transpose (J,I) of
+ * k_t -- no element matrices, 288 B read and 576 B written per node pair.
+ *
+ * The linear blocks come from a PACKED copy (36 contiguous doubles per block, in the order the plan's waves emit them),
+ * made once per linear matrix:
+ *   fs_fused_tangent_offsets  wave_off [n_recs / 64 + 1] (device, out): first packed block of every wave of records;
+ *                             n_blocks (host, out): number of blocks I <= J.  Once per plan; synchronises `stream`,
+ *                             allocates and frees scan work space.
+ *   fs_fused_tangent_pack     packed [36 * n_blocks] (device, out) from the CSR values k_lin (fs_fused_assemble_quad or
+ *                             fs_csr_numeric_desc; K is symmetric, only its blocks I <= J are read).
+ *   fs_fused_assemble_quad_tangent
+ *     u [n_nodes][6] nodal displacements; plan arrays, max_patch_elems: the plan of fs_fused_assemble_quad
+ *     (fs_fused_plan_build / fs_fused_plan_device_*; fs_fused_plan_check applies);  pat_conn [n_elem_slots][4] int32: the
+ *     connectivity rows of the plan's element slots, pat_conn[s] = conn[pat_elems[s]] (the node ids of a patch arrive with
+ *     its element indices: one dependent load less in front of the gather of u);  k_t [nnz] out;
+ *     flags: FS_TANGENT_TWO_WGS_PER_CU selects the 32-slot variant of the kernel (two workgroups per CU; measured slower).
  * Agreement with fs_shell_quad_batch(FS_WANT_KT) + fs_csr_numeric_desc: rounding level (the correction is summed apart
- * from the linear blocks and evaluated without the cancellation of B~^T C B~ - B_L^T C B_L); same bits in every run.
+ * from the linear blocks and evaluated without the cancellation of B~^T C B~ - B_L^T C B_L); k_t is exactly symmetric; the
+ * same bits in every run.  All three: no counterpart in the reference beyond the lines cited (its loop needs no plan).
  */
-#define FS_TANGENT_ONE_WG_PER_CU 1u
-int fs_fused_assemble_quad_tangent(const double *xyz, const int64_t *conn, const double *u, const int32_t *prop_id,
+#define FS_TANGENT_TWO_WGS_PER_CU 1u
+int fs_fused_tangent_offsets(int64_t n_recs, const fs_fused_rec *recs, int64_t *wave_off, int64_t *n_blocks, void *stream);
+int fs_fused_tangent_pack(int64_t n_recs, const fs_fused_rec *recs, const int64_t *wave_off, const double *k_lin,
+                          double *packed, void *stream);
+int fs_fused_assemble_quad_tangent(const double *xyz, const int32_t *pat_conn, const double *u, const int32_t *prop_id,
                                    const fs_shell_prop *props, int32_t n_props, int64_t E, int64_t n_patches,
                                    const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
-                                   const fs_fused_rec *recs, int32_t max_patch_elems, const double *k_lin, double *k_t,
-                                   uint32_t flags, void *stream);
+                                   const fs_fused_rec *recs, int32_t max_patch_elems, const int64_t *wave_off,
+                                   const double *k_lin_packed, double *k_t, uint32_t flags, void *stream);
 
 /*
  * The NONLINEAR part of the internal forces of MITC4.compute_internal_forces (elements/MITC4.py:1300-1341 after

@@ -65,7 +65,7 @@ def test_tangent_and_forces_on_assembled_matrix_vs_element_block_route(name):
     K2, f2 = asm.assemble_tangent_and_forces(u)
     asm.newton_on_assembled = True
     K = asm.assemble_stiffness_matrix(recompute=True)
-    for flags in (0, _lib.FS_TANGENT_ONE_WG_PER_CU):
+    for flags in (0, _lib.FS_TANGENT_TWO_WGS_PER_CU):
         asm.tangent_flags = flags
         KT, f = asm.assemble_tangent_and_forces(u)
         torch.cuda.synchronize()
@@ -90,16 +90,8 @@ def test_tangent_and_forces_on_assembled_matrix_vs_element_block_route(name):
     # u = 0: the tangent is the linear matrix, the force vanishes
     KT0, f0 = asm.assemble_tangent_and_forces(torch.zeros_like(u))
     assert bool((KT0.data == K.data).all()) and float(f0.abs().max()) == 0.0
-    # in place: k_t may be k_lin
-    lib, fp, d, g = _lib.load(), asm.fused_plan(), asm._fplan_d, asm._groups[0]
-    inpl = K.data.clone()
-    _lib.check(lib.fs_fused_assemble_quad_tangent(
-        _lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]), _lib.ptr(asm._props_d),
-        len(asm._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]), _lib.ptr(d["pat_elems"]),
-        _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]), fp.max_patch_elems, _lib.ptr(inpl), _lib.ptr(inpl), 0,
-        _lib.stream_ptr()), "tangent in place")
-    torch.cuda.synchronize()
-    assert bool((_bits(inpl) == _bits(KT.data)).all())
+    # the packed copy of the linear blocks follows the linear matrix
+    assert asm._K_lin_packed is not None and asm._K_lin_packed[0] is asm._K_lin_csr
 
 
 def test_tangent_and_forces_on_assembled_matrix_vs_oracle(oracle):

@@ -20,23 +20,22 @@ for nx, ny in sizes:
     field[:, 0] = 0.01 * xs * ys; field[:, 1] = -0.02 * ys + 0.003 * xs
     field[:, 2] = xs ** 2 / 100.0; field[:, 4] = -2.0 * xs / 100.0
     u = (field * 0.3).reshape(-1).contiguous()
+    asm.newton_on_assembled = False
     KT_ref = asm.assemble_tangent_stiffness(u)
+    asm.newton_on_assembled = True
     K = asm.assemble_stiffness_matrix(recompute=True)
+    asm._tangent_on_assembled(u, K.data)          # builds pat_conn
     fp = asm.fused_plan(); d = asm._fplan_d; g = asm._groups[0]
     out = torch.empty_like(K.data)
-    for flags in (1, 0):
-        def run():
-            _lib.check(lib.fs_fused_assemble_quad_tangent(
-                _lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]), _lib.ptr(asm._props_d),
-                len(asm._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]), _lib.ptr(d["pat_elems"]),
-                _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]), fp.max_patch_elems, _lib.ptr(K.data), _lib.ptr(out), flags,
-                _lib.stream_ptr()), "tangent")
-        out.fill_(float("nan"))
-        run(); torch.cuda.synchronize()
+    for flags in (0, 1):
+        asm.tangent_flags = flags
+        run = lambda: asm._tangent_on_assembled(u, K.data)
+        out = run().data; torch.cuda.synchronize()
         ref = KT_ref.data
         err = (out - ref).abs().max().item() / ref.abs().max().item()
         dk = (ref - K.data).abs().max().item() / ref.abs().max().item()
         ms = bench.avg_ms(torch, run, 20)
         print(f"{nx}x{ny} flags={flags}: max|KT - ref|/max|ref| = {err:.3e} (correction itself {dk:.3e}), nan {int(torch.isnan(out).sum())}, {ms:.4f} ms")
+    asm.newton_on_assembled = False
     ms2 = bench.avg_ms(torch, lambda: asm.assemble_tangent_stiffness(u), 10)
     print(f"  two-kernel K_T: {ms2:.4f} ms")
