@@ -30,7 +30,7 @@ SIGNATURES = {
     "fs_fused_assemble_quad": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _u32,
                                               _vp, _vp, _vp]),
     "fs_fused_assemble_quad_tangent": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32,
-                                                      _vp, _vp, _vp, _u32, _vp]),
+                                                      _vp, _vp, _vp, _vp, _u32, _vp]),
     "fs_fused_tangent_offsets": (ctypes.c_int, [_i64, _vp, _vp, ctypes.POINTER(_i64), _vp]),
     "fs_fused_tangent_pack": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "fs_shell_quad_fint_nl": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),

@@ -681,7 +681,7 @@ class MeshAssembler:
             self._K_lin_packed = (k_lin, packed)
         return self._K_lin_packed[1]
 
-    def _tangent_on_assembled(self, u, k_lin) -> CsrMatrix:
+    def _tangent_on_assembled(self, u, k_lin, f_nl=None) -> CsrMatrix:
         lib, fp, d, g = _lib.load(), self.fused_plan(), self._fplan_d, self._groups[0]
         if "pat_conn" not in d:       # connectivity rows of the plan's element slots (int32), built once
             d["pat_conn"] = g["conn_d"][d["pat_elems"].to(torch.int64)].to(torch.int32).contiguous()
@@ -691,19 +691,21 @@ class MeshAssembler:
             _lib.ptr(g["xyz_d"]), _lib.ptr(d["pat_conn"]), _lib.ptr(u), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
             len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]), _lib.ptr(d["pat_elems"]),
             _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]), fp.max_patch_elems, _lib.ptr(d["wave_off"]), _lib.ptr(packed),
-            _lib.ptr(data), self.tangent_flags, _lib.stream_ptr()), "fs_fused_assemble_quad_tangent")
+            _lib.ptr(data), _lib.ptr(f_nl), self.tangent_flags, _lib.stream_ptr()), "fs_fused_assemble_quad_tangent")
         return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
 
     tangent_flags = 0            # FS_TANGENT_* flags of fs_fused_assemble_quad_tangent
 
-    def _forces_on_assembled(self, u, k_lin):
-        """f_int = K u (assembled matrix) + element-order sums of the nonlinear membrane forces."""
+    def _forces_on_assembled(self, u, k_lin, f_nl=None):
+        """f_int = K u (assembled matrix) + element-order sums of the nonlinear membrane forces (f_nl: already formed
+        by the tangent kernel of the same iterate)."""
         lib, g, pd = _lib.load(), self._groups[0], self._plan_d
-        fe = torch.empty((g["E"], 24), dtype=torch.float64, device=self.device)
-        _lib.check(lib.fs_shell_quad_fint_nl(_lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]),
-                                             _lib.ptr(self._props_d), len(self._prop_table), g["E"], _lib.ptr(fe),
-                                             _lib.stream_ptr()), "fs_shell_quad_fint_nl")
-        f_nl = self._scatter_vector(fe.reshape(-1))
+        if f_nl is None:
+            fe = torch.empty((g["E"], 24), dtype=torch.float64, device=self.device)
+            _lib.check(lib.fs_shell_quad_fint_nl(_lib.ptr(g["xyz_d"]), _lib.ptr(g["conn_d"]), _lib.ptr(u), _lib.ptr(g["pid_d"]),
+                                                 _lib.ptr(self._props_d), len(self._prop_table), g["E"], _lib.ptr(fe),
+                                                 _lib.stream_ptr()), "fs_shell_quad_fint_nl")
+            f_nl = self._scatter_vector(fe.reshape(-1))
         f = torch.empty(self.dofs_count, dtype=torch.float64, device=self.device)
         _lib.check(lib.fs_csr_blk_matvec(_lib.ptr(pd["nbr_ptr"]), _lib.ptr(pd["nbr"]), _lib.ptr(pd["blk_row"]),
                                          int(self._plan.n_nodes), self.dofs_per_node, _lib.ptr(k_lin), _lib.ptr(u),
@@ -727,7 +729,9 @@ class MeshAssembler:
     def assemble_tangent_and_forces(self, u):
         if self._newton_fused():
             u, k_lin = self._u_nodes(u), self._linear_csr()
-            return self._tangent_on_assembled(u, k_lin), self._forces_on_assembled(u, k_lin)
+            f_nl = torch.zeros(self.dofs_count, dtype=torch.float64, device=self.device)     # (nodes without elements stay 0)
+            KT = self._tangent_on_assembled(u, k_lin, f_nl)
+            return KT, self._forces_on_assembled(u, k_lin, f_nl)
         out = self._nl_pass(u, True, True)
         return self._assemble(out["KT"]), self._scatter_vector(out["f_int"])
 

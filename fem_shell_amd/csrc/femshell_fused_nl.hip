@@ -34,8 +34,8 @@ namespace {
 // image components (per element; [component][16] inside a 16-element tile)
 constexpr int NL_GP = 15;                 // per Gauss point: nx[4], ny[4], H[3][2], detJ
 constexpr int NL_NX = 0, NL_NY = 4, NL_H = 8, NL_DET = 14;
-constexpr int NL_R = 60, NL_SM = 69, NL_NC = 72;
-constexpr int NL_TILE = NL_NC * 16;
+constexpr int NL_R = 60, NL_SM = 69, NL_FN = 72;      // NL_FN: nonlinear nodal forces [node][3] (kernels that form f_nl)
+template <bool WF> constexpr int nl_tile() { return (WF ? 84 : 72) * 16; }
 constexpr int NZ_SLOT = 21;               // staging slot, in 16-byte pieces (as in fused_quad_k_kernel)
 
 #define NL_EV_SLOT(ev) ((int)((ev) & 255u))
@@ -53,11 +53,12 @@ __device__ __forceinline__ double nl_row_shr1(double v) {      // lane i reads l
 
 // one contribution: the translational 3 x 3 correction of pair (ti <= tj) of the element in image slot NL_EV_SLOT(ev),
 // global axes, transposed when the record says so
+template <bool WF>
 __device__ __forceinline__ void dkt_eval(uint32_t ev, const double *lds, const int *s_pid,
-                                         const fs_shell_prop *__restrict__ props, double (&Y)[9]) {
+                                         const fs_shell_prop *__restrict__ props, double (&Y)[WF ? 12 : 9]) {
 #pragma clang fp contract(fast)
     const int slot = NL_EV_SLOT(ev), ti = NL_EV_TI(ev), tj = NL_EV_TJ(ev);
-    const double *ex = lds + (slot >> 4) * NL_TILE + (slot & 15);
+    const double *ex = lds + (slot >> 4) * nl_tile<WF>() + (slot & 15);
     const fs_shell_prop *pr = props + s_pid[slot];
     double C[3][3];
     for (int a = 0; a < 9; a++) (&C[0][0])[a] = pr->C_raw[a];
@@ -113,16 +114,21 @@ __device__ __forceinline__ void dkt_eval(uint32_t ev, const double *lds, const i
     const bool tr = NL_EV_TR(ev);
     for (int k = 0; k < 3; k++)
         for (int l = 0; l < 3; l++) Y[k * 3 + l] = tr ? T[l][k] : T[k][l];
+    if constexpr (WF)      // a contribution to a DIAGONAL block also carries the element's nonlinear force at that node
+        for (int a = 0; a < 3; a++) Y[9 + a] = (ti == tj) ? ex[(NL_FN + 3 * ti + a) << 4] : -0.0;
 }
 
-// SP staging slots per wave: 64 -> one workgroup per CU, 32 -> two
-template <int SP>
+// SP staging slots per wave: 64 -> one workgroup per CU, 32 -> two.  WF: the kernel also forms the element-order sums
+// f_nl of the nonlinear nodal forces (quad_fnl_lane in stage 1, three more values on the chains of the diagonal blocks)
+template <int SP, bool WF>
 __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel(
     const double *__restrict__ xyz, const int4 *__restrict__ pat_conn, const double *__restrict__ u,
     const int32_t *__restrict__ prop_id, const fs_shell_prop *__restrict__ props, int32_t n_props, int64_t n_pat,
     const int64_t *__restrict__ pat_eptr, const int32_t *__restrict__ pat_elems, const int64_t *__restrict__ pat_rptr,
     const fs_fused_rec *__restrict__ recs, const int64_t *__restrict__ wave_off, const double *__restrict__ packed,
-    double *__restrict__ data) {
+    double *__restrict__ data, double *__restrict__ f_nl) {
+    constexpr int NL_TILE = nl_tile<WF>();
+    constexpr int NV = WF ? 12 : 9;                 // values per contribution: the 3 x 3 correction (+ 3 force components)
     constexpr int NQ = (3 * SP + 63) / 64;          // direct-copy pieces per lane and pass
     constexpr int NB = (18 * SP + 63) / 64;         // 16-byte pieces of the pass's linear blocks per lane
     __shared__ double lds[4 * NL_TILE];
@@ -261,6 +267,15 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
             }
             ex[NL_DET << 4] = detJ;
             double *ee = lds + wave * NL_TILE + Q;
+            if constexpr (WF) {
+                double Hm[3][2], fn[3];
+                for (int c = 0; c < 3; c++) {
+                    Hm[c][0] = dots4(ue[0][c], ue[1][c], ue[2][c], ue[3][c], nx[0], nx[1], nx[2], nx[3]);
+                    Hm[c][1] = dots4(ue[0][c], ue[1][c], ue[2][c], ue[3][c], ny[0], ny[1], ny[2], ny[3]);
+                }
+                quad_fnl_lane(x, ue, geo, pr, g, xi, eta, detJ, ia, ib, ic, id, nx, ny, Hm, R, fn);
+                for (int a = 0; a < 3; a++) ee[(NL_FN + 3 * g + a) << 4] = nonlinear ? fn[a] : 0.0;
+            }
             if (g == 0) {
                 for (int t = 0; t < 9; t++) ee[(NL_R + t) << 4] = (&R[0][0])[t];
                 s_pid[slot] = pid;
@@ -301,6 +316,17 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
             const int nd = __popcll(__ballot(s0d != 255)) + __popcll(__ballot(s1d != 255));
             const int ntr = __popcll(__ballot(s0t != 255)) + __popcll(__ballot(s1t != 255));
 
+            // node of a DIAGONAL block this lane emits (its force sums leave with it): requested now, used after the sums
+            int fnode0 = -1, fnode1 = -1;
+            if constexpr (WF) {
+                const uint32_t evA = (two || NL_EV_ACTIVE(ev0)) ? ev0 : ev1, evB = ev1;
+                const bool d0 = out0 && NL_EV_ACTIVE(evA) && NL_EV_TI(evA) == NL_EV_TJ(evA);
+                const bool d1 = two && NL_EV_ACTIVE(evB) && NL_EV_TI(evB) == NL_EV_TJ(evB);
+                const int32_t *pcn = reinterpret_cast<const int32_t *>(pat_conn + e0);
+                const int nA = pcn[d0 ? 4 * NL_EV_SLOT(evA) + NL_EV_TI(evA) : 0];
+                const int nB = pcn[d1 ? 4 * NL_EV_SLOT(evB) + NL_EV_TI(evB) : 0];
+                fnode0 = d0 ? nA : -1; fnode1 = d1 ? nB : -1;
+            }
             // destinations of the pass's blocks into their staging slots, rank table of the transposed copies
             auto stage_addresses = [&](int s0) __attribute__((always_inline)) {
                 if (nd > SP) {
@@ -341,33 +367,43 @@ __global__ __launch_bounds__(256, (SP <= 32 ? 2 : 1)) void fused_quad_dkt_kernel
                 }
             };
             // ---- passes over the wave's blocks: linear block + correction -> staging -> (I, J) and (J, I) ----
-            double X[9], Y[9];
+            double X[NV], Y[NV];
             for (int s0 = 0; s0 < nd; s0 += SP) {       // (a wave without output blocks has nothing to evaluate)
                 load_base(s0);
                 stage_addresses(s0);
                 if (s0 == 0) {
-                // ---- the lane's two contributions, element-order sums (as fused_quad_k_kernel, on 9 values) ----
-                const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
-                if (NL_EV_ACTIVE(ev0)) dkt_eval(ev0, lds, s_pid, props, Y);
-                else
-                    for (int t = 0; t < 9; t++) Y[t] = -0.0;
-                for (int t = 0; t < 9; t++) X[t] = z0 + Y[t];
-                if (NL_EV_ACTIVE(ev1)) dkt_eval(ev1, lds, s_pid, props, Y);
-                else
-                    for (int t = 0; t < 9; t++) Y[t] = -0.0;
-                {
+                    // ---- the lane's two contributions, element-order sums (as fused_quad_k_kernel, on NV values) ----
+                    const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
+                    if (NL_EV_ACTIVE(ev0)) dkt_eval<WF>(ev0, lds, s_pid, props, Y);
+                    else
+                        for (int t = 0; t < NV; t++) Y[t] = -0.0;
+                    for (int t = 0; t < NV; t++) X[t] = z0 + Y[t];
+                    if (NL_EV_ACTIVE(ev1)) dkt_eval<WF>(ev1, lds, s_pid, props, Y);
+                    else
+                        for (int t = 0; t < NV; t++) Y[t] = -0.0;
                     const int pos = (int)((fl >> 16) & 15u);
                     const int maxc = __builtin_amdgcn_readfirstlane((int)((fl >> 8) & 255u));
-                    double S[9];
-                    for (int t = 0; t < 9; t++) S[t] = X[t] + Y[t];
+                    double S[NV];
+                    for (int t = 0; t < NV; t++) S[t] = X[t] + Y[t];
                     for (int it = 1; it < maxc; it++)
-                        for (int t = 0; t < 9; t++) {
+                        for (int t = 0; t < NV; t++) {
                             const double T = nl_row_shr1(S[t]);
                             const double v = (T + X[t]) + Y[t];
                             S[t] = (chain && pos == it) ? v : S[t];
                         }
-                    for (int t = 0; t < 9; t++) X[t] = two ? X[t] : S[t];
-                }
+                    for (int t = 0; t < NV; t++) X[t] = two ? X[t] : S[t];
+                    if constexpr (WF) {      // one writer per node: the lane that ends the chain of the node's diagonal block
+                        if (fnode0 >= 0) {
+                            double2 *fo = reinterpret_cast<double2 *>(f_nl + (int64_t)fnode0 * 6);
+                            fo[0] = make_double2(X[9] + 0.0, X[10] + 0.0); fo[1] = make_double2(X[11] + 0.0, 0.0);
+                            fo[2] = make_double2(0.0, 0.0);
+                        }
+                        if (fnode1 >= 0) {
+                            double2 *fo = reinterpret_cast<double2 *>(f_nl + (int64_t)fnode1 * 6);
+                            fo[0] = make_double2(Y[9] + 0.0, Y[10] + 0.0); fo[1] = make_double2(Y[11] + 0.0, 0.0);
+                            fo[2] = make_double2(0.0, 0.0);
+                        }
+                    }
                 }
                 const int nhere = (nd - s0 < SP) ? nd - s0 : SP;
                 for (int q = 0; q < NB; q++) {
@@ -517,7 +553,8 @@ extern "C" int fs_fused_assemble_quad_tangent(const double *xyz, const int32_t *
                                               const fs_shell_prop *props, int32_t n_props, int64_t E, int64_t n_patches,
                                               const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
                                               const fs_fused_rec *recs, int32_t max_patch_elems, const int64_t *wave_off,
-                                              const double *k_lin_packed, double *k_t, uint32_t flags, void *stream) {
+                                              const double *k_lin_packed, double *k_t, double *f_nl, uint32_t flags,
+                                              void *stream) {
     if (E < 0 || n_props <= 0 || n_patches < 0) return fs_fail_(FS_EINVAL, "fs_fused_assemble_quad_tangent: bad sizes", 0);
     if (E == 0 || n_patches == 0) return FS_OK;
     if (!xyz || !pat_conn || !u || !prop_id || !props || !pat_eptr || !pat_elems || !pat_rptr || !recs || !wave_off || !k_lin_packed || !k_t)
@@ -526,17 +563,20 @@ extern "C" int fs_fused_assemble_quad_tangent(const double *xyz, const int32_t *
         return fs_fail_(FS_EINVAL, "fs_fused_assemble_quad_tangent: a patch may hold at most FS_FUSED_MAX_PATCH_ELEMS elements", 0);
     int cus = 0;
     if (int rc = fs_device_cu_count_(&cus)) return rc;
-    const int per_cu = (flags & FS_TANGENT_TWO_WGS_PER_CU) ? 2 : 1;
+    // (the 32-slot variant has no room for the force image: with f_nl the flag is ignored)
+    const int per_cu = ((flags & FS_TANGENT_TWO_WGS_PER_CU) && !f_nl) ? 2 : 1;
     int64_t wgs = ((int64_t)cus * per_cu / 8) * 8;
     if (wgs < 8) wgs = 8;
     if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
-    if (per_cu == 1)
-        hipLaunchKernelGGL(fused_quad_dkt_kernel<64>, dim3((unsigned)wgs), dim3(256), 0, s, xyz, reinterpret_cast<const int4 *>(pat_conn), u, prop_id, props, n_props,
-                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, wave_off, k_lin_packed, k_t);
-    else
-        hipLaunchKernelGGL(fused_quad_dkt_kernel<32>, dim3((unsigned)wgs), dim3(256), 0, s, xyz, reinterpret_cast<const int4 *>(pat_conn), u, prop_id, props, n_props,
-                           n_patches, pat_eptr, pat_elems, pat_rptr, recs, wave_off, k_lin_packed, k_t);
+#define FS_DKT_LAUNCH(SP_, WF_)                                                                                          \
+    hipLaunchKernelGGL((fused_quad_dkt_kernel<SP_, WF_>), dim3((unsigned)wgs), dim3(256), 0, s, xyz,                        \
+                       reinterpret_cast<const int4 *>(pat_conn), u, prop_id, props, n_props, n_patches, pat_eptr, pat_elems,  \
+                       pat_rptr, recs, wave_off, k_lin_packed, k_t, f_nl)
+    if (f_nl) FS_DKT_LAUNCH(64, true);
+    else if (per_cu == 1) FS_DKT_LAUNCH(64, false);
+    else FS_DKT_LAUNCH(32, false);
+#undef FS_DKT_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_quad_dkt_kernel", (int)e);
     return FS_OK;

@@ -189,6 +189,147 @@ __device__ __forceinline__ double jacobian(const QuadGeom &g, const double *dxi,
 }
 
 
+// Exchange inside a quad of lanes through DPP quad_perm (VALU rate) instead of __shfl_xor, which
+// compiles to ds_bpermute_b32 pairs through the LDS crossbar.  Needs all four lanes of the quad active.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+    v += quad_perm<0xB1>(v);   // quad_perm:[1,0,3,2] == lane ^ 1
+    v += quad_perm<0x4E>(v);   // quad_perm:[2,3,0,1] == lane ^ 2
+    return v;
+}
+
+// tying shape-derivative weights of node i: dN/dxi at A,B ; dN/deta at C,D ; dN/deta, dN/dxi at E
+__device__ __forceinline__ void tying_weights(int i, double *w) {
+    w[0] = (i == 2) ? 0.5 : ((i == 3) ? -0.5 : 0.0);    // A (0, 1)
+    w[1] = (i == 0) ? -0.5 : ((i == 1) ? 0.5 : 0.0);    // B (0,-1)
+    w[2] = (i == 1) ? -0.5 : ((i == 2) ? 0.5 : 0.0);    // C ( 1,0)
+    w[3] = (i == 0) ? -0.5 : ((i == 3) ? 0.5 : 0.0);    // D (-1,0)
+    w[4] = (i >= 2) ? 0.125 : -0.125;                   // E: 0.5 * dN/deta
+    w[5] = (i == 1 || i == 2) ? 0.125 : -0.125;         // E: 0.5 * dN/dxi
+}
+
+__device__ __forceinline__ void membrane_W(const QuadGeom &geo, double xi, double eta, double detJ, double ia,
+                                           double ib, double ic, double id, double (&W)[3][5]) {
+#pragma clang fp contract(fast)
+    const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
+    const double r = xi, s = eta;
+    double bl[3][5];
+    bl[0][0] = 0.5 * (1.0 - 2.0 * aA + s + 2.0 * aA * s * s);
+    bl[0][1] = 0.5 * (1.0 - 2.0 * aB - s + 2.0 * aB * s * s);
+    bl[0][2] = aC * (-1.0 + s * s);
+    bl[0][3] = aD * (-1.0 + s * s);
+    bl[0][4] = aE * (-1.0 + s * s);
+    bl[1][0] = aA * (-1.0 + r * r);
+    bl[1][1] = aB * (-1.0 + r * r);
+    bl[1][2] = 0.5 * (1.0 - 2.0 * aC + r + 2.0 * aC * r * r);
+    bl[1][3] = 0.5 * (1.0 - 2.0 * aD - r + 2.0 * aD * r * r);
+    bl[1][4] = aE * (-1.0 + r * r);
+    bl[2][0] = 2.0 * (0.25 * (r + 4.0 * aA * r * s));
+    bl[2][1] = 2.0 * (0.25 * (-r + 4.0 * aB * r * s));
+    bl[2][2] = 2.0 * (0.25 * (s + 4.0 * aC * r * s));
+    bl[2][3] = 2.0 * (0.25 * (-s + 4.0 * aD * r * s));
+    bl[2][4] = 2.0 * (1.0 + aE * r * s);
+    double Te[3][3];
+    if (__builtin_fabs(detJ) < 1e-12) {
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) Te[a][b] = (a == b) ? 1.0 : 0.0;
+    } else {
+        Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
+        Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
+        Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
+    }
+    for (int a = 0; a < 3; a++)
+        for (int t = 0; t < 5; t++) W[a][t] = Te[a][0] * bl[0][t] + Te[a][1] * bl[1][t] + Te[a][2] * bl[2][t];
+}
+
+// Nonlinear part of the internal force of node g of an element, for the lane (element, Gauss point g) of a quad of
+// lanes (all four active): T^T ( sum_q detJ h (B_L + B_NL)^T C e_GL  -  K_m u_loc ) restricted to node g, global axes --
+// the terms mitc4_nl_tiled_kernel adds to K_e u_e (MITC4.py:1300-1341; K_m u_loc = Y^T S (Y u_loc) with the pre-contracted
+// membrane core of the stiffness kernel).  nx, ny, H, detJ: shape derivatives, displacement gradient and Jacobian of
+// the lane's Gauss point; R: rows e1, e2, e3.
+__device__ __forceinline__ void quad_fnl_lane(const double (&x)[4][3], const double (&u)[4][6], const QuadGeom &geo,
+                                              const fs_shell_prop *pr, int g, double xi, double eta, double detJ, double ia,
+                                              double ib, double ic, double id, const double (&nx)[4], const double (&ny)[4],
+                                              const double (&H)[3][2], const double (&R)[3][3], double (&fnl)[3]) {
+#pragma clang fp contract(fast)
+    const double h = pr->h;
+    double C[3][3];
+    for (int a = 0; a < 9; a++) (&C[0][0])[a] = pr->C_raw[a];
+    const double E00 = 0.5 * (2.0 * H[0][0] + (H[0][0] * H[0][0] + H[1][0] * H[1][0] + H[2][0] * H[2][0]));
+    const double E11 = 0.5 * (2.0 * H[1][1] + (H[0][1] * H[0][1] + H[1][1] * H[1][1] + H[2][1] * H[2][1]));
+    const double E01 = 0.5 * ((H[0][1] + H[1][0]) + (H[0][0] * H[0][1] + H[1][0] * H[1][1] + H[2][0] * H[2][1]));
+    const double eg[3] = {E00, E11, 2.0 * E01};
+    double sg[3];
+    for (int a = 0; a < 3; a++) sg[a] = C[a][0] * eg[0] + C[a][1] * eg[1] + C[a][2] * eg[2];
+    const double wh = detJ * h;
+    double fm[4][3];
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++) {
+            const double b0 = ((k == 0) ? nx[i] : 0.0) + H[k][0] * nx[i];
+            const double b1 = ((k == 1) ? ny[i] : 0.0) + H[k][1] * ny[i];
+            const double b2 = ((k == 0) ? ny[i] : ((k == 1) ? nx[i] : 0.0)) + (H[k][0] * ny[i] + H[k][1] * nx[i]);
+            fm[i][k] = quad_sum(wh * (b0 * sg[0] + b1 * sg[1] + b2 * sg[2]));
+        }
+    double W[3][5], Sf[5][5];
+    membrane_W(geo, xi, eta, detJ, ia, ib, ic, id, W);
+    for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = 0.0;
+    for (int t = 0; t < 5; t++)
+        for (int a = 0; a < 3; a++) {
+            const double cw = detJ * (pr->A[a * 3] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
+            for (int v = 0; v < 5; v++) Sf[v][t] += W[a][v] * cw;
+        }
+    for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = quad_sum((&Sf[0][0])[t]);
+    double gt[6][3];
+    {
+#pragma clang fp contract(off)
+        double t3[3];
+        for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
+        gt[0][0] = dot3(t3, geo.e1); gt[0][1] = dot3(t3, geo.e2); gt[0][2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
+        gt[1][0] = dot3(t3, geo.e1); gt[1][1] = dot3(t3, geo.e2); gt[1][2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
+        gt[2][0] = dot3(t3, geo.e1); gt[2][1] = dot3(t3, geo.e2); gt[2][2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
+        gt[3][0] = dot3(t3, geo.e1); gt[3][1] = dot3(t3, geo.e2); gt[3][2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
+        gt[4][0] = dot3(t3, geo.e1); gt[4][1] = dot3(t3, geo.e2); gt[4][2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
+        gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
+    }
+    double z[5] = {0, 0, 0, 0, 0}, Yg[5][3];
+    for (int i = 0; i < 4; i++) {
+        double w[6];
+        tying_weights(i, w);
+        for (int k = 0; k < 3; k++) {
+            const double ulk = R[k][0] * u[i][0] + R[k][1] * u[i][1] + R[k][2] * u[i][2];
+            double y[5];
+            for (int t = 0; t < 4; t++) y[t] = w[t] * gt[t][k];
+            y[4] = w[4] * gt[4][k] + w[5] * gt[5][k];
+            for (int t = 0; t < 5; t++) {
+                z[t] += y[t] * ulk;
+                if (i == g) Yg[t][k] = y[t];
+            }
+        }
+    }
+    double Sz[5];
+    for (int t = 0; t < 5; t++) Sz[t] = Sf[t][0] * z[0] + Sf[t][1] * z[1] + Sf[t][2] * z[2] + Sf[t][3] * z[3] + Sf[t][4] * z[4];
+    double fl[3];
+    for (int k = 0; k < 3; k++) {
+        double v = 0.0;
+        for (int i = 0; i < 4; i++) v = (i == g) ? fm[i][k] : v;
+        for (int t = 0; t < 5; t++) v -= Yg[t][k] * Sz[t];
+        fl[k] = v;
+    }
+    for (int a = 0; a < 3; a++) fnl[a] = R[0][a] * fl[0] + R[1][a] * fl[1] + R[2][a] * fl[2];
+}
+
+
 struct TriGeom {
     double e1[3], e2[3], e3[3];
     double x2, x3, y3, area, J00, J10, J11;

@@ -84,31 +84,6 @@ __host__ __device__ __forceinline__ int64_t quad_blk(int tiled, int64_t e, int p
     return tiled ? blk_t16(e, p) : e * 10 + p;
 }
 
-// Exchange inside a quad of lanes through DPP quad_perm (VALU rate) instead of __shfl_xor, which
-// compiles to ds_bpermute_b32 pairs through the LDS crossbar.  Needs all four lanes of the quad active.
-template <int CTRL>
-__device__ __forceinline__ double quad_perm(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_sum(double v) {
-    v += quad_perm<0xB1>(v);   // quad_perm:[1,0,3,2] == lane ^ 1
-    v += quad_perm<0x4E>(v);   // quad_perm:[2,3,0,1] == lane ^ 2
-    return v;
-}
-
-// tying shape-derivative weights of node i: dN/dxi at A,B ; dN/deta at C,D ; dN/deta, dN/dxi at E
-__device__ __forceinline__ void tying_weights(int i, double *w) {
-    w[0] = (i == 2) ? 0.5 : ((i == 3) ? -0.5 : 0.0);    // A (0, 1)
-    w[1] = (i == 0) ? -0.5 : ((i == 1) ? 0.5 : 0.0);    // B (0,-1)
-    w[2] = (i == 1) ? -0.5 : ((i == 2) ? 0.5 : 0.0);    // C ( 1,0)
-    w[3] = (i == 0) ? -0.5 : ((i == 3) ? 0.5 : 0.0);    // D (-1,0)
-    w[4] = (i >= 2) ? 0.125 : -0.125;                   // E: 0.5 * dN/deta
-    w[5] = (i == 1 || i == 2) ? 0.125 : -0.125;         // E: 0.5 * dN/dxi
-}
-
 // ------------------------------------------------------------------------------------------
 // MITC4+ stiffness, FS_LAYOUT_SYMBLK output
 //
@@ -1049,40 +1024,6 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
 // (K_bs + K_drill + K_c) u_loc of the reference is evaluated as K0 u_loc - K_m u_loc, with
 // K_m = Y^T S Y from the same pre-contracted core as the stiffness kernel.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void membrane_W(const QuadGeom &geo, double xi, double eta, double detJ, double ia,
-                                           double ib, double ic, double id, double (&W)[3][5]) {
-#pragma clang fp contract(fast)
-    const double aA = geo.a[0], aB = geo.a[1], aC = geo.a[2], aD = geo.a[3], aE = geo.a[4];
-    const double r = xi, s = eta;
-    double bl[3][5];
-    bl[0][0] = 0.5 * (1.0 - 2.0 * aA + s + 2.0 * aA * s * s);
-    bl[0][1] = 0.5 * (1.0 - 2.0 * aB - s + 2.0 * aB * s * s);
-    bl[0][2] = aC * (-1.0 + s * s);
-    bl[0][3] = aD * (-1.0 + s * s);
-    bl[0][4] = aE * (-1.0 + s * s);
-    bl[1][0] = aA * (-1.0 + r * r);
-    bl[1][1] = aB * (-1.0 + r * r);
-    bl[1][2] = 0.5 * (1.0 - 2.0 * aC + r + 2.0 * aC * r * r);
-    bl[1][3] = 0.5 * (1.0 - 2.0 * aD - r + 2.0 * aD * r * r);
-    bl[1][4] = aE * (-1.0 + r * r);
-    bl[2][0] = 2.0 * (0.25 * (r + 4.0 * aA * r * s));
-    bl[2][1] = 2.0 * (0.25 * (-r + 4.0 * aB * r * s));
-    bl[2][2] = 2.0 * (0.25 * (s + 4.0 * aC * r * s));
-    bl[2][3] = 2.0 * (0.25 * (-s + 4.0 * aD * r * s));
-    bl[2][4] = 2.0 * (1.0 + aE * r * s);
-    double Te[3][3];
-    if (__builtin_fabs(detJ) < 1e-12) {
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) Te[a][b] = (a == b) ? 1.0 : 0.0;
-    } else {
-        Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
-        Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
-        Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
-    }
-    for (int a = 0; a < 3; a++)
-        for (int t = 0; t < 5; t++) W[a][t] = Te[a][0] * bl[0][t] + Te[a][1] * bl[1][t] + Te[a][2] * bl[2][t];
-}
-
 __global__ __launch_bounds__(64) void mitc4_nl_kernel(const double *__restrict__ xyz,
                                                       const int32_t *__restrict__ prop_id,
                                                       const fs_shell_prop *__restrict__ props, int32_t n_props,

@@ -467,7 +467,12 @@ void fs_fused_plan_device_free(fs_fused_plan_dev *plan);
  *     (fs_fused_plan_build / fs_fused_plan_device_*; fs_fused_plan_check applies);  pat_conn [n_elem_slots][4] int32: the
  *     connectivity rows of the plan's element slots, pat_conn[s] = conn[pat_elems[s]] (the node ids of a patch arrive with
  *     its element indices: one dependent load less in front of the gather of u);  k_t [nnz] out;
- *     flags: FS_TANGENT_TWO_WGS_PER_CU selects the 32-slot variant of the kernel (two workgroups per CU; measured slower).
+ *     f_nl [n_nodes][6] out, or NULL: the element-order sums of the NONLINEAR nodal forces of compute_internal_forces
+ *     (what fs_shell_quad_fint_nl + fs_vec_gather_sum give: translational rows, zeros in the rotational rows), formed in
+ *     the same launch -- stage 1 evaluates them, they ride on the sums of the diagonal blocks; every node with a block
+ *     row is written once, other entries are left alone.  f_int = fs_csr_blk_matvec(K, u, y0 = f_nl);
+ *     flags: FS_TANGENT_TWO_WGS_PER_CU selects the 32-slot variant of the kernel (two workgroups per CU; measured slower;
+ *     ignored when f_nl is requested).
  * Agreement with fs_shell_quad_batch(FS_WANT_KT) + fs_csr_numeric_desc: rounding level (the correction is summed apart
  * from the linear blocks and evaluated without the cancellation of B~^T C B~ - B_L^T C B_L); k_t is exactly symmetric; the
  * same bits in every run.  All three: no counterpart in the reference beyond the lines cited (its loop needs no plan).
@@ -480,7 +485,7 @@ int fs_fused_assemble_quad_tangent(const double *xyz, const int32_t *pat_conn, c
                                    const fs_shell_prop *props, int32_t n_props, int64_t E, int64_t n_patches,
                                    const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_rptr,
                                    const fs_fused_rec *recs, int32_t max_patch_elems, const int64_t *wave_off,
-                                   const double *k_lin_packed, double *k_t, uint32_t flags, void *stream);
+                                   const double *k_lin_packed, double *k_t, double *f_nl, uint32_t flags, void *stream);
 
 /*
  * The NONLINEAR part of the internal forces of MITC4.compute_internal_forces (elements/MITC4.py:1300-1341 after

@@ -103,7 +103,9 @@ def _worker_newton(rank, world, port, nx, ny, q):
         A_only = da.assemble_tangent_stiffness(ul)
         da.finish()
         ip, ix, data = A.indptr.cpu().numpy(), A.indices.cpu().numpy(), A.data.cpu().numpy()
-        assert bool((A_only.data == A.data).all()) and bool((f_only == f).all())
+        # (f_int alone takes its nonlinear part from the element kernel + vector scatter, the combined call from the
+        # tangent kernel's own sums: the same terms, rounding-level apart)
+        assert bool((A_only.data == A.data).all()) and float((f_only - f).abs().max()) <= 1e-12 * float(f.abs().max())
         f = f.cpu().numpy()
         worstK = worstF = 0.0
         for r in np.flatnonzero(da.owned_rows):
