@@ -17,4 +17,6 @@ field[:, 2] = xs ** 2 / 100.0; field[:, 4] = -2.0 * xs / 100.0
 u = (field * 1e-3).reshape(-1).contiguous()
 for k in range(3):
     asm.assemble_tangent_and_forces(u)
+asm.assemble_tangent_stiffness(u)
+asm.assemble_internal_forces(u)
 torch.cuda.synchronize()
