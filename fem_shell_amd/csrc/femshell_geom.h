@@ -268,23 +268,35 @@ __device__ __forceinline__ void quad_fnl_lane(const double (&x)[4][3], const dou
     double sg[3];
     for (int a = 0; a < 3; a++) sg[a] = C[a][0] * eg[0] + C[a][1] * eg[1] + C[a][2] * eg[2];
     const double wh = detJ * h;
-    double fm[4][3];
-    for (int i = 0; i < 4; i++)
-        for (int k = 0; k < 3; k++) {
-            const double b0 = ((k == 0) ? nx[i] : 0.0) + H[k][0] * nx[i];
-            const double b1 = ((k == 1) ? ny[i] : 0.0) + H[k][1] * ny[i];
-            const double b2 = ((k == 0) ? ny[i] : ((k == 1) ? nx[i] : 0.0)) + (H[k][0] * ny[i] + H[k][1] * nx[i]);
-            fm[i][k] = quad_sum(wh * (b0 * sg[0] + b1 * sg[1] + b2 * sg[2]));
+    // membrane force of node g: every lane forms the four nodes' terms of ITS Gauss point; a transposing quad reduction
+    // (lane ^ 1, then lane ^ 2: three exchanges instead of four full quad sums) leaves on lane g the sum over the four
+    // Gauss points of node g's term
+    const bool b0 = (g & 1) != 0, b1 = (g & 2) != 0;
+    double fmg[3];
+    for (int k = 0; k < 3; k++) {
+        double v[4];
+        for (int i = 0; i < 4; i++) {
+            const double c0 = ((k == 0) ? nx[i] : 0.0) + H[k][0] * nx[i];
+            const double c1 = ((k == 1) ? ny[i] : 0.0) + H[k][1] * ny[i];
+            const double c2 = ((k == 0) ? ny[i] : ((k == 1) ? nx[i] : 0.0)) + (H[k][0] * ny[i] + H[k][1] * nx[i]);
+            v[i] = wh * (c0 * sg[0] + c1 * sg[1] + c2 * sg[2]);
         }
-    double W[3][5], Sf[5][5];
+        const double t0 = (b0 ? v[1] : v[0]) + quad_perm<0xB1>(b0 ? v[0] : v[1]);      // node b0 over lanes g, g ^ 1
+        const double t1 = (b0 ? v[3] : v[2]) + quad_perm<0xB1>(b0 ? v[2] : v[3]);      // node 2 + b0
+        fmg[k] = (b1 ? t1 : t0) + quad_perm<0x4E>(b1 ? t0 : t1);
+    }
+    // membrane core S = sum_q detJ W^T A W (symmetric 5 x 5: 15 entries)
+    double W[3][5], S[15];
     membrane_W(geo, xi, eta, detJ, ia, ib, ic, id, W);
-    for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = 0.0;
-    for (int t = 0; t < 5; t++)
-        for (int a = 0; a < 3; a++) {
-            const double cw = detJ * (pr->A[a * 3] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
-            for (int v = 0; v < 5; v++) Sf[v][t] += W[a][v] * cw;
-        }
-    for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = quad_sum((&Sf[0][0])[t]);
+    {
+        double cw[3][5];
+        for (int t = 0; t < 5; t++)
+            for (int a = 0; a < 3; a++)
+                cw[a][t] = detJ * (pr->A[a * 3] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
+        int n = 0;
+        for (int t = 0; t < 5; t++)
+            for (int v = t; v < 5; v++) { S[n] = quad_sum(W[0][t] * cw[0][v] + W[1][t] * cw[1][v] + W[2][t] * cw[2][v]); n++; }
+    }
     double gt[6][3];
     {
 #pragma clang fp contract(off)
@@ -302,27 +314,35 @@ __device__ __forceinline__ void quad_fnl_lane(const double (&x)[4][3], const dou
         for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
         gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
     }
-    double z[5] = {0, 0, 0, 0, 0}, Yg[5][3];
+    // z = Y u_loc (all nodes: compile-time weights), Y of node g through the lane's own weights
+    double z[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
         double w[6];
         tying_weights(i, w);
         for (int k = 0; k < 3; k++) {
             const double ulk = R[k][0] * u[i][0] + R[k][1] * u[i][1] + R[k][2] * u[i][2];
-            double y[5];
-            for (int t = 0; t < 4; t++) y[t] = w[t] * gt[t][k];
-            y[4] = w[4] * gt[4][k] + w[5] * gt[5][k];
-            for (int t = 0; t < 5; t++) {
-                z[t] += y[t] * ulk;
-                if (i == g) Yg[t][k] = y[t];
-            }
+            for (int t = 0; t < 4; t++) z[t] += (w[t] * gt[t][k]) * ulk;
+            z[4] += (w[4] * gt[4][k] + w[5] * gt[5][k]) * ulk;
         }
     }
+    double wg[6], Yg[5][3];
+    tying_weights(g, wg);
+    for (int k = 0; k < 3; k++) {
+        for (int t = 0; t < 4; t++) Yg[t][k] = wg[t] * gt[t][k];
+        Yg[4][k] = wg[4] * gt[4][k] + wg[5] * gt[5][k];
+    }
     double Sz[5];
-    for (int t = 0; t < 5; t++) Sz[t] = Sf[t][0] * z[0] + Sf[t][1] * z[1] + Sf[t][2] * z[2] + Sf[t][3] * z[3] + Sf[t][4] * z[4];
+    for (int t = 0; t < 5; t++) {
+        double acc = 0.0;
+        for (int v = 0; v < 5; v++) {
+            const int lo = t < v ? t : v, hi = t < v ? v : t;
+            acc += S[lo * 5 - (lo * (lo - 1)) / 2 + (hi - lo)] * z[v];
+        }
+        Sz[t] = acc;
+    }
     double fl[3];
     for (int k = 0; k < 3; k++) {
-        double v = 0.0;
-        for (int i = 0; i < 4; i++) v = (i == g) ? fm[i][k] : v;
+        double v = fmg[k];
         for (int t = 0; t < 5; t++) v -= Yg[t][k] * Sz[t];
         fl[k] = v;
     }
