@@ -81,6 +81,8 @@ int main(int argc, char **argv) {
 
     hipStream_t s;
     HIPCHK(hipStreamCreate(&s));
+    void *d_KT = NULL, *d_fnl = NULL, *d_f = NULL;       /* Newton iterate (below) */
+    double *h_u_out = NULL;
     void *d_xyz, *d_pid, *d_props, *d_conn, *d_Ke, *d_Me, *d_st;
     const size_t tile_bytes = (size_t)((E + 15) / 16) * 160 * 36 * 8;
     if (to_dev(&d_xyz, xyz, (size_t)E * 96) || to_dev(&d_pid, pid, (size_t)E * 4) ||
@@ -181,6 +183,41 @@ int main(int argc, char **argv) {
         HIPCHK(hipMemcpy(st2, d_st, (size_t)E * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(stf, d_stf, (size_t)E * 4, hipMemcpyDeviceToHost));
         if (memcmp(k2, kf, (size_t)nnz * 8) != 0 || memcmp(st2, stf, (size_t)E * 4) != 0) return 8;
+        /* one Newton iterate on the assembled matrix (update_configuration + compute_tangent_stiffness /
+         * compute_internal_forces of every element + the assembly loops): packed linear blocks once, then K_T and the
+         * nonlinear nodal forces in one launch, f_int = K u + f_nl */
+        {
+            int32_t *h_pc = malloc((size_t)nslots * 16 + 16);
+            for (int64_t q = 0; q < nslots; q++)
+                for (int c = 0; c < 4; c++) h_pc[4 * q + c] = (int32_t)conn[4 * (int64_t)h_elems[q] + c];
+            double *h_u = malloc((size_t)ndof * 8);
+            for (int64_t n = 0; n < N; n++)
+                for (int c = 0; c < 6; c++) h_u[6 * n + c] = 2e-5 * (double)((n * 7 + c * 13) % 23 - 11) * (c < 3 ? 1.0 : 10.0);
+            void *d_pc, *d_u, *d_woff, *d_packed;
+            int64_t nup = 0;
+            if (to_dev(&d_pc, h_pc, (size_t)nslots * 16) || to_dev(&d_u, h_u, (size_t)ndof * 8) ||
+                to_dev(&d_woff, NULL, (size_t)(nrecs / 64 + 1) * 8) || to_dev(&d_KT, NULL, (size_t)nnz * 8) ||
+                to_dev(&d_fnl, NULL, (size_t)ndof * 8) || to_dev(&d_f, NULL, (size_t)ndof * 8))
+                return 2;
+            FSCHK(fs_fused_tangent_offsets(nrecs, d_recs, d_woff, &nup, s));
+            if (nup != (nblk + N) / 2) return 10;                  /* the blocks I <= J of a symmetric pattern */
+            if (to_dev(&d_packed, NULL, (size_t)nup * 288)) return 2;
+            FSCHK(fs_fused_tangent_pack(nrecs, d_recs, d_woff, d_Kf, d_packed, s));
+            HIPCHK(hipMemsetAsync(d_fnl, 0, (size_t)ndof * 8, s));
+            FSCHK(fs_fused_assemble_quad_tangent(d_xyz, d_pc, d_u, d_pid, d_props, (int32_t)P, E, npat, d_eptr, d_elems,
+                                                 d_rptr, d_recs, FS_FUSED_MAX_PATCH_ELEMS, d_woff, d_packed, d_KT, d_fnl,
+                                                 0, s));
+            FSCHK(fs_csr_blk_matvec(d_nbr_ptr, d_nbr, d_blk_row, N, 6, d_Kf, d_u, d_fnl, d_f, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (fs_fused_tangent_offsets(nrecs + 1, d_recs, d_woff, &nup, s) != FS_EINVAL ||
+                fs_fused_tangent_pack(nrecs, d_recs, NULL, d_Kf, d_packed, s) != FS_EINVAL ||
+                fs_fused_assemble_quad_tangent(d_xyz, NULL, d_u, d_pid, d_props, (int32_t)P, E, npat, d_eptr, d_elems, d_rptr,
+                                               d_recs, FS_FUSED_MAX_PATCH_ELEMS, d_woff, d_packed, d_KT, NULL, 0, s) != FS_EINVAL ||
+                fs_csr_blk_matvec(d_nbr_ptr, d_nbr, d_blk_row, N, 5, d_Kf, d_u, NULL, d_f, s) != FS_EINVAL ||
+                fs_shell_quad_fint_nl(d_xyz, NULL, d_u, d_pid, d_props, (int32_t)P, E, d_f, s) != FS_EINVAL)
+                return 6;
+            h_u_out = h_u;
+        }
         /* the mass matrix through the same plan (FS_FUSED_MASS): the bits of fs_shell_quad_batch(FS_WANT_M) + fs_csr_numeric_desc */
         FSCHK(fs_fused_assemble_quad(d_xyz, d_pid, d_props, (int32_t)P, E, npat, d_eptr, d_elems, d_rptr, d_recs,
                                      FS_FUSED_MAX_PATCH_ELEMS, FS_FUSED_MASS, d_Kf, NULL, s));
@@ -239,8 +276,9 @@ int main(int argc, char **argv) {
     fwrite(oh, 8, 3, out);
     if (wr_dev(out, d_indptr, (size_t)(ndof + 1) * 8) || wr_dev(out, d_indices, (size_t)nnz * 4) ||
         wr_dev(out, d_K, (size_t)nnz * 8) || wr_dev(out, d_M, (size_t)nnz * 8) || wr_dev(out, d_lump, (size_t)ndof * 8) ||
-        wr_dev(out, d_st, (size_t)E * 4))
+        wr_dev(out, d_st, (size_t)E * 4) || wr_dev(out, d_KT, (size_t)nnz * 8) || wr_dev(out, d_f, (size_t)ndof * 8))
         return 2;
+    fwrite(h_u_out, 8, (size_t)ndof, out);
     fclose(out);
     printf("cabi_driver ok: %s (%d CUs), E=%lld nblk=%lld nnz=%lld\n", name, cus, (long long)E, (long long)nblk,
            (long long)nnz);

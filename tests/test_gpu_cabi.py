@@ -23,6 +23,7 @@ def test_c_host_drives_the_whole_path(tmp_path):
     assert os.path.exists(DRIVER), "tests/cabi/cabi_driver missing: run __graft_entry__.build()"
     mesh = meshes.jittered_plate(37, 23, n_sets=8)                    # 851 elements: ragged last tile
     props = build_prop_table(util.standard_props()[:8])
+    props["nonlinear"] = 1                                            # (the Newton iterate at the end of the driver)
     E, N = mesh.element_count, mesh.node_count
     xyz = np.ascontiguousarray(mesh.coords[mesh.conn], dtype=np.float64)
     pid = np.ascontiguousarray(mesh.set_id, dtype=np.int32)
@@ -42,6 +43,9 @@ def test_c_host_drives_the_whole_path(tmp_path):
         M = np.fromfile(f, np.float64, nnz)
         lumped = np.fromfile(f, np.float64, ndof)
         status = np.fromfile(f, np.int32, E)
+        KT = np.fromfile(f, np.float64, nnz)
+        f_int = np.fromfile(f, np.float64, ndof)
+        u = np.fromfile(f, np.float64, ndof)
     assert ndof == 6 * N and nnz == 36 * nblk and not status.any()
     Ke, st = O.mitc4_K_batch(xyz, pid, props)
     Me, _ = O.mitc4_M_batch(xyz, pid, props)
@@ -53,3 +57,15 @@ def test_c_host_drives_the_whole_path(tmp_path):
     assert np.abs(M - md).max() <= 1e-13 * np.abs(md).max()
     rs = np.add.reduceat(md, ip[:-1])
     assert np.abs(lumped - rs).max() <= 1e-13 * np.abs(rs).max()
+    # the Newton iterate of the driver (fs_fused_tangent_offsets / _pack, fs_fused_assemble_quad_tangent,
+    # fs_csr_blk_matvec) against the oracle loop update_configuration; compute_tangent_stiffness; compute_internal_forces
+    kt_e = np.empty((E, 24, 24)); f_e = np.empty((E, 24))
+    for e in range(E):
+        kt_e[e], f_e[e], _ = O.mitc4_NL(xyz[e], props[pid[e]:pid[e] + 1], u[dofs[e]])
+    _, _, ktd = O.csr_assemble(dofs, ndof, kt_e)
+    fo = np.zeros(ndof)
+    for e in range(E):
+        fo[dofs[e]] += f_e[e]
+    assert np.abs(ktd - kd).max() > 1e-8 * np.abs(kd).max()                    # the iterate does change the tangent
+    assert np.abs(KT - ktd).max() <= 1e-12 * np.abs(ktd).max()
+    assert np.abs(f_int - fo).max() <= 1e-12 * np.abs(kd).max() * np.abs(u).max()
