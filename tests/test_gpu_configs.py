@@ -259,6 +259,72 @@ def test_c4_nl_cantilever_newton(oracle):
         assert bool((Kg.data == Kd.data).all()) and bool((fg == fd).all())
 
 
+def test_c4_newton_plate_full_size(oracle):
+    """The Newton bench workload at full size (400 x 3125 = 1.25 M elements, bench.newton_leg): K_T and f_int on the
+    assembled matrix against the oracle loop on sampled nodes, against the element-block route everywhere, exact symmetry
+    through two mat-vecs."""
+    import bench
+    from fem_shell_amd.assembler import MeshAssembler
+    mesh = meshes.flat_patch(0.0, 10.0, 0.0, 1.0 * bench.STRIP_NY / 40, bench.STRIP_NX, bench.STRIP_NY)
+    mat = fsa.IsotropicMaterial("cant", 1.2e6, 0.0, 1.0)
+    asm = MeshAssembler(mesh, {"elements": {"element_family": ElementFamily.SHELL, "material": mat, "thickness": 0.1,
+                                            "nonlinear": True}}, cache_blocks=False)
+    n = asm.dofs_count
+    xs = mesh.coords[:, 0]
+    rng = np.random.default_rng(11)
+    shape = np.zeros((mesh.node_count, 6))
+    shape[:, 2] = xs ** 2 / 100.0; shape[:, 4] = -2 * xs / 100.0; shape[:, 0] = -xs / 1000.0
+    u = (5e-3 * shape + 1e-6 * rng.standard_normal(shape.shape)).reshape(-1)
+    ud = torch.from_numpy(u).to(asm.device)
+    KT, f = asm.assemble_tangent_and_forces(ud)
+    assert asm._K_blk is None                                   # no element blocks on this route
+    # sampled nodes against the oracle loop
+    nodes = rng.choice(mesh.node_count, 24, replace=False)
+    touch = np.flatnonzero(np.isin(mesh.conn, nodes).any(axis=1))
+    dofs = (mesh.conn[:, :, None] * 6 + np.arange(6)).reshape(mesh.conn.shape[0], -1)
+    kt = {}
+    fsum = {int(I): np.zeros(6) for I in nodes}
+    for e in touch:
+        kt[e], fe, _ = oracle.mitc4_NL(mesh.coords[mesh.conn[e]], asm._prop_table[:1], u[dofs[e]])
+        for i, I in enumerate(mesh.conn[e]):
+            if int(I) in fsum:
+                fsum[int(I)] += fe[6 * i:6 * i + 6]
+    ip = KT.indptr.cpu().numpy()
+    worstK = worstF = 0.0
+    scale = float(KT.data.abs().max())
+    fh = f.cpu().numpy()
+    for I in nodes:
+        lo, hi = int(ip[6 * I]), int(ip[6 * I + 6])
+        m = int(ip[6 * I + 1]) - lo
+        got = KT.data[lo:hi].cpu().numpy().reshape(6, m)
+        colnodes = KT.indices[lo:lo + m:6].cpu().numpy() // 6
+        ref = np.zeros((6, m))
+        for e in touch:                                         # element order
+            loc = np.flatnonzero(mesh.conn[e] == I)
+            if loc.size:
+                i = int(loc[0])
+                for j in range(4):
+                    c = int(np.searchsorted(colnodes, mesh.conn[e, j]))
+                    ref[:, 6 * c:6 * c + 6] += kt[e][6 * i:6 * i + 6, 6 * j:6 * j + 6]
+        worstK = max(worstK, np.abs(got - ref).max())
+        worstF = max(worstF, np.abs(fh[6 * I:6 * I + 6] - fsum[int(I)]).max())
+    terms = scale * np.abs(u).max()
+    print("C4 full size: K_T rows vs oracle", worstK / scale, "f_int vs oracle / |K||u|", worstF / terms)
+    assert worstK <= 1e-12 * scale and worstF <= 1e-12 * terms
+    # exact symmetry: x' (K_T y) == y' (K_T x) up to the rounding of the products
+    x = torch.from_numpy(rng.standard_normal(n)).to(asm.device)
+    y = torch.from_numpy(rng.standard_normal(n)).to(asm.device)
+    Kx, Ky = _spmv(KT, x), _spmv(KT, y)
+    assert abs(float(y @ Kx) - float(x @ Ky)) <= 1e-12 * float(x.norm()) * float(Ky.norm())
+    # the element-block route on the whole plate
+    asm.newton_on_assembled = False
+    K2, f2 = asm.assemble_tangent_and_forces(ud)
+    errK = float((KT.data - K2.data).abs().max()) / scale
+    errF = float((f - f2).abs().max()) / terms
+    print("C4 full size: vs element-block route K_T", errK, "f_int / |K||u|", errF)
+    assert errK <= 1e-13 and errF <= 1e-13
+
+
 def test_c5_strip_full_size(oracle):
     import bench
     from fem_shell_amd.assembler import MeshAssembler
