@@ -306,6 +306,9 @@ def c2_leg(torch, steps=20):
                                     "note": ("962 patches on 256 CUs: launch latency and the tail weigh in at this size"
                                              if E < 500000 else "7 436 patches: 29 per CU")}
             out[tag]["two_kernel_ms_per_step"] = avg_ms(torch, lambda: asm.assemble_stiffness_matrix(recompute=True, fused=False), steps)
+            # the consistent mass matrix through the same plan (fs_fused_assemble_tri_mass) and through its two kernels
+            out[tag]["mass_ms_per_step"] = avg_ms(torch, lambda: asm.assemble_mass_matrix(recompute=True), steps)
+            out[tag]["mass_two_kernel_ms_per_step"] = avg_ms(torch, lambda: asm.assemble_mass_matrix(recompute=True, fused=False), steps)
             k_ms = avg_ms(torch, lambda: asm.refresh_element_matrices(want_K=True, want_M=False, check=False), steps)
             kb = 72 + 4 + 4 + 6 * 288          # 3 nodes in, 6 upper node-pair blocks out
             out[tag]["kernels"] = {"mitc3_k_lds_kernel": {

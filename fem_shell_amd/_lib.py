@@ -44,6 +44,7 @@ SIGNATURES = {
     "fs_fused_hex_plan_free": (None, [_vp]),
     "fs_fused_assemble_hex8_mass": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_assemble_tri": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_fused_assemble_tri_mass": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_tri_plan_check": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "fs_fused_tri_plan_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_fused_tri_plan_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

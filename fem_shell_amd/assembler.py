@@ -530,8 +530,13 @@ class MeshAssembler:
             return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
         if g["nn"] == 3:
             # MITC3.K / MITC3Composite.K of every element (elements/MITC3.py:935-1103) and the ADD_VALUES loop
-            if mass:
-                raise NotImplementedError("the fused MITC3+ kernel forms K (the mass matrix keeps the two-kernel route)")
+            if mass:          # MITC3.M of every element (elements/MITC3.py:1105-1138) and the loop of core/assembler.py:305-336
+                _lib.check(lib.fs_fused_assemble_tri_mass(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
+                                                          len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
+                                                          _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_nptr"]), _lib.ptr(d["nodes"]),
+                                                          _lib.ptr(d["pat_lptr"]), _lib.ptr(d["steps"]), _lib.ptr(data),
+                                                          _lib.stream_ptr()), "fs_fused_assemble_tri_mass")
+                return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
             _lib.check(lib.fs_fused_assemble_tri(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
                                                  len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
                                                  _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_nptr"]), _lib.ptr(d["nodes"]),
@@ -569,12 +574,11 @@ class MeshAssembler:
         return self._assemble(self._K_blk)
 
     def assemble_mass_matrix(self, recompute=False, fused=None) -> CsrMatrix:
-        """core/assembler.py:305-336.  On uniform MITC4+ and HEXA8 meshes a (re-)evaluation goes through the fused kernels (no element
+        """core/assembler.py:305-336.  On uniform MITC4+, MITC3+ and HEXA8 meshes a (re-)evaluation goes through the fused kernels (no element
         mass matrices in memory; `_me_array` still materialises them on demand); fused=False forces element kernel +
         assembly kernel (same bits)."""
         fused = self.use_fused if fused is None else fused
-        if ((recompute or self._M_blk is None) and fused and self._groups[0]["nn"] in (4, 8)      # MITC4+ and HEXA8
-                and self.fused_ready()):
+        if (recompute or self._M_blk is None) and fused and self.fused_ready():      # MITC4+, MITC3+ and HEXA8
             return self.assemble_mass_fused()
         if recompute or self._M_blk is None:
             self.refresh_element_matrices(want_K=False, want_M=True, check=False)

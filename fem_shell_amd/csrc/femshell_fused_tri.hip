@@ -54,15 +54,49 @@ __device__ __forceinline__ void load_tri_prop(const fs_shell_prop *src, TriProp 
     o.flags = src->flags;
 }
 
-// UNI: the model has ONE property row (every lane reads the same numbers: scalar registers, loaded once)
-template <bool UNI>
+// One contribution of the consistent mass matrix: block (ti <= tj) of the element in image slot `slot`, the arithmetic of
+// mitc3_m_kernel statement for statement (MITC3.py:1105-1138)
+__device__ __forceinline__ void tri_mass_block(const double *s_geo, int slot, int ti, int tj, const fs_shell_prop *pr,
+                                               double (&G)[6][6]) {
+    const double area = s_geo[0 * TR_S + slot];
+    double R[3][3];
+    for (int k = 0; k < 3; k++) {
+        R[0][k] = s_geo[(1 + k) * TR_S + slot]; R[1][k] = s_geo[(4 + k) * TR_S + slot]; R[2][k] = s_geo[(7 + k) * TR_S + slot];
+    }
+    const double mt = pr->m_t, mr = pr->m_r;
+    double ct = 0.0, cr = 0.0;
+    for (int g = 0; g < 3; g++) {
+        const double r = kTriR[g], s = kTriS[g];
+        const double hi = (ti == 0) ? (1.0 - r - s) : ((ti == 1) ? r : s);
+        const double hj = (tj == 0) ? (1.0 - r - s) : ((tj == 1) ? r : s);
+        ct = ct + hi * hj * mt * (1.0 / 3.0) * area;
+        cr = cr + hi * hj * mr * (1.0 / 3.0) * area;
+    }
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) G[a][b] = 0.0;
+    for (int p3 = 0; p3 < 3; p3++)
+        for (int q = 0; q < 3; q++) {
+            double st = 0.0, sr = 0.0;
+            for (int k = 0; k < 3; k++) {
+                st = FMA(R[k][p3] * ct, R[k][q], st);
+                sr = FMA(R[k][p3] * cr, R[k][q], sr);
+            }
+            G[p3][q] = st;
+            G[3 + p3][3 + q] = sr;
+        }
+}
+
+// UNI: the model has ONE property row (every lane reads the same numbers: scalar registers, loaded once).
+// MASS: the same plan, steps and sums form the consistent MASS matrix (image: area and frame only; no function image, so
+// several workgroups share a CU)
+template <bool UNI, bool MASS = false>
 __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restrict__ xyz, const int32_t *__restrict__ prop_id,
                                                          const fs_shell_prop *__restrict__ props, int32_t n_props, int64_t n_pat,
                                                          const int64_t *__restrict__ pat_eptr, const int32_t *__restrict__ pat_elems,
                                                          const int64_t *__restrict__ pat_nptr, const fs_tri_node *__restrict__ nodes,
                                                          const int64_t *__restrict__ pat_lptr, const uint32_t *__restrict__ steps,
                                                          double *__restrict__ data, int32_t *__restrict__ status) {
-    __shared__ double s_fn[23 * TR_FS];                   // shape / tying data [component][f][slot]
+    __shared__ double s_fn[MASS ? 1 : 23 * TR_FS];        // shape / tying data [component][f][slot]
     __shared__ double s_geo[10 * TR_S];                   // area, frame rows [component][slot]
     __shared__ int32_t s_pid[TR_S];
     __shared__ fs_tri_node s_node[FS_TRI_MAX_PATCH_NODES];
@@ -76,7 +110,7 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
     // per SIMD: nothing else hides a global round trip, and a plain loop exposes six of them per patch).
     const int64_t pfirst = xcd * per_xcd + (blockIdx.x >> 3);
     TriProp Pu;
-    if (UNI) load_tri_prop(props, Pu);
+    if (UNI && !MASS) load_tri_prop(props, Pu);
     static_assert(3 * TR_NT >= 4 * TR_S, "three passes of the workgroup cover the (slot, function) pairs of a patch");
     int32_t el[3] = {0, 0, 0}, pidn[3] = {0, 0, 0};
     double xs[3][9];
@@ -119,8 +153,10 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
             if (slot >= ne) continue;
             double x[3][3];
             for (int c = 0; c < 9; c++) (&x[0][0])[c] = xs[k][c];
+            if (MASS && f != 0) continue;
             TriGeom geo;
             tri_geometry(x, geo);
+            if constexpr (!MASS) {
             TriFn F;
             tri_fn(geo, f, F);
             const int w = f * TR_SS + slot;
@@ -135,6 +171,7 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
             }
             s_fn[21 * TR_FS + w] = F.dhx;
             s_fn[22 * TR_FS + w] = F.dhy;
+            }
             if (f == 0) {
                 s_geo[0 * TR_S + slot] = geo.area;
                 for (int k2 = 0; k2 < 3; k2++) {
@@ -145,7 +182,7 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
                 const int32_t pid = pidn[k];
                 s_pid[slot] = safe_pid(pid, n_props);
                 // every patch that touches the element writes the same word
-                if (status) status[ecur[k]] = geo.status | ((pid < 0 || pid >= n_props) ? FS_ST_BAD_PROP : 0);
+                if (!MASS && status) status[ecur[k]] = geo.status | ((pid < 0 || pid >= n_props) ? FS_ST_BAD_PROP : 0);
             }
         }
         if (p + wpx < pend) fetch_ids(p + wpx);
@@ -168,7 +205,9 @@ __global__ __launch_bounds__(TR_NT) void fused_tri_kernel(const double *__restri
                 const int ti = li < lj ? li : lj, tj = li < lj ? lj : li;
                 const bool tr = li > lj;
                 double G[6][6];
-                if (UNI) {
+                if constexpr (MASS) {
+                    tri_mass_block(s_geo, slot, ti, tj, props + s_pid[slot], G);
+                } else if (UNI) {
                     tri_pair_block<TR_FS, TR_S, 1, TR_SS>(s_fn, s_geo, slot, ti, tj, &Pu, G);
                 } else {
                     TriProp pr;
@@ -256,6 +295,27 @@ extern "C" int fs_fused_assemble_tri(const double *xyz, const int32_t *prop_id, 
                            n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_lptr, steps, data, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_tri_kernel", (int)e);
+    return FS_OK;
+}
+
+extern "C" int fs_fused_assemble_tri_mass(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props,
+                                          int64_t E, int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems,
+                                          const int64_t *pat_nptr, const fs_tri_node *nodes, const int64_t *pat_lptr,
+                                          const uint32_t *steps, double *data, void *stream) {
+    if (E < 0 || n_props <= 0 || n_patches < 0) return fs_fail_(FS_EINVAL, "fs_fused_assemble_tri_mass: bad sizes", 0);
+    if (E == 0 || n_patches == 0) return FS_OK;
+    if (!xyz || !prop_id || !props || !pat_eptr || !pat_elems || !pat_nptr || !nodes || !pat_lptr || !steps || !data)
+        return fs_fail_(FS_EINVAL, "fs_fused_assemble_tri_mass: null argument", 0);
+    int cus = 0;
+    if (int rc = fs_device_cu_count_(&cus)) return rc;
+    int64_t wgs = ((int64_t)cus * 4 / 8) * 8;            // 17 KB of LDS per workgroup: four per CU
+    if (wgs < 8) wgs = 8;
+    if (wgs > ((n_patches + 7) / 8) * 8) wgs = ((n_patches + 7) / 8) * 8;
+    hipLaunchKernelGGL((fused_tri_kernel<false, true>), dim3((unsigned)wgs), dim3(TR_NT), 0, (hipStream_t)stream, xyz, prop_id,
+                       props, n_props, n_patches, pat_eptr, pat_elems, pat_nptr, nodes, pat_lptr, steps, data,
+                       (int32_t *)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fs_fail_(FS_EHIP, "fused_tri_kernel (mass)", (int)e);
     return FS_OK;
 }
 

@@ -607,6 +607,14 @@ int fs_fused_assemble_tri(const double *xyz, const int32_t *prop_id, const fs_sh
 /* The kernel trusts its plan; a plan that does not come from fs_fused_tri_plan_build must pass this check once before its
  * first launch (device pointers; synchronises `stream`, allocates 24 bytes): FS_EINVAL (fs_last_error names the first
  * violated rule) instead of a GPU fault. */
+/* The consistent MASS matrix through the plan of fs_fused_assemble_tri: MITC3.M of every element (elements/MITC3.py:1105-1138)
+ * and the loop of MeshAssembler.assemble_mass_matrix (core/assembler.py:305-336) in one launch, the bits of
+ * fs_shell_tri_batch(FS_WANT_M) + fs_csr_numeric_desc (same block arithmetic, same element-order sums), no element mass
+ * matrices in memory. */
+int fs_fused_assemble_tri_mass(const double *xyz, const int32_t *prop_id, const fs_shell_prop *props, int32_t n_props, int64_t E,
+                               int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
+                               const fs_tri_node *nodes, const int64_t *pat_lptr, const uint32_t *steps, double *data,
+                               void *stream);
 int fs_fused_tri_plan_check(int64_t n_patches, const int64_t *pat_eptr, const int32_t *pat_elems, const int64_t *pat_nptr,
                             const fs_tri_node *nodes, const int64_t *pat_lptr, const uint32_t *steps, int64_t E, int64_t nnz,
                             void *stream);

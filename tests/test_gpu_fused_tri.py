@@ -108,7 +108,18 @@ def test_fused_tri_is_bitwise_the_two_kernel_path(oracle, name):
         ip, ix, kd = oracle.csr_assemble(dofs, mesh.node_count * 6, Ke)
         assert np.array_equal(ip, Kf.indptr.cpu().numpy()) and np.array_equal(ix, Kf.indices.cpu().numpy())
         assert np.abs(Kf.data.cpu().numpy() - kd).max() <= 1e-12 * np.abs(kd).max()
-    # the mass matrix and the Newton path keep the two-kernel route and still work after a fused evaluation
+    # the mass matrix through the same plan (fs_fused_assemble_tri_mass): the bits of mitc3_m_kernel + the descriptor
+    # assembly (contraction is off in both: same statements, same element-order sums)
+    M2 = asm.assemble_mass_matrix(recompute=True, fused=False)
+    Mf = asm.assemble_mass_fused()
+    torch.cuda.synchronize()
+    assert bool((_bits(Mf.data) == _bits(M2.data)).all()), int((_bits(Mf.data) != _bits(M2.data)).sum())
+    assert bool((_bits(asm.assemble_mass_matrix(recompute=True).data) == _bits(M2.data)).all())      # default route
+    if name in ("cylinder_37x23_8props", "irregular_fans"):
+        _, Me, _ = oracle.mitc3_batch(mesh.coords[mesh.conn], asm._prop_id, asm._prop_table, want_K=False, want_M=True)
+        _, _, md = oracle.csr_assemble(dofs, mesh.node_count * 6, Me)
+        assert np.abs(Mf.data.cpu().numpy() - md).max() <= 1e-13 * np.abs(md).max()
+    # the Newton path keeps the two-kernel route and still works after a fused evaluation
     M = asm.assemble_mass_matrix()
     assert torch.isfinite(M.data).all() and asm._K_blk is None
     u = 1e-4 * torch.ones(asm.dofs_count, dtype=torch.float64, device=asm.device)
