@@ -54,15 +54,15 @@ int fail(int code, const char *what, hipError_t e = hipSuccess) {
 // kept COMPACT -- per Gauss point only J^-1, the two edge-shear scale factors and detJ; dN/dx, dN/dy and the edge-tied
 // shear rows B_gamma are rebuilt in stage 2 from these with the very expressions stage 1 uses (same bits) -- because
 // the fused kernel holds the image of a whole patch (64 elements) and LDS capacity decides its occupancy.
-//   IM_GP   [g < 4][7]   ia ib ic id (J^-1 at Gauss point g), f1, f2 (r1 / 8 detJ, r2 / 8 detJ), detJ
-//   IM_ROT  sa ca sb cb  (shear rotation, MITC4.py:844-850 in algebraic form)
+//   IM_GP   [g < 4][7]   ia ib ic id (J^-1 at Gauss point g), two of the eight shear-core scalars (quad_stage1), detJ
+//   IM_ROT  (free: the shear rotation sa ca sb cb, MITC4.py:844-850, is folded into the shear core)
 //   IM_EX, IM_EY [4]     edge deltas 41, 21, 32, 34 in local axes
 //   IM_KNB  [c < 6][node]  condensation rows
 //   IM_S [15] IM_GT [18] IM_R [9] IM_INV [3]   membrane core, tying tangents, frame, Kbb^-1 (fused kernel only: the
 //                        element kernel keeps them in registers)
 //   IM_U    [c < 10][node] coupling cores (only when some element of the launch is coupled)
 // ------------------------------------------------------------------------------------------
-constexpr int IM_GP = 0, IM_ROT = 28, IM_EX = 32, IM_EY = 36, IM_KNB = 40, IM_S = 64, IM_GT = 79, IM_R = 97, IM_INV = 106;
+constexpr int IM_GP = 0, IM_EX = 32, IM_EY = 36, IM_KNB = 40, IM_S = 64, IM_GT = 79, IM_R = 97, IM_INV = 106;
 constexpr int IM_U = 109, IM_NC = 109, IM_NC_COUPLED = 149;
 constexpr int STG_SLOT = 38;               // staging slot of one 6x6 block: 36 doubles + 2 pad (304 B: the
                                            // 8-lane groups of ds_write_b128 then hit 32 distinct banks)
@@ -262,11 +262,31 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         }
         const double d8 = 8.0 * detJ, rd8 = recip(d8);
         const double f1 = divr(r1, d8, rd8), f2 = divr(r2, d8, rd8);
-        im[(IM_GP + g * 7 + 4) << 4] = f1; im[(IM_GP + g * 7 + 5) << 4] = f2; im[(IM_GP + g * 7 + 6) << 4] = detJ;
-        if (g == 0) {
-            im[(IM_ROT + 0) << 4] = sa; im[(IM_ROT + 1) << 4] = ca; im[(IM_ROT + 2) << 4] = sb; im[(IM_ROT + 3) << 4] = cb;
-            for (int t = 0; t < 4; t++) { im[(IM_EX + t) << 4] = ex[t]; im[(IM_EY + t) << 4] = ey[t]; }
+        im[(IM_GP + g * 7 + 6) << 4] = detJ;
+        const double Cs00 = pr->Cs[0], Cs01 = pr->Cs[1], Cs10 = pr->Cs[2], Cs11 = pr->Cs[3];
+        {
+            // SHEAR CORE of the node-pair blocks.  The tied shear rows of node i at a Gauss point are
+            //   Bs_i = p a_i c0_i^T + q b_i c1_i^T,  p = (sb, -cb), q = (-sa, ca),  a_i = (1 + sy_i eta) f1, b_i = (1 + sx_i xi) f2
+            // (c0_i, c1_i: the node's two edge rows, quad_node_const), so that
+            //   sum_g detJ Bs_i^T Cs Bs_j = k00 c0_i c0_j^T + k01 c0_i c1_j^T + k10 c1_i c0_j^T + k11 c1_i c1_j^T
+            // with k.. bilinear in the signs (sx, sy) of the two nodes and EIGHT element scalars -- the same sum of products
+            // as MITC4.py:986 evaluated per Gauss point, re-associated; Cs enters symmetrised (it is symmetric for every
+            // property the reference builds).  They take the place of f1, f2 in the image.
+            const double PP = sb * (Cs00 * sb - Cs01 * cb) - cb * (Cs10 * sb - Cs11 * cb);
+            const double PQ = 0.5 * ((sb * (Cs01 * ca - Cs00 * sa) - cb * (Cs11 * ca - Cs10 * sa)) +
+                                     (ca * (Cs10 * sb - Cs11 * cb) - sa * (Cs00 * sb - Cs01 * cb)));
+            const double QQ = ca * (Cs11 * ca - Cs10 * sa) - sa * (Cs01 * ca - Cs00 * sa);
+            const double t1 = detJ * f1 * f1, t2 = detJ * f1 * f2, t3 = detJ * f2 * f2;
+            double sc[8];
+            sc[0] = PP * quad_sum(t1);          sc[1] = PP * quad_sum(t1 * eta);
+            sc[2] = PQ * quad_sum(t2);          sc[3] = PQ * quad_sum(t2 * eta);
+            sc[4] = PQ * quad_sum(t2 * xi);     sc[5] = PQ * quad_sum(t2 * (xi * eta));
+            sc[6] = QQ * quad_sum(t3);          sc[7] = QQ * quad_sum(t3 * xi);
+            for (int n = 0; n < 4; n++)
+                if (n == g) { im[(IM_GP + n * 7 + 4) << 4] = sc[2 * n]; im[(IM_GP + n * 7 + 5) << 4] = sc[2 * n + 1]; }
         }
+        if (g == 0)
+            for (int t = 0; t < 4; t++) { im[(IM_EX + t) << 4] = ex[t]; im[(IM_EY + t) << 4] = ey[t]; }
         // node -> (edge of row 0 [eta-edges 21/34], weight), (edge of row 1 [xi-edges 41/32], weight)
         const double me = 1.0 - eta, pe = 1.0 + eta, mx = 1.0 - xi, px = 1.0 + xi;
         const int e0[4] = {1, 1, 3, 3}, e1[4] = {0, 2, 2, 0};
@@ -278,7 +298,6 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         const double Cb00 = pr->D[0], Cb01 = pr->D[1], Cb02 = pr->D[2];
         const double Cb10 = pr->D[3], Cb11 = pr->D[4], Cb12 = pr->D[5];
         const double Cb20 = pr->D[6], Cb21 = pr->D[7], Cb22 = pr->D[8];
-        const double Cs00 = pr->Cs[0], Cs01 = pr->Cs[1], Cs10 = pr->Cs[2], Cs11 = pr->Cs[3];
         const double Nb = (1.0 - xi * xi) * (1.0 - eta * eta);
         const double dNbxi = -2.0 * xi * (1.0 - eta * eta), dNbeta = -2.0 * eta * (1.0 - xi * xi);
         const double bx = ia * dNbxi + ib * dNbeta, by = ic * dNbxi + id * dNbeta;
@@ -350,23 +369,6 @@ __device__ __forceinline__ void quad_node_const(const double *im, int n, QuadNod
     c.c1[0] = 0.5 * c.sy; c.c1[1] = -ey1 * 0.25; c.c1[2] = ex1 * 0.25;   // h1 = -.5 -.5 .5 .5 == 0.5 sy
 }
 
-__device__ __forceinline__ void quad_node_gp(const QuadNodeConst &c, double xg, double yg, double ia, double ib,
-                                             double ic, double id, double f1, double f2, double sa, double ca,
-                                             double sb, double cb, double &dNx, double &dNy, double (&bs)[2][3]) {
-#pragma clang fp contract(on)
-    const double E = 1.0 + c.sy * yg;        // 1 -+ eta: w0 of the node, factor of dN/dxi
-    const double X = 1.0 + c.sx * xg;        // 1 -+ xi : w1 of the node, factor of dN/deta
-    const double dxi = c.qx * E, deta = c.qy * X;
-    dNx = ia * dxi + ib * deta;
-    dNy = ic * dxi + id * deta;
-    const double a0 = E * f1, a1 = X * f2;
-    for (int k = 0; k < 3; k++) {
-        const double v0 = a0 * c.c0[k], v1 = a1 * c.c1[k];
-        bs[0][k] = sb * v0 - sa * v1;
-        bs[1][k] = -cb * v0 + ca * v1;
-    }
-}
-
 // Stage 2: the 6x6 block of node pair (ti <= tj) of element Q of the image `lds`, in GLOBAL axes:
 //   R^T [ Y_i^T S Y_j + sum_g detJ (B_k^T C_b B_k + B_g^T C_s B_g + k_d B_d B_d^T) [+ coupling]
 //         - K_nb,i Kbb^-1 K_nb,j^T ] R,   symmetrised when `diag` (ti == tj; MITC4.py:1034).
@@ -380,7 +382,6 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
     QuadNodeConst ci, cj;
     quad_node_const(im, ti, ci);
     quad_node_const(im, tj, cj);
-    const double sa = im[(IM_ROT + 0) << 4], ca = im[(IM_ROT + 1) << 4], sb = im[(IM_ROT + 2) << 4], cb = im[(IM_ROT + 3) << 4];
 
     double L[6][6];
     for (int a = 0; a < 6; a++)
@@ -427,40 +428,54 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
         }
     }
 
+    // Gauss-point sums of the GEOMETRIC factors of the pair: G.. = sum_g w dN_a,i dN_b,j, H. = sum_g w dN_a,i N_j,
+    // J. = sum_g w N_i dN_a,j, NN = sum_g w N_i N_j; the constitutive numbers meet them once, after the loop (the same
+    // sums of products as MITC4.py:774-790, 909-928, 980, 1014 evaluated per Gauss point, re-associated)
+    double Gxx = 0.0, Gxy = 0.0, Gyx = 0.0, Gyy = 0.0, Hx = 0.0, Hy = 0.0, Jx = 0.0, Jy = 0.0, NN = 0.0;
     for (int gg = 0; gg < 4; gg++) {
         const double xg = (gg == 1 || gg == 2) ? kGP : -kGP, yg = (gg >= 2) ? kGP : -kGP;
         const double *gp = im + ((IM_GP + gg * 7) << 4);
-        const double ia = gp[0 << 4], ib = gp[1 << 4], ic = gp[2 << 4], id = gp[3 << 4];
-        const double f1 = gp[4 << 4], f2 = gp[5 << 4], w = gp[6 << 4];
-        double dxi_, dyi_, dxj, dyj, bi[2][3], bsj[2][3], bsi[2][3];
-        quad_node_gp(ci, xg, yg, ia, ib, ic, id, f1, f2, sa, ca, sb, cb, dxi_, dyi_, bi);
-        quad_node_gp(cj, xg, yg, ia, ib, ic, id, f1, f2, sa, ca, sb, cb, dxj, dyj, bsj);
-        for (int c = 0; c < 6; c++) (&bsi[0][0])[c] = w * (&bi[0][0])[c];
-        const double wdxi = w * dxi_, wdyi = w * dyi_;
-        // bending: L[thx,thy][thx,thy] += w Bk_i^T Cb Bk_j          (MITC4.py:774-790,980)
-        double CK[3][2];
-        for (int rr = 0; rr < 3; rr++) {
-            CK[rr][0] = -FMA(Cb[rr][1], dyj, Cb[rr][2] * dxj);
-            CK[rr][1] = FMA(Cb[rr][0], dxj, Cb[rr][2] * dyj);
+        const double ia = gp[0 << 4], ib = gp[1 << 4], ic = gp[2 << 4], id = gp[3 << 4], w = gp[6 << 4];
+        const double Ei = 1.0 + ci.sy * yg, Xi = 1.0 + ci.sx * xg, Ej = 1.0 + cj.sy * yg, Xj = 1.0 + cj.sx * xg;
+        const double dxi_i = ci.qx * Ei, deta_i = ci.qy * Xi, dxi_j = cj.qx * Ej, deta_j = cj.qy * Xj;
+        const double dxi_ = ia * dxi_i + ib * deta_i, dyi_ = ic * dxi_i + id * deta_i;
+        const double dxj = ia * dxi_j + ib * deta_j, dyj = ic * dxi_j + id * deta_j;
+        const double Ni = 0.25 * Xi * Ei, Nj = 0.25 * Xj * Ej;
+        const double wdxi = w * dxi_, wdyi = w * dyi_, wNi = w * Ni;
+        Gxx = FMA(wdxi, dxj, Gxx); Gxy = FMA(wdxi, dyj, Gxy); Gyx = FMA(wdyi, dxj, Gyx); Gyy = FMA(wdyi, dyj, Gyy);
+        Hx = FMA(wdxi, Nj, Hx); Hy = FMA(wdyi, Nj, Hy);
+        Jx = FMA(wNi, dxj, Jx); Jy = FMA(wNi, dyj, Jy);
+        NN = FMA(wNi, Nj, NN);
+    }
+    // bending: L[thx,thy][thx,thy] += sum_g w Bk_i^T Cb Bk_j, Bk = [[0, dNx], [-dNy, 0], [-dNx, dNy]]
+    L[3][3] += (Cb[1][1] * Gyy + Cb[1][2] * Gyx) + (Cb[2][1] * Gxy + Cb[2][2] * Gxx);
+    L[3][4] -= (Cb[1][0] * Gyx + Cb[1][2] * Gyy) + (Cb[2][0] * Gxx + Cb[2][2] * Gxy);
+    L[4][3] -= (Cb[0][1] * Gxy + Cb[0][2] * Gxx) + (Cb[2][1] * Gyy + Cb[2][2] * Gyx);
+    L[4][4] += (Cb[0][0] * Gxx + Cb[0][2] * Gxy) + (Cb[2][0] * Gyx + Cb[2][2] * Gyy);
+    // drilling: k sum_g w outer(Bd_i, Bd_j) on (u, v, thz), Bd = (-dNy / 2, dNx / 2, -N)
+    {
+        const double q = 0.25 * kd, h = 0.5 * kd;
+        L[0][0] += q * Gyy; L[0][1] -= q * Gyx; L[0][5] += h * Hy;
+        L[1][0] -= q * Gxy; L[1][1] += q * Gxx; L[1][5] -= h * Hx;
+        L[5][0] += h * Jy;  L[5][1] -= h * Jx;  L[5][5] += kd * NN;
+    }
+    // shear: L[w,thx,thy][w,thx,thy] += k00 c0_i c0_j^T + k01 c0_i c1_j^T + k10 c1_i c0_j^T + k11 c1_i c1_j^T (shear core of
+    // quad_stage1; eta^2 = xi^2 = 1/3 at every Gauss point)
+    {
+        const double a0 = im[(IM_GP + 0 * 7 + 4) << 4], a1 = im[(IM_GP + 0 * 7 + 5) << 4];
+        const double b0 = im[(IM_GP + 1 * 7 + 4) << 4], b1 = im[(IM_GP + 1 * 7 + 5) << 4];
+        const double b2 = im[(IM_GP + 2 * 7 + 4) << 4], b3 = im[(IM_GP + 2 * 7 + 5) << 4];
+        const double c0 = im[(IM_GP + 3 * 7 + 4) << 4], c1 = im[(IM_GP + 3 * 7 + 5) << 4];
+        constexpr double k2 = kGP * kGP;
+        const double syy = ci.sy * cj.sy, sxx = ci.sx * cj.sx;
+        const double k00 = FMA(a0, 1.0 + syy * k2, a1 * (ci.sy + cj.sy));
+        const double k11 = FMA(c0, 1.0 + sxx * k2, c1 * (ci.sx + cj.sx));
+        const double k01 = (b0 + ci.sy * b1) + cj.sx * (b2 + ci.sy * b3);
+        const double k10 = (b0 + cj.sy * b1) + ci.sx * (b2 + cj.sy * b3);
+        for (int b = 0; b < 3; b++) {
+            const double u0 = FMA(k00, cj.c0[b], k01 * cj.c1[b]), u1 = FMA(k10, cj.c0[b], k11 * cj.c1[b]);
+            for (int a = 0; a < 3; a++) L[2 + a][2 + b] = FMA(ci.c0[a], u0, FMA(ci.c1[a], u1, L[2 + a][2 + b]));
         }
-        for (int c = 0; c < 2; c++) {
-            L[3][3 + c] = FMA(-wdyi, CK[1][c], FMA(-wdxi, CK[2][c], L[3][3 + c]));
-            L[4][3 + c] = FMA(wdxi, CK[0][c], FMA(wdyi, CK[2][c], L[4][3 + c]));
-        }
-        // shear: L[w,thx,thy][w,thx,thy] += w Bs_i^T Cs Bs_j        (MITC4.py:986)
-        double CS[2][3];
-        for (int rr = 0; rr < 2; rr++)
-            for (int b = 0; b < 3; b++) CS[rr][b] = FMA(Cs[rr][0], bsj[0][b], Cs[rr][1] * bsj[1][b]);
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(bsi[0][a], CS[0][b], FMA(bsi[1][a], CS[1][b], L[2 + a][2 + b]));
-        // drilling: k w outer(Bd_i, Bd_j) on (u,v,thz)                (MITC4.py:909-928,1014)
-        const double Ni = 0.25 * (1.0 + ci.sx * xg) * (1.0 + ci.sy * yg);
-        const double Nj = 0.25 * (1.0 + cj.sx * xg) * (1.0 + cj.sy * yg);
-        const double bdi[3] = {-0.5 * wdyi * kd, 0.5 * wdxi * kd, -Ni * (w * kd)};
-        const double bdj[3] = {-0.5 * dyj, 0.5 * dxj, -Nj};
-        const int dm[3] = {0, 1, 5};
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) L[dm[a]][dm[b]] = FMA(bdi[a], bdj[b], L[dm[a]][dm[b]]);
     }
     // bubble condensation: L[w,thx,thy][w,thx,thy] -= (Knb_i Kbb^-1) Knb_j^T (MITC4.py:996)
     {
