@@ -373,10 +373,8 @@ __device__ __forceinline__ void quad_node_const(const double *im, int n, QuadNod
 //   R^T [ Y_i^T S Y_j + sum_g detJ (B_k^T C_b B_k + B_g^T C_s B_g + k_d B_d B_d^T) [+ coupling]
 //         - K_nb,i Kbb^-1 K_nb,j^T ] R,   symmetrised when `diag` (ti == tj; MITC4.py:1034).
 __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti, int tj, bool diag,
-                                                const double (&Sf)[5][5], const double (&gt)[6][3],
                                                 const double (&R)[3][3], double i00, double i01, double i11,
-                                                const double (&Cb)[3][3], const double (&Cs)[2][2], double kd,
-                                                bool any_coupled, double (&G)[6][6]) {
+                                                const double (&Cb)[3][3], double kd, bool any_coupled, double (&G)[6][6]) {
 #pragma clang fp contract(on)
     const double *im = lds + Q;
     QuadNodeConst ci, cj;
@@ -387,42 +385,49 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
     for (int a = 0; a < 6; a++)
         for (int b = 0; b < 6; b++) L[a][b] = 0.0;
 
-    // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j   (MITC4.py:934-944 pre-contracted)
-    double Yi[5][3], Yj[5][3];
+    // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j   (MITC4.py:934-944 pre-contracted).  A node has THREE non-zero tying rows:
+    // g_r at A or B (weight sx / 2), g_s at C or D (weight sy / 2) and the centre row (sy g_r(E) + sx g_s(E)) / 8 -- the
+    // rows and the core entries they meet are read from the image (IM_GT, IM_S) by index
+    const int ai = (ti >= 2) ? 0 : 1, bi = (ti == 1 || ti == 2) ? 0 : 1;        // tying rows ai, 2 + bi, 4 of node ti
+    const int aj = (tj >= 2) ? 0 : 1, bj = (tj == 1 || tj == 2) ? 0 : 1;
+    double Yi[3][3], Yj[3][3];
+    for (int k = 0; k < 3; k++) {
+        const double g4 = im[(IM_GT + 12 + k) << 4], g5 = im[(IM_GT + 15 + k) << 4];
+        Yi[0][k] = (0.5 * ci.sx) * im[(IM_GT + 3 * ai + k) << 4];
+        Yi[1][k] = (0.5 * ci.sy) * im[(IM_GT + 6 + 3 * bi + k) << 4];
+        Yi[2][k] = (0.125 * ci.sy) * g4 + (0.125 * ci.sx) * g5;
+        Yj[0][k] = (0.5 * cj.sx) * im[(IM_GT + 3 * aj + k) << 4];
+        Yj[1][k] = (0.5 * cj.sy) * im[(IM_GT + 6 + 3 * bj + k) << 4];
+        Yj[2][k] = (0.125 * cj.sy) * g4 + (0.125 * cj.sx) * g5;
+    }
     {
-        double wi[6], wj[6];
-        tying_weights(ti, wi);
-        tying_weights(tj, wj);
-        for (int k = 0; k < 3; k++) {
-            for (int t = 0; t < 4; t++) { Yi[t][k] = wi[t] * gt[t][k]; Yj[t][k] = wj[t] * gt[t][k]; }
-            Yi[4][k] = wi[4] * gt[4][k] + wi[5] * gt[5][k];
-            Yj[4][k] = wj[4] * gt[4][k] + wj[5] * gt[5][k];
-        }
+        // upper-triangle index (row-major, t <= u) of the core entries S(T_i[p], T_j[q]), T = (a, 2 + b, 4)
+        const int n[3][3] = {{ai + aj + 3 * ai * aj, 2 + bj + 4 * ai, 4 + 4 * ai},
+                             {2 + bi + 4 * aj, 9 + bi + bj + bi * bj, 11 + 2 * bi},
+                             {4 + 4 * aj, 11 + 2 * bj, 14}};
         for (int b = 0; b < 3; b++) {
-            double SY[5];
-            for (int t = 0; t < 5; t++) {
-                double v = Sf[t][0] * Yj[0][b];
-                for (int u = 1; u < 5; u++) v = FMA(Sf[t][u], Yj[u][b], v);
-                SY[t] = v;
+            double SY[3];
+            for (int p = 0; p < 3; p++) {
+                double v = im[(IM_S + n[p][0]) << 4] * Yj[0][b];
+                v = FMA(im[(IM_S + n[p][1]) << 4], Yj[1][b], v);
+                v = FMA(im[(IM_S + n[p][2]) << 4], Yj[2][b], v);
+                SY[p] = v;
             }
-            for (int a = 0; a < 3; a++) {
-                double v = Yi[0][a] * SY[0];
-                for (int t = 1; t < 5; t++) v = FMA(Yi[t][a], SY[t], v);
-                L[a][b] = v;
-            }
+            for (int a = 0; a < 3; a++) L[a][b] = FMA(Yi[2][a], SY[2], FMA(Yi[1][a], SY[1], Yi[0][a] * SY[0]));
         }
     }
     // membrane-bending coupling: L[uvw_i][th_j] += Y_i^T U_j ; L[th_i][uvw_j] += U_i^T Y_j
     if (any_coupled) {
+        const int Ti[3] = {ai, 2 + bi, 4}, Tj[3] = {aj, 2 + bj, 4};
         for (int c = 0; c < 2; c++) {
-            double Ui[5], Uj[5];
-            for (int t = 0; t < 5; t++) {
-                Ui[t] = im[(IM_U + (2 * t + c) * 4 + ti) << 4];
-                Uj[t] = im[(IM_U + (2 * t + c) * 4 + tj) << 4];
+            double Uj[3], Ui[3];       // cores of node tj at the rows of node ti, and the other way round
+            for (int p = 0; p < 3; p++) {
+                Uj[p] = im[(IM_U + (2 * Ti[p] + c) * 4 + tj) << 4];
+                Ui[p] = im[(IM_U + (2 * Tj[p] + c) * 4 + ti) << 4];
             }
             for (int a = 0; a < 3; a++) {
                 double v = L[a][3 + c], w2 = L[3 + c][a];
-                for (int t = 0; t < 5; t++) { v = FMA(Yi[t][a], Uj[t], v); w2 = FMA(Ui[t], Yj[t][a], w2); }
+                for (int p = 0; p < 3; p++) { v = FMA(Yi[p][a], Uj[p], v); w2 = FMA(Ui[p], Yj[p][a], w2); }
                 L[a][3 + c] = v; L[3 + c][a] = w2;
             }
         }
@@ -540,21 +545,19 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     QuadElem el;
     quad_stage1(x, pr, coupled, any_coupled, g, Q, lds, geo, el);
     if (status && valid && g == 0) status[e] = el.st;
+    // membrane core and tying tangents go to the image: stage 2 reads them by tying row (quad_pair_block)
+    if (g == 0) {
+        for (int n = 0; n < 15; n++) lds[((IM_S + n) << 4) + Q] = el.S[n];
+    } else if (g == 1) {
+        for (int t = 0; t < 18; t++) lds[((IM_GT + t) << 4) + Q] = (&el.gt[0][0])[t];
+    }
 
     __syncthreads();
 
     // ---------------- stage 2: node-pair tasks ----------------
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
-    const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
     const double R[3][3] = {{geo.e1[0], geo.e1[1], geo.e1[2]}, {geo.e2[0], geo.e2[1], geo.e2[2]}, {geo.e3[0], geo.e3[1], geo.e3[2]}};
-    // full symmetric 5x5 view of S
-    double Sf[5][5];
-    {
-        int n = 0;
-        for (int t = 0; t < 5; t++)
-            for (int u = t; u < 5; u++) { Sf[t][u] = el.S[n]; Sf[u][t] = el.S[n]; n++; }
-    }
 
     for (int round = 0; round < 3; round++) {
         int ti, tj;
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
         else if (round == 1) { ti = (g == 3) ? 0 : g; tj = (g == 3) ? 3 : g + 1; }
         else { ti = g & 1; tj = (g & 1) + 2; active = active && (g < 2); }
         double G[6][6];
-        quad_pair_block(lds, Q, ti, tj, round == 0, Sf, el.gt, R, el.i00, el.i01, el.i11, Cb, Cs, kd, any_coupled, G);
+        quad_pair_block(lds, Q, ti, tj, round == 0, R, el.i00, el.i01, el.i11, Cb, kd, any_coupled, G);
         if constexpr (TILED) {
             // ---- FS_LAYOUT_SYMBLK_T16 output.  A lane that stores its own 288-byte block issues 18
             // instructions of 64 scattered 16-byte pieces; that form costs 0.45 ms of 1.58 ms per 1.25 M
@@ -654,21 +657,14 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
     const int T = slot >> 4, Q = slot & 15;
     const double *img = lds + T * LY::TILE;
     const double *ex = img + Q;
-    double Sf[5][5], gt[6][3], R[3][3];
-    {
-        int n = 0;
-        for (int t = 0; t < 5; t++)
-            for (int u = t; u < 5; u++) { const double v = ex[(IM_S + n) << 4]; Sf[t][u] = v; Sf[u][t] = v; n++; }
-    }
-    for (int t = 0; t < 18; t++) (&gt[0][0])[t] = ex[(IM_GT + t) << 4];
+    double R[3][3];
     for (int t = 0; t < 9; t++) (&R[0][0])[t] = ex[(IM_R + t) << 4];
     const double i00 = ex[(IM_INV + 0) << 4], i01 = ex[(IM_INV + 1) << 4], i11 = ex[(IM_INV + 2) << 4];
     const fs_shell_prop *pr = props + (s_pid[slot] & (FS_SLOT_COUPLED - 1));
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
-    const double Cs[2][2] = {{pr->Cs[0], pr->Cs[1]}, {pr->Cs[2], pr->Cs[3]}};
     const double kd = pr->k_drill;
     double G[6][6];
-    quad_pair_block(img, Q, ti, tj, ti == tj, Sf, gt, R, i00, i01, i11, Cb, Cs, kd, COUPLED && any_coupled, G);
+    quad_pair_block(img, Q, ti, tj, ti == tj, R, i00, i01, i11, Cb, kd, COUPLED && any_coupled, G);
     const bool tr = FS_EV_TR(ev);
     for (int k = 0; k < 6; k++)
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
