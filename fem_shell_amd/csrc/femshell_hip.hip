@@ -102,7 +102,7 @@ __host__ __device__ __forceinline__ int64_t quad_blk(int tiled, int64_t e, int p
 // ------------------------------------------------------------------------------------------
 struct QuadElem {       // per-element results of stage 1 that stage 2 needs beside the LDS image
     double S[15];       // upper triangle of the 5x5 membrane core, row-major (t <= u)
-    double gt[6][3];    // tying tangents g_r(A), g_r(B), g_s(C), g_s(D), g_r(E), g_s(E) in the element frame
+    double gt[6][3];    // tying tangents g_r(A), g_r(B), g_s(C), g_s(D), g_r(E), g_s(E), global axes
     double i00, i01, i11;   // Kbb^-1 (zero when singular: no condensation)
     int st;             // FS_ST_* bits
 #ifdef FS_FUSED_TIMING
@@ -137,23 +137,19 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
     int st = geo.status | ((detJ > 0.0) ? 0 : FS_ST_BAD_JAC);
 
     // tangent vectors at the 5 tying points (MITC4.py:589-612 evaluated at A,B,C,D,E; the zero
-    // shape-derivative terms are dropped, which is exact), projected on the frame (:287-296).
+    // shape-derivative terms are dropped, which is exact), in GLOBAL axes: the membrane part of a node-pair block is
+    // formed in global axes directly (the reference projects them on the frame, :287-296, and rotates K_m back).
     // gt[0..3] = g_r(A), g_r(B), g_s(C), g_s(D); gt[4], gt[5] = g_r(E), g_s(E)
     double (&gt)[6][3] = el.gt;
     {
-        double t3[3];
-        for (int k = 0; k < 3; k++) t3[k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
-        gt[0][0] = dot3(t3, geo.e1); gt[0][1] = dot3(t3, geo.e2); gt[0][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[1][k];
-        gt[1][0] = dot3(t3, geo.e1); gt[1][1] = dot3(t3, geo.e2); gt[1][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[1][k] + 0.5 * x[2][k];
-        gt[2][0] = dot3(t3, geo.e1); gt[2][1] = dot3(t3, geo.e2); gt[2][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = -0.5 * x[0][k] + 0.5 * x[3][k];
-        gt[3][0] = dot3(t3, geo.e1); gt[3][1] = dot3(t3, geo.e2); gt[3][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
-        gt[4][0] = dot3(t3, geo.e1); gt[4][1] = dot3(t3, geo.e2); gt[4][2] = dot3(t3, geo.e3);
-        for (int k = 0; k < 3; k++) t3[k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
-        gt[5][0] = dot3(t3, geo.e1); gt[5][1] = dot3(t3, geo.e2); gt[5][2] = dot3(t3, geo.e3);
+        for (int k = 0; k < 3; k++) {
+            gt[0][k] = 0.5 * x[2][k] + (-0.5 * x[3][k]);
+            gt[1][k] = -0.5 * x[0][k] + 0.5 * x[1][k];
+            gt[2][k] = -0.5 * x[1][k] + 0.5 * x[2][k];
+            gt[3][k] = -0.5 * x[0][k] + 0.5 * x[3][k];
+            gt[4][k] = ((-0.25 * x[0][k] + 0.25 * x[1][k]) + 0.25 * x[2][k]) + (-0.25 * x[3][k]);
+            gt[5][k] = ((-0.25 * x[0][k] + (-0.25 * x[1][k])) + 0.25 * x[2][k]) + 0.25 * x[3][k];
+        }
     }
 
     FS_T1(1);
@@ -381,9 +377,13 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
     quad_node_const(im, ti, ci);
     quad_node_const(im, tj, cj);
 
-    double L[6][6];
+    // L: the parts formed in the element frame (bending, shear, drilling, condensation); Gm: membrane block, GLOBAL axes
+    // (global tying tangents); Ctr / Crt: membrane-bending coupling, translations global, rotations (thx, thy) local
+    double L[6][6], Gm[3][3], Ctr[3][2], Crt[2][3];
     for (int a = 0; a < 6; a++)
         for (int b = 0; b < 6; b++) L[a][b] = 0.0;
+    for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 2; c++) { Ctr[a][c] = 0.0; Crt[c][a] = 0.0; }
 
     // membrane: L[u,v,w][u,v,w] = Y_i^T S Y_j   (MITC4.py:934-944 pre-contracted).  A node has THREE non-zero tying rows:
     // g_r at A or B (weight sx / 2), g_s at C or D (weight sy / 2) and the centre row (sy g_r(E) + sx g_s(E)) / 8 -- the
@@ -413,7 +413,7 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
                 v = FMA(im[(IM_S + n[p][2]) << 4], Yj[2][b], v);
                 SY[p] = v;
             }
-            for (int a = 0; a < 3; a++) L[a][b] = FMA(Yi[2][a], SY[2], FMA(Yi[1][a], SY[1], Yi[0][a] * SY[0]));
+            for (int a = 0; a < 3; a++) Gm[a][b] = FMA(Yi[2][a], SY[2], FMA(Yi[1][a], SY[1], Yi[0][a] * SY[0]));
         }
     }
     // membrane-bending coupling: L[uvw_i][th_j] += Y_i^T U_j ; L[th_i][uvw_j] += U_i^T Y_j
@@ -426,9 +426,9 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
                 Ui[p] = im[(IM_U + (2 * Tj[p] + c) * 4 + ti) << 4];
             }
             for (int a = 0; a < 3; a++) {
-                double v = L[a][3 + c], w2 = L[3 + c][a];
+                double v = 0.0, w2 = 0.0;
                 for (int p = 0; p < 3; p++) { v = FMA(Yi[p][a], Uj[p], v); w2 = FMA(Ui[p], Yj[p][a], w2); }
-                L[a][3 + c] = v; L[3 + c][a] = w2;
+                Ctr[a][c] = v; Crt[c][a] = w2;
             }
         }
     }
@@ -494,17 +494,40 @@ __device__ __forceinline__ void quad_pair_block(const double *lds, int Q, int ti
             for (int b = 0; b < 3; b++) L[2 + a][2 + b] = FMA(-h0, kj[b][0], FMA(-h1, kj[b][1], L[2 + a][2 + b]));
         }
     }
-    // rotation to global axes, 3x3 block-wise: G = R^T X R  (MITC4.py:634-640,1032-1033)
-    for (int ba = 0; ba < 2; ba++)
-        for (int bb = 0; bb < 2; bb++) {
-            double Y[3][3];
-            for (int p = 0; p < 3; p++)
-                for (int q = 0; q < 3; q++)
-                    Y[p][q] = FMA(R[2][p], L[3 * ba + 2][3 * bb + q], FMA(R[1][p], L[3 * ba + 1][3 * bb + q], R[0][p] * L[3 * ba][3 * bb + q]));
-            for (int p = 0; p < 3; p++)
-                for (int q = 0; q < 3; q++)
-                    G[3 * ba + p][3 * bb + q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], Y[p][0] * R[0][q]));
+    // rotation to global axes, 3x3 block-wise: G = R^T X R  (MITC4.py:634-640,1032-1033) -- of what was formed in the
+    // element frame only, along its non-zero pattern: tt {[0..1][0..1], [2][2]}, tr {[2][3..4], [0..1][5]}, rt likewise,
+    // rr {[3..4][3..4], [5][5]}
+    {
+        double Y[3][3];
+        for (int p = 0; p < 3; p++) {                       // translations x translations
+            Y[p][0] = FMA(R[1][p], L[1][0], R[0][p] * L[0][0]);
+            Y[p][1] = FMA(R[1][p], L[1][1], R[0][p] * L[0][1]);
+            Y[p][2] = R[2][p] * L[2][2];
         }
+        for (int p = 0; p < 3; p++)
+            for (int q = 0; q < 3; q++) G[p][q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], FMA(Y[p][0], R[0][q], Gm[p][q])));
+        for (int p = 0; p < 3; p++) {                       // translations x rotations
+            Y[p][0] = FMA(R[2][p], L[2][3], Ctr[p][0]);
+            Y[p][1] = FMA(R[2][p], L[2][4], Ctr[p][1]);
+            Y[p][2] = FMA(R[1][p], L[1][5], R[0][p] * L[0][5]);
+        }
+        for (int p = 0; p < 3; p++)
+            for (int q = 0; q < 3; q++) G[p][3 + q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], Y[p][0] * R[0][q]));
+        for (int q = 0; q < 3; q++) {                       // rotations x translations: Y = X R (+ coupling), then R^T Y
+            Y[0][q] = FMA(L[3][2], R[2][q], Crt[0][q]);
+            Y[1][q] = FMA(L[4][2], R[2][q], Crt[1][q]);
+            Y[2][q] = FMA(L[5][1], R[1][q], L[5][0] * R[0][q]);
+        }
+        for (int p = 0; p < 3; p++)
+            for (int q = 0; q < 3; q++) G[3 + p][q] = FMA(R[2][p], Y[2][q], FMA(R[1][p], Y[1][q], R[0][p] * Y[0][q]));
+        for (int p = 0; p < 3; p++) {                       // rotations x rotations
+            Y[p][0] = FMA(R[1][p], L[4][3], R[0][p] * L[3][3]);
+            Y[p][1] = FMA(R[1][p], L[4][4], R[0][p] * L[3][4]);
+            Y[p][2] = R[2][p] * L[5][5];
+        }
+        for (int p = 0; p < 3; p++)
+            for (int q = 0; q < 3; q++) G[3 + p][3 + q] = FMA(Y[p][2], R[2][q], FMA(Y[p][1], R[1][q], Y[p][0] * R[0][q]));
+    }
     if (diag) {  // diagonal block: K = 0.5 (K + K^T)  (MITC4.py:1034)
         for (int a = 0; a < 6; a++)
             for (int b = a + 1; b < 6; b++) {
