@@ -17,13 +17,10 @@ __global__ __launch_bounds__(256) PROBE_ATTR void probe_part(const double *in, d
     for (int t = threadIdx.x; t < LDS_WAVE; t += 256) lds[t] = in[t];
     __syncthreads();
     const double *p = in + LDS_WAVE + threadIdx.x * 128;
-    double Sf[5][5], gt[6][3], R[3][3], Cb[3][3], Cs[2][2];
-    for (int t = 0; t < 25; t++) (&Sf[0][0])[t] = p[t];
-    for (int t = 0; t < 18; t++) (&gt[0][0])[t] = p[25 + t];
+    double R[3][3], Cb[3][3];      // (membrane core, tying tangents and the shear core are read from the image since round 3)
     for (int t = 0; t < 9; t++) { (&R[0][0])[t] = p[43 + t]; (&Cb[0][0])[t] = p[52 + t]; }
-    for (int t = 0; t < 4; t++) (&Cs[0][0])[t] = p[61 + t];
     double G[6][6];
-    quad_pair_block(lds, threadIdx.x & 15, ti, tj, false, Sf, gt, R, p[65], p[66], p[67], Cb, Cs, p[68], C, G);
+    quad_pair_block(lds, threadIdx.x & 15, ti, tj, false, R, p[65], p[66], p[67], Cb, p[68], C, G);
     for (int a = 0; a < NR; a++)
         for (int b = 0; b < NC; b++) out[threadIdx.x * 36 + a * 6 + b] = G[a][b];
 }
