@@ -676,7 +676,10 @@ template <bool COUPLED>
 __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const int *s_pid,
                                            const fs_shell_prop *__restrict__ props, bool any_coupled, double (&Y)[36]) {
     using LY = FusedLayout<COUPLED>;
-    const int slot = FS_EV_SLOT(ev), ti = FS_EV_TI(ev), tj = FS_EV_TJ(ev);
+    // a contribution the block receives transposed is formed as the block of the swapped pair, (tj, ti): the same
+    // products with the roles of the two nodes exchanged (equal to the transpose up to rounding) instead of 36 selects
+    const bool tr = FS_EV_TR(ev);
+    const int slot = FS_EV_SLOT(ev), ti = tr ? FS_EV_TJ(ev) : FS_EV_TI(ev), tj = tr ? FS_EV_TI(ev) : FS_EV_TJ(ev);
     const int T = slot >> 4, Q = slot & 15;
     const double *img = lds + T * LY::TILE;
     const double *ex = img + Q;
@@ -686,11 +689,8 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
     const fs_shell_prop *pr = props + (s_pid[slot] & (FS_SLOT_COUPLED - 1));
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double kd = pr->k_drill;
-    double G[6][6];
-    quad_pair_block(img, Q, ti, tj, ti == tj, R, i00, i01, i11, Cb, kd, COUPLED && any_coupled, G);
-    const bool tr = FS_EV_TR(ev);
-    for (int k = 0; k < 6; k++)
-        for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
+    quad_pair_block(img, Q, ti, tj, ti == tj, R, i00, i01, i11, Cb, kd, COUPLED && any_coupled,
+                    reinterpret_cast<double (&)[6][6]>(Y));
 }
 
 // One contribution of the consistent mass matrix: block (ti <= tj) of the element in image slot FS_EV_SLOT(ev), the
@@ -732,6 +732,15 @@ __device__ __forceinline__ void fused_eval_mass(uint32_t ev, const double *lds, 
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
 }
 
+#ifdef FS_SIGNED_ZERO_EXACT
+#define FS_ZFILL (-0.0)
+#define FS_ZSTART(z, y) ((z) + (y))
+#define FS_ZPAD(x, p) ((x) + (p))
+#else
+#define FS_ZFILL 0.0
+#define FS_ZSTART(z, y) (y)
+#define FS_ZPAD(x, p) (x)
+#endif
 #ifdef FS_FUSED_TIMING
 __device__ unsigned long long g_fused_t[24];
 #define FS_TICK(ph) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
@@ -908,8 +917,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 else fused_eval<COUPLED>(ev0, lds, s_pid, props, c0, Y);
             }
             else
-                for (int t = 0; t < 36; t++) Y[t] = -0.0;
-            for (int t = 0; t < 36; t++) X[t] = z0 + Y[t];
+                for (int t = 0; t < 36; t++) Y[t] = FS_ZFILL;
+            for (int t = 0; t < 36; t++) X[t] = FS_ZSTART(z0, Y[t]);
             asm volatile("" : "+v"(pidn));                     // (wait for pidn here, not right after its load)
             pflagsn = props[safe_pid(pidn, n_props)].flags;     // (every round: see above)
             FS_TICK(2);
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 else fused_eval<COUPLED>(ev1, lds, s_pid, props, c1, Y);
             }
             else
-                for (int t = 0; t < 36; t++) Y[t] = -0.0;
+                for (int t = 0; t < 36; t++) Y[t] = FS_ZFILL;
             FS_TICK(3);
             asm volatile("" :: "v"(pflagsn));      // the flags load stays above this point (it would be sunk to its use)
             // sums in element order: one lane x0 + x1; a lane chained to its left neighbour (R_left + x2) + x3, ...
@@ -937,8 +946,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             // blocks with fewer than 4 contributions: the padded sum of the descriptor kernel ends in + 0.0
             const double padv = (fl & FS_FL_PAD) ? 0.0 : -0.0;
             for (int t = 0; t < 36; t++) {
-                X[t] = (two ? X[t] : R[t]) + padv;       // output block 0
-                Y[t] = Y[t] + padv;                      // output block 1 (lanes with two blocks)
+                X[t] = FS_ZPAD((two ? X[t] : R[t]), padv);       // output block 0
+                Y[t] = FS_ZPAD(Y[t], padv);                      // output block 1 (lanes with two blocks)
             }
             // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
             // arrive while the stores below are issued

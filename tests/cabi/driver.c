@@ -15,6 +15,7 @@
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -182,7 +183,16 @@ int main(int argc, char **argv) {
         HIPCHK(hipMemcpy(kf, d_Kf, (size_t)nnz * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(st2, d_st, (size_t)E * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(stf, d_stf, (size_t)E * 4, hipMemcpyDeviceToHost));
-        if (memcmp(k2, kf, (size_t)nnz * 8) != 0 || memcmp(st2, stf, (size_t)E * 4) != 0) return 8;
+        /* the two routes sum the same blocks in the same order; a contribution received transposed is formed by the fused
+         * kernel as the block of the swapped node pair, so the values agree to rounding, the status words exactly */
+        {
+            double kmax = 0.0, dmax = 0.0;
+            for (int64_t i = 0; i < nnz; i++) {
+                if (fabs(k2[i]) > kmax) kmax = fabs(k2[i]);
+                if (!(fabs(kf[i] - k2[i]) <= dmax)) dmax = fabs(kf[i] - k2[i]);
+            }
+            if (!(dmax <= 2e-14 * kmax) || memcmp(st2, stf, (size_t)E * 4) != 0) return 8;
+        }
         /* one Newton iterate on the assembled matrix (update_configuration + compute_tangent_stiffness /
          * compute_internal_forces of every element + the assembly loops): packed linear blocks once, then K_T and the
          * nonlinear nodal forces in one launch, f_int = K u + f_nl */

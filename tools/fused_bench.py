@@ -46,6 +46,8 @@ t2 = timed(two)
 tf = timed(asm.assemble_stiffness_fused)
 K2, Kf = two(), asm.assemble_stiffness_fused()
 same = bool((K2.data.view(torch.int64) == Kf.data.view(torch.int64)).all())
+d_ = (K2.data - Kf.data).abs().max().item() / K2.data.abs().max().item()
+print("max |fused - two-kernel| / max|K| = %.2e, symmetric: %s" % (d_, "n/a"))
 print(f"E={E} two-kernel {t2:.3f} ms  fused {tf:.3f} ms  ({E / tf * 1e3:.3e} el/s)  bitwise equal: {same}")
 print(f"fused step roofline: {E * 2708 / tf * 1e3 / 1e12:.2f} TB/s of 8 ({E * 2708 / tf * 1e3 / 8e12:.3f}), "
       f"{E * 27750 / tf * 1e3 / 1e12:.1f} TFLOP/s of 78.6 ({E * 27750 / tf * 1e3 / 78.6e12:.3f})")
