@@ -204,6 +204,41 @@ __device__ __forceinline__ double quad_sum(double v) {
     return v;
 }
 
+// The same reductions with the four Gauss-point lanes of an element on the four 16-lane ROWS of the wave (lane = g * 16 + Q)
+// through gfx950's row swaps: v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its
+// second, v_permlane16_swap the odd rows of the first with the even rows of the second, so that a + b after a swap holds the
+// partial sums of a in one half (or row parity) and of b in the other -- a TRANSPOSING reduction: four values go in, and row r
+// comes out with the sum over the rows of value kRowsPi[r] of its column (nine instructions for four values; the DPP
+// all-reduce above takes six per value plus its hazard waits).  tools/exp/permlane_probe.hip checks the lane map on the GPU.
+__device__ __forceinline__ void rows_swap32(double &a, double &b) {
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double(hi[0], lo[0]); b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void rows_swap16(double &a, double &b) {
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double(hi[0], lo[0]); b = __hiloint2double(hi[1], lo[1]);
+}
+// row r receives the column sums of value rows_pi(r): rows 0..3 -> values 0, 2, 1, 3
+__device__ __forceinline__ int rows_pi(int g) { return ((g & 1) << 1) | (g >> 1); }
+__device__ __forceinline__ double rows_sum4(double v0, double v1, double v2, double v3) {
+    rows_swap32(v0, v1); rows_swap32(v2, v3);
+    double a = v0 + v1, b = v2 + v3;
+    rows_swap16(a, b);
+    return a + b;
+}
+// every row receives the column sum of v
+__device__ __forceinline__ double rows_allsum(double v) {
+    double a = v, b = v;
+    rows_swap32(a, b);
+    a = a + b; b = a;
+    rows_swap16(a, b);
+    return a + b;
+}
+
 // tying shape-derivative weights of node i: dN/dxi at A,B ; dN/deta at C,D ; dN/deta, dN/dxi at E
 __device__ __forceinline__ void tying_weights(int i, double *w) {
     w[0] = (i == 2) ? 0.5 : ((i == 3) ? -0.5 : 0.0);    // A (0, 1)

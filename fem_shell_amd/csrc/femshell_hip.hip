@@ -119,6 +119,11 @@ struct QuadElem {       // per-element results of stage 1 that stage 2 needs bes
 // Gauss point -> LDS image `lds` (layout IM_* above, element Q of the 16-element tile), bubble blocks and membrane
 // core reduced over the quad with DPP.
 // All four lanes of every quad must be active.  any_coupled: uniform over the quad.
+// ROWS (the fused kernel): the four Gauss-point lanes of element Q are lanes g * 16 + Q, the sums over the Gauss points are
+// transposing row reductions (rows_sum4: every sum arrives on ONE lane, which writes it to the image -- the membrane core
+// too, el.S is then scratch); otherwise lanes 4 Q + g and DPP all-reductions inside the quad.  The two forms add the four
+// Gauss-point terms in different orders: equal to rounding.
+template <bool ROWS>
 __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_shell_prop *pr, bool coupled,
                                             bool any_coupled, int g, int Q, double *lds, QuadGeom &geo, QuadElem &el) {
     double Bv[9];       // coupling matrix: fetched up front, in one batch, by every lane of a wave that needs it (a load at
@@ -135,6 +140,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
     double ia, ib, ic, id;
     const double detJ = jacobian(geo, dxi, deta, ia, ib, ic, id);
     int st = geo.status | ((detJ > 0.0) ? 0 : FS_ST_BAD_JAC);
+    const int pig = rows_pi(g);            // ROWS: the value of a group of four this lane's row receives
 
     // tangent vectors at the 5 tying points (MITC4.py:589-612 evaluated at A,B,C,D,E; the zero
     // shape-derivative terms are dropped, which is exact), in GLOBAL axes: the membrane part of a node-pair block is
@@ -213,6 +219,20 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             double Bl[3][3];
             for (int a = 0; a < 3; a++)
                 for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? detJ * Bv[a * 3 + b] : 0.0;
+            if constexpr (ROWS) {
+                double LK[4][3][2];
+                for (int j = 0; j < 4; j++)
+                    for (int a = 0; a < 3; a++) {
+                        LK[j][a][0] = -(Bl[a][1] * dNy[j] + Bl[a][2] * dNx[j]);
+                        LK[j][a][1] = Bl[a][0] * dNx[j] + Bl[a][2] * dNy[j];
+                    }
+                for (int t = 0; t < 5; t++)
+                    for (int c = 0; c < 2; c++) {
+                        double u[4];
+                        for (int j = 0; j < 4; j++) u[j] = W[0][t] * LK[j][0][c] + W[1][t] * LK[j][1][c] + W[2][t] * LK[j][2][c];
+                        im[(IM_U + (2 * t + c) * 4 + pig) << 4] = rows_sum4(u[0], u[1], u[2], u[3]);
+                    }
+            } else
             for (int j = 0; j < 4; j++) {
                 double LK[3][2];
                 for (int a = 0; a < 3; a++) {
@@ -273,6 +293,14 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
                                      (ca * (Cs10 * sb - Cs11 * cb) - sa * (Cs00 * sb - Cs01 * cb)));
             const double QQ = ca * (Cs11 * ca - Cs10 * sa) - sa * (Cs01 * ca - Cs00 * sa);
             const double t1 = detJ * f1 * f1, t2 = detJ * f1 * f2, t3 = detJ * f2 * f2;
+            if constexpr (ROWS) {
+                // scalars 0..3 and 4..7 as two groups of four: this row receives numbers pig and 4 + pig (odd rows: pig >= 2)
+                const double sA = rows_sum4(t1, t1 * eta, t2, t2 * eta);
+                const double sB = rows_sum4(t2 * xi, t2 * (xi * eta), t3, t3 * xi);
+                const bool up = pig >= 2;
+                im[(IM_GP + (pig >> 1) * 7 + 4 + (pig & 1)) << 4] = (up ? PQ : PP) * sA;
+                im[(IM_GP + (2 + (pig >> 1)) * 7 + 4 + (pig & 1)) << 4] = (up ? QQ : PQ) * sB;
+            } else {
             double sc[8];
             sc[0] = PP * quad_sum(t1);          sc[1] = PP * quad_sum(t1 * eta);
             sc[2] = PQ * quad_sum(t2);          sc[3] = PQ * quad_sum(t2 * eta);
@@ -280,6 +308,7 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             sc[6] = QQ * quad_sum(t3);          sc[7] = QQ * quad_sum(t3 * xi);
             for (int n = 0; n < 4; n++)
                 if (n == g) { im[(IM_GP + n * 7 + 4) << 4] = sc[2 * n]; im[(IM_GP + n * 7 + 5) << 4] = sc[2 * n + 1]; }
+            }
         }
         if (g == 0)
             for (int t = 0; t < 4; t++) { im[(IM_EX + t) << 4] = ex[t]; im[(IM_EY + t) << 4] = ey[t]; }
@@ -303,6 +332,31 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         const double q20 = -Cb21 * by - Cb22 * bx, q21 = Cb20 * bx + Cb22 * by;
         // Bsb = [[0,Nb],[-Nb,0]] ; Cs*Bsb (2x2)
         const double s00 = -Cs01 * Nb, s01 = Cs00 * Nb, s10 = -Cs11 * Nb, s11 = Cs10 * Nb;
+        if constexpr (ROWS) {
+            double a0[4], a1[4], kx0[4], kx1[4], ky0[4], ky1[4];
+            for (int i = 0; i < 4; i++) {
+                a0[i] = w0[i] * f1; a1[i] = w1[i] * f2;
+                kx0[i] = -dNy[i] * q10 - dNx[i] * q20; kx1[i] = -dNy[i] * q11 - dNx[i] * q21;
+                ky0[i] = dNx[i] * q00 + dNy[i] * q20;  ky1[i] = dNx[i] * q01 + dNy[i] * q21;
+            }
+            for (int k = 0; k < 3; k++) {
+                double n0[4], n1[4];
+                for (int i = 0; i < 4; i++) {
+                    const double c0 = (k == 0) ? h0[i] : ((k == 1) ? -ey[e0[i]] * 0.25 : ex[e0[i]] * 0.25);
+                    const double c1 = (k == 0) ? h1[i] : ((k == 1) ? -ey[e1[i]] * 0.25 : ex[e1[i]] * 0.25);
+                    const double v0 = a0[i] * c0, v1 = a1[i] * c1;
+                    const double b0 = sb * v0 - sa * v1;
+                    const double b1 = -cb * v0 + ca * v1;
+                    double m0 = b0 * s00 + b1 * s10;
+                    double m1 = b0 * s01 + b1 * s11;
+                    if (k == 1) { m0 += kx0[i]; m1 += kx1[i]; }
+                    if (k == 2) { m0 += ky0[i]; m1 += ky1[i]; }
+                    n0[i] = detJ * m0; n1[i] = detJ * m1;
+                }
+                im[(IM_KNB + (2 * k) * 4 + pig) << 4] = rows_sum4(n0[0], n0[1], n0[2], n0[3]);
+                im[(IM_KNB + (2 * k + 1) * 4 + pig) << 4] = rows_sum4(n1[0], n1[1], n1[2], n1[3]);
+            }
+        } else
         for (int i = 0; i < 4; i++) {
             const double a0 = w0[i] * f1, a1 = w1[i] * f2;
             const double v0[3] = {a0 * h0[i], a0 * (-ey[e0[i]] * 0.25), a0 * (ex[e0[i]] * 0.25)};
@@ -332,10 +386,23 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
     }
     FS_T1(5);
+    if constexpr (ROWS) {
+        // membrane core: four groups of four (the last one padded); row g writes entries 4 k + pig
+        for (int k4 = 0; k4 < 4; k4++) {
+            const double v = rows_sum4(S[4 * k4], S[4 * k4 + 1], S[4 * k4 + 2], (k4 < 3) ? S[4 * k4 + 3] : 0.0);
+            if (4 * k4 + pig < 15) im[(IM_S + 4 * k4 + pig) << 4] = v;
+        }
+        kbb00 = rows_allsum(kbb00); kbb01 = rows_allsum(kbb01); kbb11 = rows_allsum(kbb11);
+        // FS_ST_BAD_JAC of any of the element's four Gauss points (the other bits are the same on its four lanes)
+        unsigned long long bj = __ballot((st & FS_ST_BAD_JAC) != 0);
+        bj |= bj >> 32; bj |= bj >> 16;
+        if ((bj >> Q) & 1ull) st |= FS_ST_BAD_JAC;
+    } else {
     for (int n = 0; n < 15; n++) S[n] = quad_sum(S[n]);
     kbb00 = quad_sum(kbb00); kbb01 = quad_sum(kbb01); kbb11 = quad_sum(kbb11);
     st |= __builtin_amdgcn_update_dpp(0, st, 0xB1, 0xF, 0xF, true);
     st |= __builtin_amdgcn_update_dpp(0, st, 0x4E, 0xF, 0xF, true);
+    }
     // Kbb^-1 (MITC4.py:994-998; singular -> no condensation)
     const double p0 = kbb00 * kbb11, p1 = kbb01 * kbb01;
     const double kdet = p0 - p1;
@@ -566,7 +633,7 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
     // ---------------- stage 1: Gauss point g ----------------
     QuadGeom geo;
     QuadElem el;
-    quad_stage1(x, pr, coupled, any_coupled, g, Q, lds, geo, el);
+    quad_stage1<false>(x, pr, coupled, any_coupled, g, Q, lds, geo, el);
     if (status && valid && g == 0) status[e] = el.st;
     // membrane core and tying tangents go to the image: stage 2 reads them by tying row (quad_pair_block)
     if (g == 0) {
@@ -732,15 +799,6 @@ __device__ __forceinline__ void fused_eval_mass(uint32_t ev, const double *lds, 
         for (int l = 0; l < 6; l++) Y[k * 6 + l] = tr ? G[l][k] : G[k][l];
 }
 
-#ifdef FS_SIGNED_ZERO_EXACT
-#define FS_ZFILL (-0.0)
-#define FS_ZSTART(z, y) ((z) + (y))
-#define FS_ZPAD(x, p) ((x) + (p))
-#else
-#define FS_ZFILL 0.0
-#define FS_ZSTART(z, y) (y)
-#define FS_ZPAD(x, p) (x)
-#endif
 #ifdef FS_FUSED_TIMING
 __device__ unsigned long long g_fused_t[24];
 #define FS_TICK(ph) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
@@ -764,7 +822,10 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     __shared__ double2 s_stage[4 * FZ_SLOT * SP];   // per wave: SP staging slots of 21 x 16 bytes
     __shared__ unsigned char s_tab[4 * 128];        // per wave: rank of a transposed copy -> staging slot of its block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Q = lane >> 2, g = lane & 3, slot = wave * 16 + Q;
+    // stage-1 lane map: stiffness -- Gauss point g of element Q on lane g * 16 + Q (row reductions, quad_stage1<true>);
+    // mass -- lane 4 Q + g
+    constexpr bool FQ_ROWS = (OP == FS_OP_K);
+    const int Q = FQ_ROWS ? (lane & 15) : (lane >> 2), g = FQ_ROWS ? (lane >> 4) : (lane & 3), slot = wave * 16 + Q;
     // PERSISTENT workgroups: workgroup w lives on XCD w & 7 (round-robin dispatch) and walks through that XCD's
     // contiguous range of patches -- neighbouring patches (shared halo elements, shared CSR lines) meet in one L2,
     // the stores of a patch drain while stage 1 of the next one runs, and the next patch's inputs are fetched
@@ -854,7 +915,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
 #ifdef FS_FUSED_TIMING
             acc_[18] += el.tick - tick_;       // loop top .. call of quad_stage1 (prefetch issue, waits for the inputs)
 #endif
-            quad_stage1(x, pr, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
+            quad_stage1<FQ_ROWS>(x, pr, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
 #ifdef FS_FUSED_TIMING
             for (int t = 0; t < 7; t++) acc_[7 + t] += el.tacc[t];
             acc_[17] += el.tacc[7];
@@ -863,7 +924,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             if (COUPLED && !wave_coupled)
                 for (int t = 0; t < 10; t++) ex[(IM_U + t * 4 + g) << 4] = 0.0;
             if (g == 0) {
-                for (int n = 0; n < 15; n++) ex[(IM_S + n) << 4] = el.S[n];
+                if (!FQ_ROWS)
+                    for (int n = 0; n < 15; n++) ex[(IM_S + n) << 4] = el.S[n];
                 s_pid[slot] = pid | ((COUPLED && flagged) ? FS_SLOT_COUPLED : 0);
                 if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
             } else if (g == 1) {
@@ -904,21 +966,18 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 }
             }
             const uint32_t ev0 = (uint32_t)rd.x, ev1 = (uint32_t)rd.y, fl = (uint32_t)rd.z, slots = (uint32_t)rd.w;
-            // X = first contribution (-0.0 + y == y bit for bit; blocks with more than 4 contributions start from +0.0
-            // like the descriptor kernel's loop), Y = second one (-0.0 when absent: adds nothing)
+            // X = first contribution, Y = second one (+0.0 when absent: adds nothing)
             double X[36], Y[36];
-            const double z0 = (fl & FS_FL_ZERO_START) ? 0.0 : -0.0;
             const bool last_round = more && rb + 256 >= r1;
             const bool a0 = FS_EV_ACTIVE(ev0), a1 = FS_EV_ACTIVE(ev1);
             const bool c0 = COUPLED && __any(a0 && (s_pid[FS_EV_SLOT(ev0)] & FS_SLOT_COUPLED));
             const bool c1 = COUPLED && __any(a1 && (s_pid[FS_EV_SLOT(ev1)] & FS_SLOT_COUPLED));
             if (a0) {
-                if constexpr (OP == FS_OP_M) fused_eval_mass(ev0, lds, s_pid, props, Y);
-                else fused_eval<COUPLED>(ev0, lds, s_pid, props, c0, Y);
+                if constexpr (OP == FS_OP_M) fused_eval_mass(ev0, lds, s_pid, props, X);
+                else fused_eval<COUPLED>(ev0, lds, s_pid, props, c0, X);
             }
             else
-                for (int t = 0; t < 36; t++) Y[t] = FS_ZFILL;
-            for (int t = 0; t < 36; t++) X[t] = FS_ZSTART(z0, Y[t]);
+                for (int t = 0; t < 36; t++) X[t] = 0.0;
             asm volatile("" : "+v"(pidn));                     // (wait for pidn here, not right after its load)
             pflagsn = props[safe_pid(pidn, n_props)].flags;     // (every round: see above)
             FS_TICK(2);
@@ -927,28 +986,22 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 else fused_eval<COUPLED>(ev1, lds, s_pid, props, c1, Y);
             }
             else
-                for (int t = 0; t < 36; t++) Y[t] = FS_ZFILL;
+                for (int t = 0; t < 36; t++) Y[t] = 0.0;
             FS_TICK(3);
             asm volatile("" :: "v"(pflagsn));      // the flags load stays above this point (it would be sunk to its use)
             // sums in element order: one lane x0 + x1; a lane chained to its left neighbour (R_left + x2) + x3, ...
-            // Lanes that carry two single-contribution blocks keep X and Y apart.
+            // Lanes that carry two single-contribution blocks keep X and Y apart.  No selects: with m = 0 for lanes with two
+            // blocks (else 1) and c = 1 for chained lanes (else 0), R = fma(m, Y, fma(c, R_left, X)) is x0 + x1 on the first lane
+            // of a block, X alone on a lane with two blocks and (R_left + x2) + x3 on a chained lane -- fma(1, a, b) is a + b
+            // to the bit.  A chained lane at position pos is final from iteration pos on (its left neighbour was final one
+            // iteration earlier), what it holds before is never read.
             const bool two = (fl & FS_FL_OUT1) != 0, chain = (fl & FS_FL_CHAIN) != 0;
-            const int pos = (int)((fl >> 16) & 15u);
             const int maxc = __builtin_amdgcn_readfirstlane((int)((fl >> 8) & 255u));
-            double R[36];
-            for (int t = 0; t < 36; t++) R[t] = X[t] + Y[t];
+            const double mY = two ? 0.0 : 1.0, cT = chain ? 1.0 : 0.0;
+            double R[36];                                       // output block 0; Y: output block 1 (lanes with two blocks)
+            for (int t = 0; t < 36; t++) R[t] = FMA(mY, Y[t], X[t]);
             for (int it = 1; it < maxc; it++)
-                for (int t = 0; t < 36; t++) {
-                    const double T = row_shr1(R[t]);
-                    const double v = (T + X[t]) + Y[t];
-                    R[t] = (chain && pos == it) ? v : R[t];
-                }
-            // blocks with fewer than 4 contributions: the padded sum of the descriptor kernel ends in + 0.0
-            const double padv = (fl & FS_FL_PAD) ? 0.0 : -0.0;
-            for (int t = 0; t < 36; t++) {
-                X[t] = FS_ZPAD((two ? X[t] : R[t]), padv);       // output block 0
-                Y[t] = FS_ZPAD(Y[t], padv);                      // output block 1 (lanes with two blocks)
-            }
+                for (int t = 0; t < 36; t++) R[t] = FMA(mY, Y[t], FMA(cT, row_shr1(R[t]), X[t]));
             // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
             // arrive while the stores below are issued
             if (last_round) {
@@ -985,7 +1038,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 const int q0d = s0d - s0, q1d = s1d - s0;
                 if (s0d != 255 && q0d >= 0 && q0d < SP) {
                     double2 *sp = stg + q0d * FZ_SLOT;
-                    for (int t = 0; t < 18; t++) sp[t] = make_double2(X[2 * t], X[2 * t + 1]);
+                    for (int t = 0; t < 18; t++) sp[t] = make_double2(R[2 * t], R[2 * t + 1]);
                     sp[18] = make_double2(__longlong_as_double(dst0), __longlong_as_double((long long)rc.x));
                     sp[19] = make_double2(__longlong_as_double(dst0t), __longlong_as_double((long long)rc.z));
                     if (s0t != 255) tab[s0t] = (unsigned char)q0d;
