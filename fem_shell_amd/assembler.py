@@ -92,7 +92,8 @@ class _LazyElementMap:
 class MeshAssembler:
     reuse_linear_blocks = True   # K_T / f_int re-assembly reads the cached linear blocks (tiled quad meshes)
     use_fused = True             # uniform MITC4+ meshes: assemble_stiffness_matrix(recompute=True) is ONE fused
-                                 # evaluate-and-assemble launch (fs_fused_assemble_quad), bitwise the two-kernel result
+                                 # evaluate-and-assemble launch (fs_fused_assemble_quad): the two-kernel result to
+                                 # rounding (4e-16 of the largest entry), exactly symmetric, bitwise repeatable
     fused_max_patch_elems = 64   # elements per patch of the fused plan (<= 80)
     newton_on_assembled = True   # uniform MITC4+ meshes: K_T(u) = K_csr + element-order sums of the geometric corrections
                                  # (fs_fused_assemble_quad_tangent), f_int(u) = K_csr u + nonlinear membrane forces
@@ -556,7 +557,8 @@ class MeshAssembler:
 
     def assemble_stiffness_matrix(self, recompute=False, fused=None) -> CsrMatrix:
         """core/assembler.py:269-303.  recompute=True re-evaluates the element matrices: on uniform MITC4+ meshes
-        through the fused kernel (fused=False forces element kernel + assembly kernel; same bits)."""
+        through the fused kernel (fused=False forces element kernel + assembly kernel: the same sums of the same block
+        function, equal to rounding -- see fs_fused_assemble_quad in include/femshell_hip.h)."""
         fused = self.use_fused if fused is None else fused
         if (recompute or self._K_blk is None) and fused and self.fused_ready():
             # the geometry was checked when the assembler was built (the reference checks in its element constructors

@@ -329,8 +329,12 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
  * Fused evaluate-and-assemble for uniform MITC4+ quad meshes, gather form: the CSR values of K straight from the
  * coordinates, without element matrices in memory.  Replaces the whole loop of MeshAssembler.assemble_stiffness_matrix
  * over the cached element matrices (core/assembler.py:287-303) TOGETHER with the element evaluations that fill the
- * cache (core/assembler.py:160-193 -> MITC4.K, elements/MITC4.py:1018-1036); bit-identical to
- * fs_shell_quad_batch(FS_WANT_K) followed by fs_csr_numeric_desc (same block values, same element-order sums).
+ * cache (core/assembler.py:160-193 -> MITC4.K, elements/MITC4.py:1018-1036).  Same block function and the same
+ * element-order sums as fs_shell_quad_batch(FS_WANT_K) followed by fs_csr_numeric_desc; the values agree with that route to
+ * rounding (about 4e-16 of the largest entry: a contribution its block receives transposed is formed as the block of the
+ * swapped node pair, the Gauss-point sums of stage 1 run in another order), not to the bit.  The result is EXACTLY
+ * symmetric (block (J, I) is written from the registers of block (I, J)), the same bits in every run, and an entry that
+ * is exactly zero may carry either sign.  FS_FUSED_MASS is bit-identical to the two-kernel mass route.
  *
  * The mesh is cut into PATCHES of nodes (plan built once per mesh by fs_fused_plan_build below from a map node ->
  * patch: fem_shell_amd/fused.py::partition_nodes, or any map whose patches touch at most max_patch_elems elements;
