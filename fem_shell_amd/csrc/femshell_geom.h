@@ -395,17 +395,19 @@ struct TriGeom {
 __device__ __forceinline__ void tri_geometry(const double (&x)[3][3], TriGeom &t) {
     double v12[3], v13[3], n[3];
     for (int k = 0; k < 3; k++) { v12[k] = x[1][k] - x[0][k]; v13[k] = x[2][k] - x[0][k]; }
-    const double L12 = norm3(v12);
-    for (int k = 0; k < 3; k++) t.e1[k] = v12[k] / L12;
+    // (three quotients over one denominator: one shared reciprocal, the same bits as three divisions -- see recip / divr)
+    const double L12 = norm3(v12), rL12 = recip(L12);
+    for (int k = 0; k < 3; k++) t.e1[k] = divr(v12[k], L12, rL12);
     cross3(v12, v13, n);
-    const double nl = norm3(n);
+    const double nl = norm3(n), rnl = recip(nl);
     t.status = (nl >= 1e-12) ? 0 : FS_ST_NAN_FRAME;  // ValueError("Degenerate triangle")
-    for (int k = 0; k < 3; k++) t.e3[k] = n[k] / nl;
+    for (int k = 0; k < 3; k++) t.e3[k] = divr(n[k], nl, rnl);
     cross3(t.e3, t.e1, t.e2);
     t.x2 = L12; t.x3 = dot3(v13, t.e1); t.y3 = dot3(v13, t.e2);
     const double det = t.x2 * t.y3;      // J = [[x2, 0], [x3, y3]]
     t.area = 0.5 * __builtin_fabs(det);
-    t.J00 = t.y3 / det; t.J10 = -t.x3 / det; t.J11 = t.x2 / det;   // J^-1, J01^-1 == 0
+    const double rdet = recip(det);
+    t.J00 = divr(t.y3, det, rdet); t.J10 = divr(-t.x3, det, rdet); t.J11 = divr(t.x2, det, rdet);   // J^-1, J01^-1 == 0
 }
 
 

@@ -334,7 +334,9 @@ int fs_csr_numeric_desc(const double *vals, const fs_blk_desc *desc, const int64
  * rounding (about 4e-16 of the largest entry: a contribution its block receives transposed is formed as the block of the
  * swapped node pair, the Gauss-point sums of stage 1 run in another order), not to the bit.  The result is EXACTLY
  * symmetric (block (J, I) is written from the registers of block (I, J)), the same bits in every run, and an entry that
- * is exactly zero may carry either sign.  FS_FUSED_MASS is bit-identical to the two-kernel mass route.
+ * is exactly zero may carry either sign.  FS_FUSED_MASS is bit-identical to the two-kernel mass route.  An element whose
+ * matrix is not finite (status reports it) can reach the blocks summed on the neighbouring lanes of its wave as well: check
+ * status before using the values.
  *
  * The mesh is cut into PATCHES of nodes (plan built once per mesh by fs_fused_plan_build below from a map node ->
  * patch: fem_shell_amd/fused.py::partition_nodes, or any map whose patches touch at most max_patch_elems elements;
