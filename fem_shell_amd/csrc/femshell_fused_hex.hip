@@ -80,10 +80,25 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
     }
     const double gp = kGP;                                // 1 / sqrt(3)   (SOLID.py:1745-1766: order k-j-i, weights 1)
 
-    for (int64_t p = xcd * per_xcd + (blockIdx.x >> 3); p < pend; p += wpx) {
-        const int64_t e0 = pat_eptr[p], n0 = pat_nptr[p], r0 = pat_rptr[p], l0 = pat_lptr[p];
-        const int ne = (int)(pat_eptr[p + 1] - e0), nn = (int)(pat_nptr[p + 1] - n0), nr = (int)(pat_rptr[p + 1] - r0);
+    // a wave: 8 slots (fastest) x 8 Gauss points; a lane's two (slot, point) pairs of phase 1
+    const int q1 = (tid >> 3) & 7;
+    const int slotA = (tid >> 6) * 8 + (tid & 7), slotB = slotA + HX_NT / 8;
+    int64_t p = xcd * per_xcd + (blockIdx.x >> 3);
+    if (p >= pend) return;
+    // The element ids of a patch are fetched while the patch before it runs, and one word of every 24 bytes of their
+    // coordinates is touched under that patch's phase 2 (a load between arithmetic costs the wave nothing): phase 1 then
+    // starts with ONE round trip to this XCD's L2 instead of three dependent ones (header -> ids -> coordinates from HBM).
+    // 1 048 576 bricks: 1.44 -> 1.31 ms.
+    int ne = (int)(pat_eptr[p + 1] - pat_eptr[p]);
+    int32_t eA = pat_elems[pat_eptr[p] + (slotA < ne ? slotA : ne - 1)], eB = pat_elems[pat_eptr[p] + (slotB < ne ? slotB : ne - 1)];
+    for (; p < pend; p += wpx) {
+        const int64_t n0 = pat_nptr[p], r0 = pat_rptr[p], l0 = pat_lptr[p];
+        const int nn = (int)(pat_nptr[p + 1] - n0), nr = (int)(pat_rptr[p + 1] - r0);
         const int nl = (int)(pat_lptr[p + 1] - l0);
+        const int64_t pn = (p + wpx < pend) ? p + wpx : p;
+        const int64_t e0n = pat_eptr[pn];
+        const int nen = (int)(pat_eptr[pn + 1] - e0n);
+        const int32_t eAn = pat_elems[e0n + (slotA < nen ? slotA : nen - 1)], eBn = pat_elems[e0n + (slotB < nen ? slotB : nen - 1)];
         // this lane's eight steps (used after phase 1: the loads travel under it)
         uint4 sa = make_uint4(0, 0, 0, 0), sb = sa;
         if (tid < nl) {
@@ -97,9 +112,6 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
         // the element indices and coordinates of BOTH passes are requested before the first one computes (a loop exposes
         // two dependent global round trips per pass)
         static_assert(2 * HX_NT >= ((FS_HEX_MAX_PATCH_ELEMS + 7) & ~7) * 8, "two passes cover a patch");
-        const int q1 = (tid >> 3) & 7;                                // a wave: 8 slots (fastest) x 8 Gauss points
-        const int slotA = (tid >> 6) * 8 + (tid & 7), slotB = slotA + HX_NT / 8;
-        const int64_t eA = pat_elems[e0 + (slotA < ne ? slotA : ne - 1)], eB = pat_elems[e0 + (slotB < ne ? slotB : ne - 1)];
         auto gradients = [&](int slot, int q, int64_t e) {
 #pragma clang fp contract(fast)
             const double xi = (q & 1) ? gp : -gp, eta = (q & 2) ? gp : -gp, zeta = (q & 4) ? gp : -gp;
@@ -144,6 +156,10 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
         if (slotA < ne) gradients(slotA, q1, eA);
         if (slotB < ne) gradients(slotB, q1, eB);
         __syncthreads();
+        // one word of every 24 bytes of the next patch's coordinates: the lines travel to this XCD's L2 while phase 2 runs
+        // (the values are dropped behind phase 2)
+        const int32_t *xw = reinterpret_cast<const int32_t *>(xyz);
+        const int32_t tA = xw[(int64_t)eAn * 48 + q1 * 6], tB = xw[(int64_t)eBn * 48 + q1 * 6];
 
         // ---------------- phase 2: eight steps per lane ----------------
         double Kout[4][9];       // finished blocks: the plan lets blocks end at odd steps only
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                 }
             }
         }
+        asm volatile("" :: "v"(tA), "v"(tB));
         __syncthreads();        // every wave is done with the gradients: the staging image overlays them
         {
             const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
             if (tid == 64 && ((run.len - head) & 1)) dst[2 * np2] = src[2 * np2];
         }
         __syncthreads();        // the next patch's phase 1 overwrites the image
+        ne = nen; eA = eAn; eB = eBn;
     }
 }
 
@@ -290,6 +308,13 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_mass_kernel(const double *__
         }
         if (tid < nn) s_node[tid] = nodes[n0 + tid];
         if (tid >= 64 && tid - 64 < nr) s_run[tid - 64] = runs[r0 + tid - 64];
+        // the next patch's elements of this lane: their coordinates and property ids are touched under the steps below and
+        // wait in this XCD's L2 when its phase 1 asks for them (see fused_hex8_kernel)
+        const int64_t pn = (p + wpx < pend) ? p + wpx : p;
+        const int64_t e0n = pat_eptr[pn];
+        const int nen = (int)(pat_eptr[pn + 1] - e0n);
+        const int sA = tid >> 3, sB = sA + HX_NT / 8;
+        const int32_t eAn = pat_elems[e0n + (sA < nen ? sA : nen - 1)], eBn = pat_elems[e0n + (sB < nen ? sB : nen - 1)];
         for (int t = tid; t < ne * 8; t += HX_NT) {
 #pragma clang fp contract(fast)
             const int slot = t >> 3, q = t & 7;
@@ -315,6 +340,9 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_mass_kernel(const double *__
             for (int i = 0; i < 8; i++) g[i] = sw * N[i];
         }
         __syncthreads();
+        const int32_t *xw = reinterpret_cast<const int32_t *>(xyz);
+        const int32_t tA = xw[(int64_t)eAn * 48 + (tid & 7) * 6], tB = xw[(int64_t)eBn * 48 + (tid & 7) * 6];
+        const int32_t tC = prop_id[(tid & 1) ? eBn : eAn];
         double Mout[4];
         {
 #pragma clang fp contract(fast)
@@ -333,6 +361,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_mass_kernel(const double *__
                 if ((s & 1) && HX_FLUSH(r)) { Mout[s >> 1] = acc; acc = 0.0; }
             }
         }
+        asm volatile("" :: "v"(tA), "v"(tB), "v"(tC));
         __syncthreads();
         {
             const uint32_t rec[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
