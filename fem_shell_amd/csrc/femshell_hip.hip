@@ -862,6 +862,15 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     unsigned long long acc_[19] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
+    // Vector-memory operations return IN ORDER: a load issued behind a patch's store burst (36 instructions per wave,
+    // 124 KB per CU, draining at the chip's write rate for several microseconds) comes back only after it -- and the
+    // compiler guards every loaded value that is still pending when the loop comes round with a conservative vmcnt wait
+    // at its first use, i.e. at the top of stage 1.  Two measures keep stage 1 free of vector-memory waits: (1) an
+    // explicit vmcnt(0) in front of the loop and between the staging writes and the stores of a pass, where every
+    // prefetch has long arrived: the wait-count bookkeeping then carries nothing round the loop; (2) the property row of
+    // a wave whose elements share one is read through a uniform pointer, i.e. SCALAR loads, which another counter
+    // tracks (waves across a laminate boundary keep the per-lane loads and wait for the stores).  Strip 1.49 -> 1.42 ms.
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0); lgkmcnt and expcnt untouched
     for (;;) {
         // element of the next patch for this lane (header already here), header of the patch after it
         const int64_t pn = p + wpx, pnn = pn + wpx;
@@ -883,6 +892,9 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             const bool valid = slot < ne;
             int bad = 0;
             if (pid < 0 || pid >= n_props) { pid = 0; bad = FS_ST_BAD_PROP; }     // never read outside the table
+            // one property row for the whole wave (3 of 4 waves of the bench plate): uniform pointer, scalar loads
+            const int pid_u = __builtin_amdgcn_readfirstlane(pid);
+            const bool pid_uniform = __all(pid == pid_u);
             const fs_shell_prop *pr = props + pid;
             const bool flagged = (pflags & FS_PROP_COUPLED) != 0;
             if (OP == FS_OP_K && !COUPLED && flagged) bad = FS_ST_BAD_PROP;      // caller promised a table without coupled rows
@@ -915,7 +927,8 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
 #ifdef FS_FUSED_TIMING
             acc_[18] += el.tick - tick_;       // loop top .. call of quad_stage1 (prefetch issue, waits for the inputs)
 #endif
-            quad_stage1<FQ_ROWS>(x, pr, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
+            if (pid_uniform) quad_stage1<FQ_ROWS>(x, props + pid_u, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
+            else quad_stage1<FQ_ROWS>(x, pr, COUPLED && flagged, wave_coupled, g, Q, img, geo, el);
 #ifdef FS_FUSED_TIMING
             for (int t = 0; t < 7; t++) acc_[7 + t] += el.tacc[t];
             acc_[17] += el.tacc[7];
@@ -1052,6 +1065,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): every prefetch is in before the stores go out (see the loop top)
                 FS_TICK(15);
                 // direct copies: piece pc -> (block pc / 3, piece pc % 3)
                 const int nhere = (nd - s0 < SP) ? nd - s0 : SP;
