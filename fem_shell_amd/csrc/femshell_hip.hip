@@ -95,8 +95,9 @@ __host__ __device__ __forceinline__ int64_t quad_blk(int tiled, int64_t e, int p
 // removes B_m from LDS and from the Gauss-point loop of every node-pair task.
 //
 // Stage 1 (quad_stage1) and the node-pair block of stage 2 (quad_pair_block) are shared by mitc4_k_kernel and the
-// fused evaluate-and-assemble kernel (fused_quad_k_kernel), which must produce the SAME bits.  They are therefore
-// compiled with `fp contract(on)`: a*b + c contracts where the SOURCE expression says so (clang emits llvm.fmuladd,
+// fused evaluate-and-assemble kernel (fused_quad_k_kernel).  Through round 2 the two had to produce the SAME bits; since
+// round 3 the fused kernel orders its Gauss-point sums and its transposes differently (quad_stage1<true>, fused_eval) and
+// agrees to rounding.  The functions are still compiled with `fp contract(on)`: a*b + c contracts where the SOURCE expression says so (clang emits llvm.fmuladd,
 // always an FMA for f64 on gfx950), never across statements, so the rounding sequence does not depend on the
 // kernel the functions are inlined into (contract(fast) lets the backend pick which product of a*b + c*d to fuse).
 // ------------------------------------------------------------------------------------------
@@ -696,17 +697,18 @@ __global__ __launch_bounds__(64) void mitc4_k_kernel(const double *__restrict__ 
 //
 // A workgroup owns a PATCH of nodes (fem_shell_amd/fused.py builds the plan for any quad mesh):
 //   stage 1  every element that touches a patch node (<= 16 NT of them; the one-element halo is recomputed) runs
-//            quad_stage1 exactly as in mitc4_k_kernel, 16 elements per wave; besides the strain-displacement image
+//            quad_stage1 (the row-reduction form, lane = Gauss point * 16 + element), 16 elements per wave; besides the
+//            strain-displacement image
 //            the per-element data that stage 2 of mitc4_k_kernel keeps in registers (membrane core S, tying
 //            tangents, frame, Kbb^-1) goes to LDS, because here a lane meets elements it did not evaluate;
-//   stage 2  a lane evaluates ONE contribution (element, local node pair) of a CSR node-pair block (I <= J) with
-//            quad_pair_block -- the same bits as mitc4_k_kernel writes to FS_LAYOUT_SYMBLK -- the <= 4
-//            contributions of a block sit on adjacent lanes of a quad and are summed IN ELEMENT ORDER with DPP
-//            ( ((x0 + x1) + x2) + x3, absent terms +0.0: the sum of csr_numeric_desc6_lds_kernel and of the
-//            reference's ADD_VALUES insertion order), and the group's first lane stores the block to (I,J) and,
-//            transposed, to (J,I).  Blocks with more than 4 contributions (nodes of valence > 4) are summed by one
-//            lane serially (0 + y0 + y1 + ..., again the order of the descriptor kernel).
-// The result is bitwise the CSR of mitc4_k_kernel + csr_numeric_desc6_lds_kernel; HBM traffic per element drops from
+//   stage 2  a lane evaluates up to TWO contributions (element, local node pair) of a CSR node-pair block (I <= J) with
+//            quad_pair_block (a contribution the block receives transposed: the block of the swapped pair); the
+//            contributions of a block sit on adjacent lanes and are summed IN ELEMENT ORDER along DPP row_shr chains
+//            ( ((x0 + x1) + x2) + x3 ...: the order of csr_numeric_desc6_lds_kernel and of the reference's ADD_VALUES
+//            insertion), and the chain's last lane hands the block to the staging area, from which it is stored to
+//            (I,J) and, transposed, to (J,I).
+// The result equals the CSR of mitc4_k_kernel + csr_numeric_desc6_lds_kernel to rounding, is exactly symmetric and the
+// same bits in every run (the mass operator: the same bits as the two-kernel route); HBM traffic per element drops from
 // 2 880 (blocks out) + 2 880 (blocks in) + 2 592 (CSR out) + 432 (descriptors) to 2 592 + ~330 (plan records).
 // ------------------------------------------------------------------------------------------
 // operator of the fused kernel: stiffness K (image IM_*, quad_stage1 / quad_pair_block) or consistent mass M (image
