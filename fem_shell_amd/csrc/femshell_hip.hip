@@ -758,7 +758,8 @@ __device__ __forceinline__ void fused_eval(uint32_t ev, const double *lds, const
     const fs_shell_prop *pr = props + (s_pid[slot] & (FS_SLOT_COUPLED - 1));
     const double Cb[3][3] = {{pr->D[0], pr->D[1], pr->D[2]}, {pr->D[3], pr->D[4], pr->D[5]}, {pr->D[6], pr->D[7], pr->D[8]}};
     const double kd = pr->k_drill;
-    quad_pair_block(img, Q, ti, tj, ti == tj, R, i00, i01, i11, Cb, kd, COUPLED && any_coupled,
+    // (diagonal blocks are symmetrised once, on the sum of their contributions: see the patch loop)
+    quad_pair_block(img, Q, ti, tj, false, R, i00, i01, i11, Cb, kd, COUPLED && any_coupled,
                     reinterpret_cast<double (&)[6][6]>(Y));
 }
 
@@ -1017,6 +1018,27 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             for (int t = 0; t < 36; t++) R[t] = FMA(mY, Y[t], X[t]);
             for (int it = 1; it < maxc; it++)
                 for (int t = 0; t < 36; t++) R[t] = FMA(mY, Y[t], FMA(cT, row_shr1(R[t]), X[t]));
+            // diagonal blocks: K = (K + K^T) / 2 of every element (MITC4.py:1034) taken on the SUM of the block's contributions
+            // (the same number up to rounding, 15 means per block instead of per contribution; a diagonal block has
+            // diagonal contributions only).  The mass blocks are symmetric as they are formed.
+            if constexpr (OP == FS_OP_K) {
+                if (a0 && FS_EV_TI(ev0) == FS_EV_TJ(ev0)) {
+                    for (int a = 0; a < 6; a++)
+                        for (int b = a + 1; b < 6; b++) {
+                            const double m = 0.5 * (R[a * 6 + b] + R[b * 6 + a]);
+                            R[a * 6 + b] = m; R[b * 6 + a] = m;
+                        }
+                }
+                const bool dg1 = two && a1 && FS_EV_TI(ev1) == FS_EV_TJ(ev1);       // (a corner node's block on a two-block lane)
+                if (__any(dg1)) {
+                    if (dg1)
+                        for (int a = 0; a < 6; a++)
+                            for (int b = a + 1; b < 6; b++) {
+                                const double m = 0.5 * (Y[a * 6 + b] + Y[b * 6 + a]);
+                                Y[a * 6 + b] = m; Y[b * 6 + a] = m;
+                            }
+                }
+            }
             // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
             // arrive while the stores below are issued
             if (last_round) {
