@@ -207,6 +207,13 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         // S partial = detJ W^T Cm W
         {
             double CW[3][5];
+            if constexpr (ROWS) {       // detJ on the nine constitutive numbers instead of the fifteen products
+                double AJ[9];
+                for (int t = 0; t < 9; t++) AJ[t] = detJ * pr->A[t];
+                for (int a = 0; a < 3; a++)
+                    for (int t = 0; t < 5; t++)
+                        CW[a][t] = AJ[a * 3 + 0] * W[0][t] + AJ[a * 3 + 1] * W[1][t] + AJ[a * 3 + 2] * W[2][t];
+            } else
             for (int a = 0; a < 3; a++)
                 for (int t = 0; t < 5; t++)
                     CW[a][t] = detJ * (pr->A[a * 3 + 0] * W[0][t] + pr->A[a * 3 + 1] * W[1][t] + pr->A[a * 3 + 2] * W[2][t]);
@@ -221,18 +228,19 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             for (int a = 0; a < 3; a++)
                 for (int b = 0; b < 3; b++) Bl[a][b] = coupled ? detJ * Bv[a * 3 + b] : 0.0;
             if constexpr (ROWS) {
-                double LK[4][3][2];
-                for (int j = 0; j < 4; j++)
-                    for (int a = 0; a < 3; a++) {
-                        LK[j][a][0] = -(Bl[a][1] * dNy[j] + Bl[a][2] * dNx[j]);
-                        LK[j][a][1] = Bl[a][0] * dNx[j] + Bl[a][2] * dNy[j];
+                // W^T Bl first (5 x 3), then the two non-zero curvature rows of every node: the products of the quad form
+                // below in another order
+                for (int t = 0; t < 5; t++) {
+                    double WB[3];
+                    for (int b = 0; b < 3; b++) WB[b] = W[0][t] * Bl[0][b] + W[1][t] * Bl[1][b] + W[2][t] * Bl[2][b];
+                    double u0[4], u1[4];
+                    for (int j = 0; j < 4; j++) {
+                        u0[j] = -(WB[1] * dNy[j] + WB[2] * dNx[j]);
+                        u1[j] = WB[0] * dNx[j] + WB[2] * dNy[j];
                     }
-                for (int t = 0; t < 5; t++)
-                    for (int c = 0; c < 2; c++) {
-                        double u[4];
-                        for (int j = 0; j < 4; j++) u[j] = W[0][t] * LK[j][0][c] + W[1][t] * LK[j][1][c] + W[2][t] * LK[j][2][c];
-                        im[(IM_U + (2 * t + c) * 4 + pig) << 4] = rows_sum4(u[0], u[1], u[2], u[3]);
-                    }
+                    im[(IM_U + (2 * t) * 4 + pig) << 4] = rows_sum4(u0[0], u0[1], u0[2], u0[3]);
+                    im[(IM_U + (2 * t + 1) * 4 + pig) << 4] = rows_sum4(u1[0], u1[1], u1[2], u1[3]);
+                }
             } else
             for (int j = 0; j < 4; j++) {
                 double LK[3][2];
@@ -334,29 +342,41 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         // Bsb = [[0,Nb],[-Nb,0]] ; Cs*Bsb (2x2)
         const double s00 = -Cs01 * Nb, s01 = Cs00 * Nb, s10 = -Cs11 * Nb, s11 = Cs10 * Nb;
         if constexpr (ROWS) {
-            double a0[4], a1[4], kx0[4], kx1[4], ky0[4], ky1[4];
-            for (int i = 0; i < 4; i++) {
-                a0[i] = w0[i] * f1; a1[i] = w1[i] * f2;
-                kx0[i] = -dNy[i] * q10 - dNx[i] * q20; kx1[i] = -dNy[i] * q11 - dNx[i] * q21;
-                ky0[i] = dNx[i] * q00 + dNy[i] * q20;  ky1[i] = dNx[i] * q01 + dNy[i] * q21;
-            }
+            // The same sum of products as the quad form below with detJ and the Gauss-point factors taken out of the
+            // (row k, node i) loop: the shear part of entry (k, c) of node i is
+            //   detJ (a_i c0 (sb s0c - cb s1c) + b_i c1 (ca s1c - sa s0c)),  a_i = w0_i f1, b_i = w1_i f2
+            // and w0, w1 take two values each, so that four products per column c cover the four nodes; the bending part
+            // carries detJ through bx, by.  Kbb uses the scaled factors too.
+            const double NbJ = detJ * Nb, bxJ = detJ * bx, byJ = detJ * by;
+            const double z00 = -Cs01 * NbJ, z01 = Cs00 * NbJ, z10 = -Cs11 * NbJ, z11 = Cs10 * NbJ;
+            const double P0[2] = {f1 * (sb * z00 - cb * z10), f1 * (sb * z01 - cb * z11)};
+            const double P1[2] = {f2 * (ca * z10 - sa * z00), f2 * (ca * z11 - sa * z01)};
+            const double A0m[2] = {me * P0[0], me * P0[1]}, A0p[2] = {pe * P0[0], pe * P0[1]};
+            const double A1m[2] = {mx * P1[0], mx * P1[1]}, A1p[2] = {px * P1[0], px * P1[1]};
+            const double r00 = -Cb01 * byJ - Cb02 * bxJ, r01 = Cb00 * bxJ + Cb02 * byJ;
+            const double r10 = -Cb11 * byJ - Cb12 * bxJ, r11 = Cb10 * bxJ + Cb12 * byJ;
+            const double r20 = -Cb21 * byJ - Cb22 * bxJ, r21 = Cb20 * bxJ + Cb22 * byJ;
+            const double qy[4] = {-0.25 * ey[0], -0.25 * ey[1], -0.25 * ey[2], -0.25 * ey[3]};
+            const double qx[4] = {0.25 * ex[0], 0.25 * ex[1], 0.25 * ex[2], 0.25 * ex[3]};
             for (int k = 0; k < 3; k++) {
                 double n0[4], n1[4];
                 for (int i = 0; i < 4; i++) {
-                    const double c0 = (k == 0) ? h0[i] : ((k == 1) ? -ey[e0[i]] * 0.25 : ex[e0[i]] * 0.25);
-                    const double c1 = (k == 0) ? h1[i] : ((k == 1) ? -ey[e1[i]] * 0.25 : ex[e1[i]] * 0.25);
-                    const double v0 = a0[i] * c0, v1 = a1[i] * c1;
-                    const double b0 = sb * v0 - sa * v1;
-                    const double b1 = -cb * v0 + ca * v1;
-                    double m0 = b0 * s00 + b1 * s10;
-                    double m1 = b0 * s01 + b1 * s11;
-                    if (k == 1) { m0 += kx0[i]; m1 += kx1[i]; }
-                    if (k == 2) { m0 += ky0[i]; m1 += ky1[i]; }
-                    n0[i] = detJ * m0; n1[i] = detJ * m1;
+                    const double c0 = (k == 0) ? h0[i] : ((k == 1) ? qy[e0[i]] : qx[e0[i]]);
+                    const double c1 = (k == 0) ? h1[i] : ((k == 1) ? qy[e1[i]] : qx[e1[i]]);
+                    const double A00 = (i < 2) ? A0m[0] : A0p[0], A01 = (i < 2) ? A0m[1] : A0p[1];
+                    const double A10 = (i == 0 || i == 3) ? A1m[0] : A1p[0], A11 = (i == 0 || i == 3) ? A1m[1] : A1p[1];
+                    double t0 = 0.0, t1 = 0.0;
+                    if (k == 1) { t0 = -dNy[i] * r10 - dNx[i] * r20; t1 = -dNy[i] * r11 - dNx[i] * r21; }
+                    if (k == 2) { t0 = dNx[i] * r00 + dNy[i] * r20;  t1 = dNx[i] * r01 + dNy[i] * r21; }
+                    n0[i] = (k == 0) ? (c0 * A00 + c1 * A10) : FMA(c0, A00, FMA(c1, A10, t0));
+                    n1[i] = (k == 0) ? (c0 * A01 + c1 * A11) : FMA(c0, A01, FMA(c1, A11, t1));
                 }
                 im[(IM_KNB + (2 * k) * 4 + pig) << 4] = rows_sum4(n0[0], n0[1], n0[2], n0[3]);
                 im[(IM_KNB + (2 * k + 1) * 4 + pig) << 4] = rows_sum4(n1[0], n1[1], n1[2], n1[3]);
             }
+            kbb00 = (-by) * r10 + (-bx) * r20 + (-Nb) * z10;
+            kbb01 = (-by) * r11 + (-bx) * r21 + (-Nb) * z11;
+            kbb11 = bx * r01 + by * r21 + Nb * z01;
         } else
         for (int i = 0; i < 4; i++) {
             const double a0 = w0[i] * f1, a1 = w1[i] * f2;
@@ -382,9 +402,11 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             }
         }
         // Kbb = Bkb^T Cb Bkb + Bsb^T Cs Bsb
-        kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
-        kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
-        kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
+        if constexpr (!ROWS) {
+            kbb00 = detJ * ((-by) * q10 + (-bx) * q20 + (-Nb) * s10);
+            kbb01 = detJ * ((-by) * q11 + (-bx) * q21 + (-Nb) * s11);
+            kbb11 = detJ * (bx * q01 + by * q21 + Nb * s01);
+        }
     }
     FS_T1(5);
     if constexpr (ROWS) {
