@@ -37,7 +37,23 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
     p = a[2] * b[0]; q = a[0] * b[2]; c[1] = p - q;
     p = a[0] * b[1]; q = a[1] * b[0]; c[2] = p - q;
 }
-__device__ __forceinline__ double norm3(const double *a) { return __builtin_sqrt(dot3(a, a)); }
+// IEEE square root without the range handling of the compiler's f64 sqrt expansion: the same v_rsq_f64 start and the same
+// Newton steps (so the same bits for every operand the expansion does not rescale, i.e. above 2^-767), minus the compare /
+// ldexp pairs that rescale smaller operands -- squared lengths of mesh edges are nowhere near.  +-0 and +inf return
+// themselves, negative operands and NaN give NaN, as sqrt does.
+__device__ __forceinline__ double fsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = FMA(-h, g, 0.5);
+    g = FMA(g, r, g);
+    double d = FMA(-g, g, x);
+    h = FMA(h, r, h);
+    g = FMA(d, h, g);
+    d = FMA(-g, g, x);
+    g = FMA(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;      // +-0, +inf
+}
+__device__ __forceinline__ double norm3(const double *a) { return fsqrt(dot3(a, a)); }
 
 // IEEE division with a SHARED reciprocal: the same arithmetic as the compiler's f64 fdiv expansion
 // (v_rcp_f64, two Newton steps, quotient, residual, correction) minus the v_div_scale / v_div_fixup

@@ -193,13 +193,14 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
         bl[2][3] = 2.0 * (0.25 * (-s + 4.0 * aD * r * s));
         bl[2][4] = 2.0 * (1.0 + aE * r * s);
         double Te[3][3];
-        if (__builtin_fabs(detJ) < 1e-12) {  // MITC4.py:331-332
+        // MITC4.py:334-347
+        Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
+        Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
+        Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
+        const bool flat = __builtin_fabs(detJ) < 1e-12;  // MITC4.py:331-332 (a wave without such a lane skips the selects)
+        if (__any(flat)) {
             for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) Te[a][b] = (a == b) ? 1.0 : 0.0;
-        } else {  // MITC4.py:334-347
-            Te[0][0] = ia * ia; Te[0][1] = ic * ic; Te[0][2] = ia * ic;
-            Te[1][0] = ib * ib; Te[1][1] = id * id; Te[1][2] = ib * id;
-            Te[2][0] = 2.0 * ia * ib; Te[2][1] = 2.0 * ic * id; Te[2][2] = ia * id + ib * ic;
+                for (int b = 0; b < 3; b++) Te[a][b] = flat ? ((a == b) ? 1.0 : 0.0) : Te[a][b];
         }
         double W[3][5];
         for (int a = 0; a < 3; a++)
@@ -274,16 +275,16 @@ __device__ __forceinline__ void quad_stage1(const double (&x)[4][3], const fs_sh
             Cy = ((-xl[0][1] - xl[1][1]) + xl[2][1]) + xl[3][1];
         }
         // Rot = [[sin b, -sin a], [-cos b, cos a]], a = atan2(Ay,Ax), b = pi/2 - atan2(Cx,Cy)
-        const double nA = __builtin_sqrt(Ax * Ax + Ay * Ay), nC = __builtin_sqrt(Cx * Cx + Cy * Cy);
+        const double nA = fsqrt(Ax * Ax + Ay * Ay), nC = fsqrt(Cx * Cx + Cy * Cy);
         const double rnA = recip(nA), rnC = recip(nC);
         const double sa = divr(Ay, nA, rnA), ca = divr(Ax, nA, rnA), sb = divr(Cy, nC, rnC), cb = divr(Cx, nC, rnC);
         double r1, r2;
         {
 #pragma clang fp contract(off)
             const double p0 = Cx + xi * Bx, p1 = Cy + xi * By;
-            r1 = __builtin_sqrt(FMA(p1, p1, p0 * p0));
+            r1 = fsqrt(FMA(p1, p1, p0 * p0));
             const double q0 = Ax + eta * Bx, q1 = Ay + eta * By;
-            r2 = __builtin_sqrt(FMA(q1, q1, q0 * q0));
+            r2 = fsqrt(FMA(q1, q1, q0 * q0));
         }
         const double d8 = 8.0 * detJ, rd8 = recip(d8);
         const double f1 = divr(r1, d8, rd8), f2 = divr(r2, d8, rd8);
