@@ -140,7 +140,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_kernel(const double *__restr
                 inv[2][0] = divr(c02, det, rdet); inv[2][1] = divr(J[0][1] * J[2][0] - J[0][0] * J[2][1], det, rdet);
                 inv[2][2] = divr(J[0][0] * J[1][1] - J[0][1] * J[1][0], det, rdet);
             }
-            const double sw = __builtin_sqrt(det);          // weights are 1: w detJ = detJ
+            const double sw = fsqrt(det);                   // weights are 1: w detJ = detJ
             double2 *ga = s_a + slot * HX_SA + q * 8;
             double *gb = reinterpret_cast<double *>(s_b + slot * HX_SB + (q >> 1) * 8) + (q & 1);
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(HX_NT) void fused_hex8_mass_kernel(const double *__
             const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
                                J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
             const double rho = props[(int64_t)safe_pid(prop_id[e], n_props) * 37 + 36];
-            const double sw = __builtin_sqrt(rho * det);          // weights are 1
+            const double sw = fsqrt(rho * det);                   // weights are 1
             double *g = s_g + slot * HX_MS + q * 8;
 #pragma unroll
             for (int i = 0; i < 8; i++) g[i] = sw * N[i];
