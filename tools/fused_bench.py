@@ -41,6 +41,9 @@ def two():
 
 if os.environ.get("FUSED_BENCH_ONLY"):
     print("fused only: %.3f ms" % timed(asm.assemble_stiffness_fused, n=int(os.environ["FUSED_BENCH_ONLY"])))
+    if os.environ.get("FUSED_BENCH_STATUS"):       # the same with the status words written (what a bench step does)
+        st = torch.zeros(E, dtype=torch.int32, device="cuda")
+        print("fused with status: %.3f ms" % timed(lambda: asm.assemble_stiffness_fused(status=st), n=int(os.environ["FUSED_BENCH_ONLY"])))
     sys.exit(0)
 t2 = timed(two)
 tf = timed(asm.assemble_stiffness_fused)
