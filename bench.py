@@ -79,7 +79,7 @@ def pmc_traffic(full):
         d = tempfile.mkdtemp(prefix="femshell_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--pmc-child", "--steps", "2", "--warmup", "1"] + ([] if full else ["--strip-only"])
-        env = dict(os.environ, TMPDIR="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", FEMSHELL_BENCH_NO_PREWARM="1")      # (counters, not times)
         try:
             # own process group: a pass that hangs is killed with everything it started (the profiled python included)
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -636,6 +636,15 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
         torch.cuda.synchronize()
 
     K = None
+    # Steady clocks before the W warm-up steps: after an idle period the first ~35 ms of kernel time run up to 20 % slower
+    # (launch by launch in profiles/r03_launch_ramp.txt: 1.38 -> 1.55 -> 1.28 ms on the strip).  Three warm-up steps of the
+    # 10 M plate cover that, three of a strip (1.3 ms each) do not, and the curve over N would compare a warm GPU at N = 1
+    # with cold ones at N = 8.  So the same step runs untimed for about 100 ms first; the count depends on the strip size
+    # only (the same on every rank: the interface exchanges pair up) and is reported as config.prewarm_steps.
+    prewarm = 0 if os.environ.get("FEMSHELL_BENCH_NO_PREWARM") else min(100, int(np.ceil(0.1 / (E / 9.0e8))))
+    for _ in range(prewarm):
+        K = None
+        K = asm.assemble_stiffness_matrix(recompute=True)
     for _ in range(warmup):
         K = None                       # (the previous step's values go back to the allocator before the next 26 GB are taken)
         K = asm.assemble_stiffness_matrix(recompute=True)
@@ -660,6 +669,7 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
     # the kernel alone, HIP events on its stream, nothing else in flight (no exchange)
     k_ms = avg_ms(torch, lambda: local.assemble_stiffness_fused(), max(3, min(steps, 10)))
     res = {"E": E, "dt": dt, "kernel_ms": k_ms, "nx": nx, "ny": ny, "launch_stream_ms_per_step": stream_ms, "nnz": nnz,
+           "prewarm_steps": prewarm,
            "coupled_frac": float(np.mean((local._prop_table["flags"][local._prop_id] & 1) != 0)),
            "setup_s": {"mesh": t1 - t0, "assembler_symbolic_and_first_K": t2 - t1, "fused_plan": t3 - t2},
            "plan": local.fused_plan().stats(),
@@ -823,6 +833,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "elements_per_gpu": E, "nnz_per_gpu": r["nnz"],
                        "partition": f"x-strips x{world}" if world > 1 else "none",
+                       "prewarm_steps": r["prewarm_steps"],      # untimed, before the W warm-up steps (steady clocks: plate_run)
                        "setup_s_rank0": r["setup_s"], "device_memory_GB_rank0": r["device_memory_GB"],
                        "fused_plan": {k: r["plan"][k] for k in ("patches", "elements_per_patch", "stage1_recompute",
                                                                  "stage2_lane_fill", "record_bytes_per_element")},

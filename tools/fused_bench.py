@@ -1,6 +1,6 @@
 """Fused evaluate-and-assemble kernel vs element kernel + assembly kernel on the C5 strip (bench workload).
 usage: python tools/fused_bench.py [nx ny] [max_patch_elems]"""
-import sys, time, json
+import os, sys, time, json
 import numpy as np, torch
 sys.path.insert(0, '.')
 import bench
@@ -25,7 +25,9 @@ print("fused plan: %.2f s" % t_plan, json.dumps({k: round(v, 3) for k, v in fp.s
 
 
 def timed(fn, n=10):
-    for _ in range(3): fn()
+    # (the first ~25 launches after an idle period run up to 20 % slower -- clocks / power management; FUSED_BENCH_PREWARM=60
+    # times the steady state instead)
+    for _ in range(int(os.environ.get("FUSED_BENCH_PREWARM", "3"))): fn()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
