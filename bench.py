@@ -15,7 +15,9 @@ MITC4+ laminate plate (16 laminates in x-bands of 25 columns cycling over the pl
 configs[0..3] and the HEXA8 block of configs[4] are timed in their own legs outside `value`; tests/ holds their parity.
 
 Contract: python bench.py --gpus N --steps K --warmup W  (N > 1: launched by torch.distributed.run,
-one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  W untimed warm-up steps, then exactly K timed steps between
+barrier + synchronize; before the warm-up steps the same step runs untimed for about 100 ms (`config.prewarm_steps`,
+see plate_run: the GPU's clocks settle over ~35 ms of load, which is three steps of the plate and thirty of a strip).
 """
 import argparse
 import json
