@@ -668,8 +668,11 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
     nnz = int(K.nnz)
     if not distributed:
         K = None                                       # (not kept beside the next measurement's value arrays)
-    # the kernel alone, HIP events on its stream, nothing else in flight (no exchange)
-    k_ms = avg_ms(torch, lambda: local.assemble_stiffness_fused(), max(3, min(steps, 10)))
+    # the kernel alone, HIP events on its stream, nothing else in flight (no exchange): the launch of a step, status words
+    # written (they are among the algorithmic bytes; the 40 MB fill that zeroes them first is inside the events)
+    st = torch.zeros(E, dtype=torch.int32, device="cuda")
+    k_ms = avg_ms(torch, lambda: local.assemble_stiffness_fused(status=st), max(3, min(steps, 10)))
+    del st
     res = {"E": E, "dt": dt, "kernel_ms": k_ms, "nx": nx, "ny": ny, "launch_stream_ms_per_step": stream_ms, "nnz": nnz,
            "prewarm_steps": prewarm,
            "coupled_frac": float(np.mean((local._prop_table["flags"][local._prop_id] & 1) != 0)),

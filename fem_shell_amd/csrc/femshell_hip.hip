@@ -847,6 +847,7 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
     __shared__ int s_pid[NT * 16];
     __shared__ double2 s_stage[4 * FZ_SLOT * SP];   // per wave: SP staging slots of 21 x 16 bytes
     __shared__ unsigned char s_tab[4 * 128];        // per wave: rank of a transposed copy -> staging slot of its block
+    __shared__ int s_st[NT * 16], s_el[NT * 16];    // status word and element index of a slot (stored after stage 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // stage-1 lane map: stiffness -- Gauss point g of element Q on lane g * 16 + Q (row reductions, quad_stage1<true>);
     // mass -- lane 4 Q + g
@@ -966,7 +967,9 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 if (!FQ_ROWS)
                     for (int n = 0; n < 15; n++) ex[(IM_S + n) << 4] = el.S[n];
                 s_pid[slot] = pid | ((COUPLED && flagged) ? FS_SLOT_COUPLED : 0);
-                if (status && valid) status[e] = el.st | bad;     // halo elements: every patch writes the same value
+                // the status word waits in LDS for the end of the patch: stored from here, it would be one more vector-memory
+                // operation the stage-1 barrier's vmcnt(0) has to see acknowledged (1.5 % of a step)
+                s_st[slot] = valid ? (el.st | bad) : -1; s_el[slot] = (int)e;
             } else if (g == 1) {
                 for (int t = 0; t < 18; t++) ex[(IM_GT + t) << 4] = (&el.gt[0][0])[t];
             } else if (g == 2) {
@@ -1156,6 +1159,12 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                 __builtin_amdgcn_wave_barrier();
                 FS_TICK(16);
             }
+        }
+        // status words of the patch's elements, one store instruction behind the copy-out (halo elements: every patch
+        // writes the same value)
+        if (OP == FS_OP_K && status && wave == 0) {
+            const int st_ = s_st[lane];
+            if (lane < ne && st_ >= 0) status[s_el[lane]] = st_;
         }
         FS_TICK(5);
 #ifdef FS_FUSED_TIMING
