@@ -1037,6 +1037,13 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
             // of a block, X alone on a lane with two blocks and (R_left + x2) + x3 on a chained lane -- fma(1, a, b) is a + b
             // to the bit.  A chained lane at position pos is final from iteration pos on (its left neighbour was final one
             // iteration earlier), what it holds before is never read.
+            // last round: the next patch's coordinates are requested HERE, in front of the sums -- the vmcnt(0) between the
+            // staging writes and the stores waits for them, and requested behind the sums they were still on their way
+            // (strip 1.289 -> 1.260 ms; in front of the second evaluation the 24 registers they hold spill: 1.53 ms)
+            if (last_round) {
+                const double2 *xp = reinterpret_cast<const double2 *>(xyz + en_use * 12);
+                for (int t = 0; t < 6; t++) { const double2 v = xp[t]; xn[2 * t] = v.x; xn[2 * t + 1] = v.y; }
+            }
             const bool two = (fl & FS_FL_OUT1) != 0, chain = (fl & FS_FL_CHAIN) != 0;
             const int maxc = __builtin_amdgcn_readfirstlane((int)((fl >> 8) & 255u));
             const double mY = two ? 0.0 : 1.0, cT = chain ? 1.0 : 0.0;
@@ -1064,12 +1071,6 @@ __global__ __launch_bounds__(256) void fused_quad_k_kernel(const double *__restr
                                 Y[a * 6 + b] = m; Y[b * 6 + a] = m;
                             }
                 }
-            }
-            // last round: the image is no longer needed by this wave -- fetch the next patch's coordinates now, they
-            // arrive while the stores below are issued
-            if (last_round) {
-                const double2 *xp = reinterpret_cast<const double2 *>(xyz + en_use * 12);
-                for (int t = 0; t < 6; t++) { const double2 v = xp[t]; xn[2 * t] = v.x; xn[2 * t + 1] = v.y; }
             }
             FS_TICK(4);
             // ---- stores: through a wave-private LDS staging area.  Every block a lane emits goes to a slot (numbered by the
