@@ -43,6 +43,8 @@ def two():
 
 if os.environ.get("FUSED_BENCH_ONLY"):
     print("fused only: %.3f ms" % timed(asm.assemble_stiffness_fused, n=int(os.environ["FUSED_BENCH_ONLY"])))
+    if os.environ.get("FUSED_BENCH_MASS"):
+        print("fused mass: %.3f ms" % timed(asm.assemble_mass_fused, n=int(os.environ["FUSED_BENCH_ONLY"])))
     if os.environ.get("FUSED_BENCH_STATUS"):       # the same with the status words written (what a bench step does)
         st = torch.zeros(E, dtype=torch.int32, device="cuda")
         print("fused with status: %.3f ms" % timed(lambda: asm.assemble_stiffness_fused(status=st), n=int(os.environ["FUSED_BENCH_ONLY"])))
