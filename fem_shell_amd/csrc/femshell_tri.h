@@ -232,7 +232,10 @@ __device__ __forceinline__ void tri_pair_block(const double *fn, const double *g
     }
     // static condensation of the two bubble rotations (MITC3.py:958-1007)
     const double det = Kbb[0][0] * Kbb[1][1] - Kbb[0][1] * Kbb[1][0];
-    const double i00 = Kbb[1][1] / det, i01 = -Kbb[0][1] / det, i10 = -Kbb[1][0] / det, i11 = Kbb[0][0] / det;
+    // (four quotients over one reciprocal: the bits of the four IEEE divisions, femshell_geom.h)
+    const double rdet = recip(det);
+    const double i00 = divr(Kbb[1][1], det, rdet), i01 = divr(-Kbb[0][1], det, rdet), i10 = divr(-Kbb[1][0], det, rdet),
+                 i11 = divr(Kbb[0][0], det, rdet);
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
