@@ -650,9 +650,13 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
     # with cold ones at N = 8.  So the same step runs untimed for about 100 ms first; the count depends on the strip size
     # only (the same on every rank: the interface exchanges pair up) and is reported as config.prewarm_steps.
     prewarm = 0 if os.environ.get("FEMSHELL_BENCH_NO_PREWARM") else min(100, int(np.ceil(0.1 / (E / 9.0e8))))
-    for _ in range(prewarm):
+    for i in range(prewarm):
         K = None
         K = asm.assemble_stiffness_matrix(recompute=True)
+        if i % 8 == 7:                 # (untimed: keep the side-stream exchanges and the value arrays they hold from piling up)
+            if distributed:
+                asm.finish()
+            torch.cuda.synchronize()
     for _ in range(warmup):
         K = None                       # (the previous step's values go back to the allocator before the next 26 GB are taken)
         K = asm.assemble_stiffness_matrix(recompute=True)
