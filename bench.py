@@ -644,6 +644,20 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
         torch.cuda.synchronize()
 
     K = None
+    # Host-side flow control: the host enqueues a step in ~0.1 ms and would run the whole loop ahead of the GPU.  With the
+    # interface exchange on a side stream every step's value array stays reserved until ITS exchange has run, so a host that is
+    # 20 steps ahead holds 20 arrays (13 GB each at N = 2).  The host therefore stays at most two steps ahead (it waits for
+    # the event of the step before the previous one; the GPU queue never runs dry).
+    import collections
+    inflight = collections.deque()
+
+    def throttle():
+        ev = torch.cuda.Event()
+        ev.record()
+        inflight.append(ev)
+        if len(inflight) > 2:
+            inflight.popleft().synchronize()
+
     # Steady clocks before the W warm-up steps: after an idle period the first ~35 ms of kernel time run up to 20 % slower
     # (launch by launch in profiles/r03_launch_ramp.txt: 1.38 -> 1.55 -> 1.28 ms on the strip).  Three warm-up steps of the
     # 10 M plate cover that, three of a strip (1.3 ms each) do not, and the curve over N would compare a warm GPU at N = 1
@@ -660,13 +674,16 @@ def plate_run(torch, dist, rank, world, nx, ny, steps, warmup, distributed, retu
     for _ in range(warmup):
         K = None                       # (the previous step's values go back to the allocator before the next 26 GB are taken)
         K = asm.assemble_stiffness_matrix(recompute=True)
+        throttle()
     barrier()
+    inflight.clear()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0s = time.perf_counter()
     e0.record()
     for _ in range(steps):
         K = None
         K = asm.assemble_stiffness_matrix(recompute=True)
+        throttle()
     e1.record()
     barrier()
     dt = time.perf_counter() - t0s
