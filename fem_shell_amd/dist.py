@@ -379,7 +379,9 @@ class DistributedAssembler:
         """Owned rows of the returned CSR (see `owned_rows`) hold the globally assembled values;
         column j of the local matrix is global DOF d*nodes_g[j//d] + j%d (d = 6 shells, 3 solids).
         With overlap=True the caller's stream does NOT wait for the previous matrix's exchange: every call writes a
-        fresh value array, and the exchanges queue up in order on the side stream (finish() joins the last one)."""
+        fresh value array, and the exchanges queue up in order on the side stream (finish() joins the last one).  Every
+        queued exchange keeps its value array reserved (record_stream): a host loop that runs many calls ahead of the GPU
+        holds as many arrays -- stay a call or two ahead (an event per call, as bench.py::plate_run does)."""
         return self._exchange(self.local.assemble_stiffness_matrix(recompute=recompute))
 
     def assemble_mass_matrix(self, recompute=False):
