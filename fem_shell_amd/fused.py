@@ -15,6 +15,8 @@ uniform MITC4+ meshes by ONE launch that never writes element matrices to memory
 
 Everything here is integer bookkeeping on the symbolic plan (symbolic.BlockPlan); no floating-point work.
 """
+import os
+
 import numpy as np
 
 from .symbolic import _T16_RG
@@ -91,6 +93,24 @@ def _elements_per_patch(patch, conn, npat):
     return np.bincount(pc[first], minlength=npat)
 
 
+# Patch ids are numbered in TILES of PATCH_TILE[0] x PATCH_TILE[1] grid cells (numbering direction x the next one), not row
+# by row: the kernel gives the 32 workgroups of an XCD 32 CONSECUTIVE patches at a time, and the CSR lines and halo elements
+# a patch shares with its neighbours meet in that XCD's L2 only if the neighbours are at work at about the same time.  Row by
+# row, the vertical neighbours of a patch of the 10 M plate come 17 rounds later (534 patches per row) and the shared lines
+# travel to HBM twice: 10.13 ms per launch; 4 x 8 tiles 9.64 ms (2 x 8 ... 4 x 8 within 0.3 %, 8 x 2 10.03, whole columns 16 %
+# slower on the strip).  The order changes nothing in the result (every CSR entry has one writer).  FEMSHELL_PATCH_TILE=WxH
+# overrides it for experiments (tools/exp/tile_full.sh).
+PATCH_TILE = tuple(int(v) for v in os.environ.get("FEMSHELL_PATCH_TILE", "4x8").split("x"))
+
+
+def _tiled_patch_key(bi, bj, nbi):
+    """Sort key of grid cell (bi, bj) -- NumPy arrays or torch tensors -- in tiles of PATCH_TILE cells, tiles row by row,
+    cells row by row inside a tile."""
+    tw, th = PATCH_TILE
+    ntx = (nbi + tw - 1) // tw
+    return ((bj // th) * ntx + (bi // tw)) * (tw * th) + (bj % th) * tw + (bi % tw)
+
+
 def partition_nodes(coords, conn, max_elems=64):
     """node -> patch id (int64 [N]); the elements touching any patch number <= max_elems.
 
@@ -132,9 +152,12 @@ def partition_nodes(coords, conn, max_elems=64):
     nb = b[used].max(axis=0) + 1
     b = np.minimum(b, nb - 1)
     order_axes = [ax] + [k for k in range(nd) if k != ax]             # numbering axis fastest
-    key = np.zeros(N, dtype=np.int64)
-    for k in reversed(order_axes):
-        key = key * nb[k] + b[:, k]
+    if nd == 2:
+        key = _tiled_patch_key(b[:, order_axes[0]], b[:, order_axes[1]], int(nb[order_axes[0]]))
+    else:
+        key = np.zeros(N, dtype=np.int64)
+        for k in reversed(order_axes):
+            key = key * nb[k] + b[:, k]
     _, patch = np.unique(key, return_inverse=True)
     patch = patch.astype(np.int64)
     for _ in range(64):
@@ -199,7 +222,8 @@ def partition_nodes_device(n_nodes, conn_d, max_elems=64, as_host=True):
     bi = torch.where(used, (li - umin_i) // best[0], torch.zeros_like(li))
     bj = torch.where(used, (lj - umin_j) // best[1], torch.zeros_like(lj))
     nbi, nbj = int(bi[used].max()) + 1, int(bj[used].max()) + 1
-    key = torch.minimum(bj, torch.tensor(nbj - 1, device=conn.device)) * nbi + torch.minimum(bi, torch.tensor(nbi - 1, device=conn.device))
+    bi, bj = torch.clamp(bi, max=nbi - 1), torch.clamp(bj, max=nbj - 1)
+    key = _tiled_patch_key(bi, bj, nbi)
     _, patch = torch.unique(key, return_inverse=True)
     npat = int(patch.max()) + 1
     pc, _ = torch.sort(patch[conn], dim=1)
