@@ -121,6 +121,7 @@ class MeshAssembler:
         self._K_lin_csr = None    # values of the assembled linear K the Newton path works on (see _linear_csr)
         self._K_lin_packed = None # (those values, their packed upper block triangle): see _linear_packed
         self._fplan = self._fplan_d = None
+        self._fplan_m = self._fplan_m_d = None
         self._fplan_error = None
         self._precompute_elements()
         self._compute_sparsity_pattern()
@@ -458,29 +459,50 @@ class MeshAssembler:
                 self._fplan = FusedTriPlan(host_view(), self._conn, self._coords)
                 self._fused_flags = 0
             else:
-                g = self._groups[0]
-                # structured numbering: the node -> patch map is integer arithmetic on the device (None otherwise: the
-                # NumPy partition with its bisection pass takes over)
-                node_patch = partition_nodes_device(int(self.mesh.node_count), g["conn_d"], self.fused_max_patch_elems,
-                                                    as_host=not on_device)
-                self._fplan = None
-                if on_device:
-                    # the whole plan on the device (fs_fused_plan_device_begin / _finish); a mesh beyond its LDS capacities
-                    # goes through the host builder, every other failure is the mesh's (fused_ready() handles it)
-                    if node_patch is None:
-                        node_patch = torch.from_numpy(partition_nodes(self._coords, self._conn, self.fused_max_patch_elems))
-                    try:
-                        self._fplan = FusedQuadPlanDevice(p, g["conn_d"], node_patch, self.fused_max_patch_elems)
-                    except _lib.FemShellHipError as exc:
-                        if "capacity" not in str(exc):
-                            raise
-                        node_patch = node_patch.cpu().numpy()
-                if self._fplan is None:
-                    self._fplan = FusedQuadPlan(host_view(), self._conn, self._coords,
-                                                max_patch_elems=self.fused_max_patch_elems, node_patch=node_patch)
+                self._fplan = self._build_quad_plan(None)
                 self._fused_flags = _lib.FS_FUSED_HAS_COUPLED if (self._prop_table["flags"] & 1).any() else 0
             self._fplan_d = self._fplan.to_device(self.device)
         return self._fplan
+
+    def _build_quad_plan(self, tile):
+        """FusedQuadPlan(Device) with the patch ids in `tile` order (fused.PATCH_TILE when None)."""
+        from types import SimpleNamespace
+        from .fused import FusedQuadPlan, FusedQuadPlanDevice, partition_nodes, partition_nodes_device
+        p, g = self._plan, self._groups[0]
+        on_device = not isinstance(p.nbr_ptr, np.ndarray)
+        # structured numbering: the node -> patch map is integer arithmetic on the device (None otherwise: the
+        # NumPy partition with its bisection pass takes over)
+        node_patch = partition_nodes_device(int(self.mesh.node_count), g["conn_d"], self.fused_max_patch_elems,
+                                            as_host=not on_device, tile=tile)
+        fplan = None
+        if on_device:
+            # the whole plan on the device (fs_fused_plan_device_begin / _finish); a mesh beyond its LDS capacities
+            # goes through the host builder, every other failure is the mesh's (fused_ready() handles it)
+            if node_patch is None:
+                node_patch = torch.from_numpy(partition_nodes(self._coords, self._conn, self.fused_max_patch_elems, tile=tile))
+            try:
+                fplan = FusedQuadPlanDevice(p, g["conn_d"], node_patch, self.fused_max_patch_elems)
+            except _lib.FemShellHipError as exc:
+                if "capacity" not in str(exc):
+                    raise
+                node_patch = node_patch.cpu().numpy()
+        if fplan is None:
+            host = p if not on_device else SimpleNamespace(d=p.d, n_nodes=p.n_nodes, nbr_ptr=p.nbr_ptr.cpu().numpy(),
+                                                           nbr=p.nbr.cpu().numpy())
+            fplan = FusedQuadPlan(host, self._conn, self._coords, max_patch_elems=self.fused_max_patch_elems,
+                                  node_patch=node_patch)
+        return fplan
+
+    def _mass_plan(self):
+        """(plan, device arrays) the fused MASS operator of a quad mesh runs on: the same patches numbered row by row
+        (fused.PATCH_TILE explains why), built on first use; the stiffness plan itself when that is row by row already."""
+        from . import fused
+        if tuple(fused.PATCH_TILE) == (1, 1):
+            return self._fplan, self._fplan_d
+        if getattr(self, "_fplan_m", None) is None:
+            self._fplan_m = self._build_quad_plan((1, 1))
+            self._fplan_m_d = self._fplan_m.to_device(self.device)
+        return self._fplan_m, self._fplan_m_d
 
     def fused_ready(self):
         """True when the fused route can run on this mesh.  The patch plan has limits the two-kernel route does not
@@ -544,6 +566,8 @@ class MeshAssembler:
                                                  _lib.ptr(d["pat_lptr"]), _lib.ptr(d["steps"]), _lib.ptr(data),
                                                  _lib.ptr(status), _lib.stream_ptr()), "fs_fused_assemble_tri")
             return CsrMatrix(self._indptr, self._indices, data, (self.dofs_count, self.dofs_count))
+        if mass:
+            fp, d = self._mass_plan()        # the same patches, numbered row by row
         _lib.check(lib.fs_fused_assemble_quad(_lib.ptr(g["xyz_d"]), _lib.ptr(g["pid_d"]), _lib.ptr(self._props_d),
                                               len(self._prop_table), g["E"], fp.n_patches, _lib.ptr(d["pat_eptr"]),
                                               _lib.ptr(d["pat_elems"]), _lib.ptr(d["pat_rptr"]), _lib.ptr(d["recs"]),

@@ -98,25 +98,27 @@ def _elements_per_patch(patch, conn, npat):
 # a patch shares with its neighbours meet in that XCD's L2 only if the neighbours are at work at about the same time.  Row by
 # row, the vertical neighbours of a patch of the 10 M plate come 17 rounds later (534 patches per row) and the shared lines
 # travel to HBM twice: 10.13 ms per launch; 4 x 8 tiles 9.64 ms (2 x 8 ... 4 x 8 within 0.3 %, 8 x 2 10.03, whole columns 16 %
-# slower on the strip).  The order changes nothing in the result (every CSR entry has one writer).  FEMSHELL_PATCH_TILE=WxH
-# overrides it for experiments (tools/exp/tile_full.sh).
+# slower on the strip).  The order changes nothing in the result (every CSR entry has one writer).  The MASS operator of the
+# same kernel, all stores and hardly any arithmetic, is 6-19 % slower on any tiled order (strip: 0.958 ms row by row, 1.088
+# in 4 x 8 tiles), so MeshAssembler keeps a second, row-by-row plan for it (tile=(1, 1)).  FEMSHELL_PATCH_TILE=WxH overrides
+# the stiffness order for experiments (tools/exp/tile_full.sh, tile_ab.sh).
 PATCH_TILE = tuple(int(v) for v in os.environ.get("FEMSHELL_PATCH_TILE", "4x8").split("x"))
 
 
-def _tiled_patch_key(bi, bj, nbi):
-    """Sort key of grid cell (bi, bj) -- NumPy arrays or torch tensors -- in tiles of PATCH_TILE cells, tiles row by row,
-    cells row by row inside a tile."""
-    tw, th = PATCH_TILE
+def _tiled_patch_key(bi, bj, nbi, tile=None):
+    """Sort key of grid cell (bi, bj) -- NumPy arrays or torch tensors -- in tiles of `tile` (default PATCH_TILE) cells, tiles
+    row by row, cells row by row inside a tile; (1, 1) is the plain row-by-row order."""
+    tw, th = tile or PATCH_TILE
     ntx = (nbi + tw - 1) // tw
     return ((bj // th) * ntx + (bi // tw)) * (tw * th) + (bj % th) * tw + (bi % tw)
 
 
-def partition_nodes(coords, conn, max_elems=64):
+def partition_nodes(coords, conn, max_elems=64, tile=None):
     """node -> patch id (int64 [N]); the elements touching any patch number <= max_elems.
 
     Grid binning: cells of a x b nodes, a (<= GRID_NODES) along the direction in which consecutive node indices run
     and a b as large as (a + 1)(b + 1) <= max_elems allows (6 x 8 nodes / 63 elements for 64; patch ids follow the
-    grid, so consecutive patches are spatial neighbours), then recursive median bisection, along the longest
+    grid in tiles of PATCH_TILE cells, so that 32 consecutive patches are a compact block of neighbours), then recursive median bisection, along the longest
     extent, of the patches that still touch too many elements.  The grid lives on the (i, j) lattice of the node
     numbering when the mesh is numbered like a structured grid (curved shells: the patches follow the mesh lines),
     otherwise on the coordinates with the mean element edge as spacing.  Any mesh works; compact patches recompute
@@ -153,7 +155,7 @@ def partition_nodes(coords, conn, max_elems=64):
     b = np.minimum(b, nb - 1)
     order_axes = [ax] + [k for k in range(nd) if k != ax]             # numbering axis fastest
     if nd == 2:
-        key = _tiled_patch_key(b[:, order_axes[0]], b[:, order_axes[1]], int(nb[order_axes[0]]))
+        key = _tiled_patch_key(b[:, order_axes[0]], b[:, order_axes[1]], int(nb[order_axes[0]]), tile)
     else:
         key = np.zeros(N, dtype=np.int64)
         for k in reversed(order_axes):
@@ -187,7 +189,7 @@ def partition_nodes(coords, conn, max_elems=64):
     raise RuntimeError("partition_nodes did not converge")
 
 
-def partition_nodes_device(n_nodes, conn_d, max_elems=64, as_host=True):
+def partition_nodes_device(n_nodes, conn_d, max_elems=64, as_host=True, tile=None):
     """partition_nodes for meshes numbered like a structured grid, on the device (torch integer plumbing, the same
     arithmetic: lattice test, grid binning with patch ids in grid order).  Returns the int64 [N] map as a HOST array (as a
     device tensor with as_host=False), or
@@ -223,7 +225,7 @@ def partition_nodes_device(n_nodes, conn_d, max_elems=64, as_host=True):
     bj = torch.where(used, (lj - umin_j) // best[1], torch.zeros_like(lj))
     nbi, nbj = int(bi[used].max()) + 1, int(bj[used].max()) + 1
     bi, bj = torch.clamp(bi, max=nbi - 1), torch.clamp(bj, max=nbj - 1)
-    key = _tiled_patch_key(bi, bj, nbi)
+    key = _tiled_patch_key(bi, bj, nbi, tile)
     _, patch = torch.unique(key, return_inverse=True)
     npat = int(patch.max()) + 1
     pc, _ = torch.sort(patch[conn], dim=1)
@@ -637,6 +639,7 @@ def partition_nodes_tri(coords, conn, max_elems=176, max_nodes=96, max_lanes=256
     b = np.clip(np.floor((cc - lo) / side).astype(np.int64), 0, None)
     nb = b[used].max(axis=0) + 1
     b = np.minimum(b, nb - 1)
+    # (row by row: the 4 x 8 tiles of the quad plan make this kernel, whose CUs hold several workgroups, 3 % slower)
     key = np.zeros(N, dtype=np.int64)
     for k in reversed([ax] + [k for k in range(nd) if k != ax]):
         key = key * nb[k] + b[:, k]
